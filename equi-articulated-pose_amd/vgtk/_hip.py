@@ -1,0 +1,141 @@
+"""ctypes binding of libeap_hip.so -- the C ABI declared in include/eap_hip.h.
+
+PyTorch is used for device memory and streams only: every call takes torch tensors, checks
+them the way the reference's C++ wrappers do (device + contiguous, e.g.
+vgtk/vgtk/cuda/zpconv_cuda.cpp:L37-39 CHECK_INPUT -> RuntimeError), and launches on the
+CURRENT torch stream of the tensor's device (the reference launches on the legacy default
+stream with no device guard, zpconv_cuda_kernel.cu:L219).
+
+There is NO CPU or eager fallback: if the shared library is missing this module raises at
+import, and non-device tensors are rejected.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+LIB_PATH = os.path.join(_PKG_ROOT, 'libeap_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} not found: build the HIP extension first '
+        '(python -c "import __graft_entry__ as g; g.build()" or make -C equi-articulated-pose_amd/csrc). '
+        'This package has no CPU fallback.')
+
+lib = ctypes.CDLL(LIB_PATH)
+lib.eap_last_error.restype = ctypes.c_char_p
+lib.eap_gemm_f32_reduce_workspace.restype = ctypes.c_int64
+
+_I64 = ctypes.c_int64
+_F32 = ctypes.c_float
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def check_input(*tensors):
+    """CHECK_INPUT of the reference C++ wrappers: device tensor + contiguous."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('tensor must be a CUDA(HIP) tensor')
+        if not t.is_contiguous():
+            raise RuntimeError('tensor must be contiguous')
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def call(name, ref_tensor, *args):
+    """Invoke lib.<name>(*args, stream) under the device of `ref_tensor`; raise on error."""
+    fn = getattr(lib, name)
+    with torch.cuda.device(ref_tensor.device):
+        rc = fn(*args, stream_of(ref_tensor))
+    if rc != 0:
+        raise RuntimeError(f'{name} failed (hip error {rc}): {lib.eap_last_error().decode()}')
+
+
+def suffix(t):
+    if t.dtype == torch.float32:
+        return 'f32'
+    if t.dtype == torch.float64:
+        return 'f64'
+    raise RuntimeError(f'unsupported dtype {t.dtype} (float32 / float64 only)')
+
+
+# ---- raw launchers used by the operator layer ---------------------------------------------------
+
+def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch):
+    call('eap_gemm_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
+         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch)
+
+
+def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch):
+    n_ws = lib.eap_gemm_f32_reduce_workspace(M, N, K, batch)
+    ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=C.device)
+    call('eap_gemm_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
+         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws))
+
+
+def so3_prep(q_xyz, s_xyz, idx, q_pose, s_pose, anchors, identity_anchor):
+    b, _, p = q_xyz.shape
+    n = s_xyz.shape[2]
+    nn = idx.shape[2]
+    gx = torch.empty(b, p, nn, 4, dtype=torch.float32, device=q_xyz.device)
+    call('eap_so3_prep_f32', gx, b, p, n, nn, anchors.shape[0], _ptr(q_xyz), _ptr(s_xyz), _ptr(idx),
+         _ptr(q_pose), _ptr(s_pose), _ptr(anchors), int(identity_anchor), _ptr(gx))
+    return gx
+
+
+def so3_inter_weights(gx, rk, sigma):
+    b, p, nn, _ = gx.shape
+    na, ks, _ = rk.shape
+    w = torch.empty(b, p, na, ks, nn, dtype=torch.float32, device=gx.device)
+    call('eap_so3_inter_weights_f32', w, b, p, nn, na, ks, _F32(sigma), _ptr(gx), _ptr(rk), _ptr(w))
+    return w
+
+
+def so3_anchor_perm(gx, mult):
+    b, p, nn, _ = gx.shape
+    na = mult.shape[0]
+    perm = torch.empty(b, p, nn, na, dtype=torch.int64, device=gx.device)
+    call('eap_so3_anchor_perm', gx, b, p, nn, na, _ptr(gx), _ptr(mult), _ptr(perm))
+    return perm
+
+
+def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma):
+    b, c, n, na = feats.shape
+    p, nn = idx.shape[1], idx.shape[2]
+    ks = rk.shape[1]
+    out = torch.empty(b, c, ks, p, na, dtype=torch.float32, device=feats.device)
+    call('eap_so3_inter_group_fwd_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
+         _ptr(gx), _ptr(rk), _ptr(mult), _ptr(out))
+    return out
+
+
+def so3_inter_group_bwd(gout, idx, gx, rk, mult, sigma, n):
+    b, c, ks, p, na = gout.shape
+    nn = idx.shape[2]
+    gfeats = torch.empty(b, c, n, na, dtype=torch.float32, device=gout.device)
+    call('eap_so3_inter_group_bwd_f32', gfeats, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(gout), _ptr(idx),
+         _ptr(gx), _ptr(rk), _ptr(mult), _ptr(gfeats))
+    return gfeats
+
+
+def so3_intra_group_fwd(feats, intra_idx):
+    b, c, p, na = feats.shape
+    t = intra_idx.shape[1]
+    out = torch.empty(b, c, t, p, na, dtype=torch.float32, device=feats.device)
+    call('eap_so3_intra_group_fwd_f32', out, b, c, p, na, t, _ptr(feats), _ptr(intra_idx), _ptr(out))
+    return out
+
+
+def so3_intra_group_bwd(gout, intra_idx):
+    b, c, t, p, na = gout.shape
+    gfeats = torch.empty(b, c, p, na, dtype=torch.float32, device=gout.device)
+    call('eap_so3_intra_group_bwd_f32', gfeats, b, c, p, na, t, _ptr(gout), _ptr(intra_idx), _ptr(gfeats))
+    return gfeats

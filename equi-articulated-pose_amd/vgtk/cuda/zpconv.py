@@ -1,0 +1,60 @@
+"""vgtk.cuda.zpconv -- replaces the pybind module of vgtk/vgtk/cuda/zpconv_cuda.cpp."""
+import torch
+
+from .. import _hip
+
+
+def _check(idx, w, x):
+    _hip.check_input(idx, w, x)
+    if idx.dtype != torch.int32:
+        raise RuntimeError('zpconv: neighbour index must be int32')
+    if w.dtype != x.dtype:
+        raise RuntimeError('zpconv: weights and features must have the same dtype')
+
+
+def inter_zpconv_forward(idx, w, feats):
+    """(idx int32 [B,P,A,K,ANN], w T [B,P,A,K,ANN], feats T [B,C,Q,A]) -> T [B,C,K,P,A];
+    zpconv_cuda.cpp:L41-56."""
+    _check(idx, w, feats)
+    b, np_, na, ks, ann = idx.shape
+    c, nq = feats.shape[1], feats.shape[2]
+    out = torch.empty(b, c, ks, np_, na, dtype=feats.dtype, device=feats.device)
+    _hip.call('eap_inter_zpconv_fwd_' + _hip.suffix(feats), out, b, np_, nq, na, ks, ann, c,
+              _hip._ptr(idx), _hip._ptr(w), _hip._ptr(feats), _hip._ptr(out))
+    return out
+
+
+def inter_zpconv_backward(idx, w, grad, npoint):
+    """(idx, w, grad T [B,C,K,P,A], int npoint) -> T [B,C,npoint,A]; zpconv_cuda.cpp:L58-75."""
+    _check(idx, w, grad)
+    b, np_, na, ks, ann = idx.shape
+    c = grad.shape[1]
+    out = torch.empty(b, c, int(npoint), na, dtype=grad.dtype, device=grad.device)
+    _hip.call('eap_inter_zpconv_bwd_' + _hip.suffix(grad), out, b, np_, int(npoint), na, ks, ann, c,
+              _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
+    return out
+
+
+def intra_zpconv_forward(idx, w, feats):
+    """(idx int32 [A_out,ANN], w T [A_out,K,ANN], feats T [B,C,P,A_in]) -> T [B,C,K,P,A_out];
+    zpconv_cuda.cpp:L77-92."""
+    _check(idx, w, feats)
+    na_out, ann = idx.shape
+    ks = w.shape[1]
+    b, c, np_, na_in = feats.shape
+    out = torch.empty(b, c, ks, np_, na_out, dtype=feats.dtype, device=feats.device)
+    _hip.call('eap_intra_zpconv_fwd_' + _hip.suffix(feats), out, b, np_, na_in, na_out, ks, ann, c,
+              _hip._ptr(idx), _hip._ptr(w), _hip._ptr(feats), _hip._ptr(out))
+    return out
+
+
+def intra_zpconv_backward(idx, w, grad, anchor_in):
+    """(idx, w, grad T [B,C,K,P,A_out], int anchor_in) -> T [B,C,P,anchor_in]; zpconv_cuda.cpp:L94-110."""
+    _check(idx, w, grad)
+    na_out, ann = idx.shape
+    ks = w.shape[1]
+    b, c, _, np_, _ = grad.shape
+    out = torch.empty(b, c, np_, int(anchor_in), dtype=grad.dtype, device=grad.device)
+    _hip.call('eap_intra_zpconv_bwd_' + _hip.suffix(grad), out, b, np_, int(anchor_in), na_out, ks, ann, c,
+              _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
+    return out

@@ -1,0 +1,3 @@
+from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose  # noqa: F401
+from .functional import *  # noqa: F401,F403
+from .modules import *  # noqa: F401,F403

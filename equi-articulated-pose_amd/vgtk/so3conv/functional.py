@@ -1,0 +1,311 @@
+"""vgtk.so3conv.functional -- operator layer of the SE(3)-equivariant point convolution
+(reference: vgtk/vgtk/so3conv/functional.py).  Same function names, argument order and return
+structures as the reference; the compute runs in libeap_hip.so (HIP, gfx950):
+
+    ball_query -> so3_prep (offsets, relative-rotation anchor) -> fused grouping
+    (kernel weights + anchor permutation + gather + weighted sum) -> fp32-MFMA contraction
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * `inter_w` is returned as a lazy `InterWeights` handle; call `.materialize()` (or set
+    vgtk.so3conv.functional.MATERIALIZE_INTER_W = True) to get the [b,p,na,ks,nn] tensor the
+    reference always builds (12 GB at B=8, P=4096).  Callers in SPConvNets only hand it back to
+    the next conv, which ignores it for stride 1 (functional.py:L1025ff recomputes everything).
+  * gradients flow to `feats` and `W` (what the reference trains); xyz / pose are treated as data.
+  * float32 device tensors only -- there is no CPU path.
+"""
+import os
+
+import numpy as np
+import torch
+
+import vgtk
+import vgtk.functional as fr
+import vgtk.pc as pctk
+import vgtk.spconv as zpconv
+import vgtk.cuda.grouping as cuda_nn
+
+from .. import _hip
+
+inter_so3conv_feat_grouping = zpconv.inter_zpconv_grouping_naive
+batched_index_select = zpconv.batched_index_select
+batched_index_select_other = zpconv.batched_index_select_other
+
+MATERIALIZE_INTER_W = False
+
+# ------------------------------------------------------------------------------------------------
+# constants (functional.py:L111-121, L2630-2659)
+# ------------------------------------------------------------------------------------------------
+GAMMA_SIZE = 3
+ROOT = vgtk.__path__[0]
+Rs, R_idx, canonical_relative = fr.icosahedron_so3(GAMMA_SIZE)
+_KP = np.load(os.path.join(ROOT, 'data', 'anchors', 'constants.npz'))
+
+
+def select_anchor(anchors, k):
+    if k == 1:
+        return anchors[29][None]
+    elif k == 20:
+        return anchors[::3]
+    elif k == 40:
+        return anchors.reshape(20, 3, 3, 3)[:, :2].reshape(-1, 3, 3)
+    return anchors
+
+
+def get_anchors(k=60):
+    return select_anchor(Rs, k)
+
+
+def get_intra_idx():
+    return R_idx
+
+
+def get_canonical_relative():
+    return canonical_relative
+
+
+def get_sphereical_kernel_points_from_ply(radius, kernel_size):
+    """kernel_size 1/2/3 -> 24/30/66 kernel points rescaled so the max norm is `radius`."""
+    assert 0 < kernel_size <= 3
+    pts = _KP['kpsphere%d' % {1: 24, 2: 30, 3: 66}[kernel_size]].astype('float32')
+    r = np.sqrt((pts ** 2).sum(1).max())
+    return pts * radius / r
+
+
+def get_occupancy_features(pc, n_anchor, use_center=False):
+    """pc [nb,np,3] -> ones [nb,1,np,na] (functional.py:L50-69; normals are not supported --
+    the reference branch for them is broken: `ns.anchors` at L61)."""
+    nb, np_, nd = pc.shape
+    if nd != 3:
+        raise NotImplementedError('get_occupancy_features: xyz-only point clouds')
+    features = torch.ones(nb, 1, np_, n_anchor, dtype=torch.float32, device=pc.device)
+    if use_center:
+        features[:, :, 0, :] = 0.0
+    return features
+
+
+# ------------------------------------------------------------------------------------------------
+# per-(anchor set, kernel set, device) tables
+# ------------------------------------------------------------------------------------------------
+_TABLES = {}
+
+
+def _group_tables(anchors):
+    """mult table (uint8 [na,na]) + identity index when `anchors` is a group, else (None, None)."""
+    key = (anchors.data_ptr(), anchors.device, anchors.shape[0])
+    hit = _TABLES.get(key)
+    if hit is not None:
+        return hit
+    A = anchors.detach().double().cpu().numpy()
+    na = A.shape[0]
+    prod = np.einsum('gij,ajk->gaik', A, A)
+    score = np.einsum('gaij,cij->gac', prod, A)
+    mult = score.argmax(-1)
+    closed = np.allclose(score.max(-1), 3.0, atol=1e-4)
+    ident = int(np.einsum('cii->c', A).argmax())
+    has_identity = np.allclose(A[ident], np.eye(3), atol=1e-5)
+    if closed and has_identity:
+        out = (torch.from_numpy(mult.astype(np.uint8)).to(anchors.device).contiguous(), ident)
+    else:
+        out = (None, None)
+    _TABLES[key] = out
+    return out
+
+
+def rotated_kernels(anchors, kernels):
+    """rk [na,ks,3] = A_a kappa_k  (functional.py:L2519)."""
+    return torch.matmul(anchors, kernels.transpose(0, 1)).permute(0, 2, 1).contiguous()
+
+
+class InterWeights:
+    """Lazy stand-in for the reference's inter_w [b,p,na,ks,nn] (functional.py:L2508-2549)."""
+
+    def __init__(self, gx, rk, sigma):
+        self.gx, self.rk, self.sigma = gx, rk, float(sigma)
+
+    @property
+    def shape(self):
+        b, p, nn, _ = self.gx.shape
+        return torch.Size((b, p, self.rk.shape[0], self.rk.shape[1], nn))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def materialize(self):
+        return _hip.so3_inter_weights(self.gx, self.rk, self.sigma)
+
+
+def _as_gx(grouped_xyz):
+    """[b,3,p,nn] -> float4 [b,p,nn,4] with r = 0."""
+    b, _, p, nn = grouped_xyz.shape
+    gx = torch.zeros(b, p, nn, 4, dtype=torch.float32, device=grouped_xyz.device)
+    gx[..., :3] = grouped_xyz.permute(0, 2, 3, 1)
+    return gx
+
+
+def inter_so3conv_grouping_anchor(grouped_xyz, anchors, kernels, sigma, interpolate='linear'):
+    """grouped_xyz [b,3,p,nn] -> materialised w [b,p,na,ks,nn] = relu(1 - |g - A_a k|^2/sigma)
+    (functional.py:L2508-2549)."""
+    if interpolate != 'linear':
+        raise NotImplementedError('kernel function %s is not implemented!' % interpolate)
+    _hip.check_input(grouped_xyz)
+    return _hip.so3_inter_weights(_as_gx(grouped_xyz), rotated_kernels(anchors, kernels), float(sigma))
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd ops
+# ------------------------------------------------------------------------------------------------
+class _InterGroup(torch.autograd.Function):
+    """new_feats[b,c,k,p,a] = sum_n feats[b,c,idx_n,perm_n(a)] w(p,a,k,n)  (functional.py:L1221-1261)."""
+
+    @staticmethod
+    def forward(ctx, feats, idx, gx, rk, mult, sigma):
+        feats = feats.contiguous()
+        ctx.save_for_backward(idx, gx, rk, mult if mult is not None else torch.empty(0))
+        ctx.has_mult = mult is not None
+        ctx.sigma = sigma
+        ctx.n = feats.shape[2]
+        return _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma)
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, gx, rk, mult = ctx.saved_tensors
+        g = _hip.so3_inter_group_bwd(gout.contiguous(), idx, gx, rk, mult if ctx.has_mult else None,
+                                     ctx.sigma, ctx.n)
+        return g, None, None, None, None, None
+
+
+class _IntraGroup(torch.autograd.Function):
+    """out[b,c,t,p,a] = feats[b,c,p,intra_idx[a,t]]  (functional.py:L2553-2602)."""
+
+    @staticmethod
+    def forward(ctx, feats, intra_idx32):
+        ctx.save_for_backward(intra_idx32)
+        return _hip.so3_intra_group_fwd(feats.contiguous(), intra_idx32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        intra_idx32, = ctx.saved_tensors
+        return _hip.so3_intra_group_bwd(gout.contiguous(), intra_idx32), None
+
+
+class _Contract(torch.autograd.Function):
+    """y[b,o,pa] = W[o,ck] x[b,ck,pa] on the matrix cores (BasicSO3Conv, modules.py:L48-55)."""
+
+    @staticmethod
+    def forward(ctx, W, x):
+        W = W.contiguous()
+        x = x.contiguous()
+        b, ck, pa = x.shape
+        o = W.shape[0]
+        y = torch.empty(b, o, pa, dtype=torch.float32, device=x.device)
+        _hip.gemm(0, 0, o, pa, ck, W, ck, 0, x, pa, ck * pa, y, pa, o * pa, b)
+        ctx.save_for_backward(W, x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, x = ctx.saved_tensors
+        gy = gy.contiguous()
+        b, ck, pa = x.shape
+        o = W.shape[0]
+        gW = gx = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.empty_like(x)          # W^T gy : [ck,o] [o,pa]
+            _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy, pa, o * pa, gx, pa, ck * pa, b)
+        if ctx.needs_input_grad[0]:
+            gW = torch.empty_like(W)          # sum_b gy_b x_b^T : [o,pa] [pa,ck]
+            _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)
+        return gW, gx
+
+
+def so3_contract(W, x):
+    """W [O, C*K], x [b, C*K, P*A] -> [b, O, P*A]."""
+    _hip.check_input(x)
+    if x.dtype != torch.float32 or W.dtype != torch.float32:
+        raise RuntimeError('so3_contract: float32 only')
+    if not W.is_cuda:
+        raise RuntimeError('so3_contract: W must be a device tensor')
+    return _Contract.apply(W, x)
+
+
+# ------------------------------------------------------------------------------------------------
+# grouping entry points
+# ------------------------------------------------------------------------------------------------
+def _check_stride(stride, pooling, feats):
+    if stride != 1:
+        raise NotImplementedError(
+            'stride > 1 (furthest-point-sampled centres) is outside the accelerated path: the shipped '
+            'models force stride 1 (SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L2191)')
+
+
+def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, permute):
+    if feats.dtype != torch.float32 or xyz.dtype != torch.float32:
+        raise RuntimeError('so3conv: float32 only')
+    _hip.check_input(xyz)
+    if not feats.is_cuda:
+        raise RuntimeError('so3conv: feats must be a device tensor')
+    ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
+    rk = rotated_kernels(anchors, kernels)
+    mult = ident = None
+    rot = None
+    if pose is not None:
+        rot = pose.contiguous()
+        if rot.shape[-2:] != (4, 4) or rot.dtype != torch.float32:
+            raise RuntimeError('so3conv: pose must be float32 [b,p,4,4]')
+        if permute:
+            mult, ident = _group_tables(anchors)
+            if mult is None:
+                raise NotImplementedError(
+                    'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
+    gx = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma))
+    inter_w = InterWeights(gx, rk, sigma)
+    return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), new_feats
+
+
+def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, radius, sigma,
+                           inter_idx=None, inter_w=None, lazy_sample=True, radius_expansion=1.0,
+                           pooling=None):
+    """Pose-free grouping (functional.py:L144-203), stride 1.
+    -> inter_idx [b,p,nn], inter_w, new_xyz, new_feats [b,c,ks,p,na], sample_idx."""
+    _check_stride(stride, pooling, feats)
+    if inter_idx is None:
+        inter_idx, inter_w, new_feats = _inter_group(xyz, None, feats, n_neighbor, anchors, kernels,
+                                                     radius * radius_expansion, sigma, False)
+        sample_idx = torch.arange(xyz.shape[2], dtype=torch.long, device=xyz.device).unsqueeze(0).repeat(xyz.shape[0], 1)
+        return inter_idx, inter_w, xyz, new_feats, sample_idx
+    # cached neighbourhood from an earlier layer (functional.py:L195-201)
+    if isinstance(inter_w, InterWeights):
+        new_feats = _InterGroup.apply(feats, inter_idx, inter_w.gx, inter_w.rk, None, inter_w.sigma)
+    else:
+        new_feats = inter_so3conv_feat_grouping(inter_idx, inter_w, zpconv.add_shadow_feature(feats))
+    return inter_idx, inter_w, xyz, new_feats, None
+
+
+def inter_so3poseconv_grouping_strided(xyz, pose, feats, stride, n_neighbor, anchors, kernels, radius,
+                                       sigma, inter_idx=None, inter_w=None, lazy_sample=True,
+                                       radius_expansion=1.0, pooling=None, permute_modes=0):
+    """Pose-aware grouping, stride-1 branch of functional.py:L896-1286 (the neighbourhood is
+    recomputed on every call, exactly like the reference: passed-in inter_idx / inter_w are
+    ignored and handed back unchanged).
+    -> inter_idx (as passed in), inter_w, new_xyz, new_feats [b,c,ks,p,na], sample_idx (None),
+       sampled_pose."""
+    _check_stride(stride, pooling, feats)
+    _, w, new_feats = _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma,
+                                   permute_modes != 0)
+    return inter_idx, w, xyz, new_feats, None, pose
+
+
+def intra_so3conv_grouping(intra_idx, feature):
+    """intra_idx [na,pnn], feature [nb,c,np,na] -> [nb,c,pnn,np,na] (functional.py:L2553-2602)."""
+    if feature.dtype != torch.float32 or not feature.is_cuda:
+        raise RuntimeError('intra_so3conv_grouping: float32 device tensors only')
+    return _IntraGroup.apply(feature, intra_idx.to(torch.int32).contiguous())
+
+
+def anchor_permutation_index(xyz, pose, n_neighbor, anchors, radius):
+    """The reference's rotated_anchor_idx int64 [b,p,nn,na] (functional.py:L1199-1204); test hook."""
+    ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
+    mult, ident = _group_tables(anchors)
+    gx = _hip.so3_prep(xyz, xyz, ball_idx, pose.contiguous(), pose.contiguous(), anchors.contiguous(), ident)
+    return _hip.so3_anchor_perm(gx, mult)

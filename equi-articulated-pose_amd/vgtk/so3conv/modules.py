@@ -1,0 +1,159 @@
+"""vgtk.so3conv.modules -- nn.Modules of the SO(3) convolution (reference:
+vgtk/vgtk/so3conv/modules.py).  Parameter / buffer names and shapes match the reference
+(`basic_conv.W` [O, C*K], `anchors`, `kernels`, `intra_idx`) so its checkpoints load."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose
+import vgtk.pc as pctk
+from . import functional as L
+
+KERNEL_CONDENSE_RATIO = 0.7
+
+
+class BasicSO3Conv(nn.Module):
+    """[b, c1, k, p, a] -> [b, c2, p, a]  (modules.py:L21-55): W [c2, c1*k], no bias,
+    xavier-normal with relu gain."""
+
+    def __init__(self, dim_in, dim_out, kernel_size, debug=False):
+        super(BasicSO3Conv, self).__init__()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = kernel_size
+        if debug:
+            self.register_buffer('W', torch.ones(dim_out, dim_in * kernel_size))
+        else:
+            W = torch.empty(dim_out, dim_in, kernel_size)
+            nn.init.xavier_normal_(W, gain=nn.init.calculate_gain('relu'))
+            self.register_parameter('W', nn.Parameter(W.view(dim_out, dim_in * kernel_size)))
+
+    def forward(self, x):
+        bs, np_, na = x.shape[0], x.shape[3], x.shape[4]
+        y = L.so3_contract(self.W, x.reshape(bs, self.dim_in * self.kernel_size, np_ * na))
+        return y.view(bs, self.dim_out, np_, na)
+
+
+class InterSO3Conv(nn.Module):
+    """Pose-free inter conv (modules.py:L125-174)."""
+
+    def __init__(self, dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
+                 lazy_sample=True, pooling=None, kanchor=60):
+        super(InterSO3Conv, self).__init__()
+        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+        anchors = L.get_anchors(kanchor)
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = kernels.shape[0]
+        self.stride = stride
+        self.radius = radius
+        self.sigma = sigma
+        self.n_neighbor = n_neighbor
+        self.lazy_sample = lazy_sample
+        self.pooling = pooling
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        self.register_buffer('kernels', torch.from_numpy(kernels))
+
+    def forward(self, x, inter_idx=None, inter_w=None):
+        inter_idx, inter_w, xyz, feats, sample_idx = \
+            L.inter_so3conv_grouping(x.xyz, x.feats, self.stride, self.n_neighbor, self.anchors,
+                                     self.kernels, self.radius, self.sigma, inter_idx, inter_w,
+                                     self.lazy_sample, pooling=self.pooling)
+        feats = self.basic_conv(feats)
+        return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, feats, self.anchors)
+
+
+class InterSO3PoseConv(nn.Module):
+    """Pose-aware inter conv (modules.py:L177-322); forward returns
+    (inter_idx, inter_w, sample_idx, SphericalPointCloudPose)."""
+
+    def __init__(self, dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
+                 lazy_sample=True, pooling=None, kanchor=60, permute_modes=0, use_2d=False,
+                 use_art_mode=False):
+        super(InterSO3PoseConv, self).__init__()
+        if use_2d or use_art_mode:
+            raise NotImplementedError('use_2d / use_art_mode grouping variants are outside the accelerated path')
+        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+        anchors = L.get_anchors(kanchor)
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = kernels.shape[0]
+        self.stride = stride
+        self.radius = radius
+        self.sigma = sigma
+        self.n_neighbor = n_neighbor
+        self.lazy_sample = lazy_sample
+        self.pooling = pooling
+        self.permute_modes = permute_modes
+        self.use_2d = use_2d
+        self.use_art_mode = use_art_mode
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        self.register_buffer('kernels', torch.from_numpy(kernels))
+
+    def forward(self, x, inter_idx=None, inter_w=None, seg=None):
+        inter_idx, inter_w, xyz, feats, sample_idx, sampled_pose = \
+            L.inter_so3poseconv_grouping_strided(x.xyz, x.pose, x.feats, self.stride, self.n_neighbor,
+                                                 self.anchors, self.kernels, self.radius, self.sigma,
+                                                 inter_idx, inter_w, self.lazy_sample,
+                                                 pooling=self.pooling, permute_modes=self.permute_modes)
+        feats = self.basic_conv(feats)
+        return inter_idx, inter_w, sample_idx, SphericalPointCloudPose(xyz, feats, self.anchors, sampled_pose)
+
+
+class IntraSO3Conv(nn.Module):
+    """Group conv over the 12 icosahedral neighbours of each anchor (modules.py:L325-347);
+    only valid for kanchor = 60."""
+
+    def __init__(self, dim_in, dim_out):
+        super(IntraSO3Conv, self).__init__()
+        anchors = L.get_anchors()
+        intra_idx = L.get_intra_idx()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = intra_idx.shape[1]
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
+
+    def forward(self, x):
+        feats = L.intra_so3conv_grouping(self.intra_idx, x.feats)
+        feats = self.basic_conv(feats)
+        return SphericalPointCloud(x.xyz, feats, self.anchors)
+
+
+class PointnetSO3Conv(nn.Module):
+    """Equivariant pointnet aggregation (modules.py:L376-412): 1x1 conv over [feats ; A^T xyz]
+    then max over points.  Dense torch layers (out of the HIP scope)."""
+
+    def __init__(self, dim_in, dim_out, kanchor=60, return_raw=False):
+        super(PointnetSO3Conv, self).__init__()
+        anchors = L.get_anchors(kanchor)
+        self.dim_in = dim_in + 3
+        self.dim_out = dim_out
+        self.return_raw = return_raw
+        self.embed = nn.Conv2d(self.dim_in, self.dim_out, 1)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+
+    def forward(self, x):
+        xyz = x.xyz
+        feats = x.feats
+        na = feats.shape[3]
+        xyz = xyz - xyz.mean(2, keepdim=True)
+        if na == 1:
+            feats = torch.cat([x.feats, xyz[..., None]], 1)
+        else:
+            xyzr = torch.einsum('aji,bjn->bina', self.anchors, xyz)
+            feats = torch.cat([x.feats, xyzr], 1)
+        feats = self.embed(feats)
+        if self.return_raw:
+            return feats
+        return torch.max(feats, 2)[0]
+
+
+class PointnetSO3PoseConv(PointnetSO3Conv):
+    """modules.py:L415-449 (same computation, always max-pooled)."""
+
+    def __init__(self, dim_in, dim_out, kanchor=60):
+        super(PointnetSO3PoseConv, self).__init__(dim_in, dim_out, kanchor, return_raw=False)

@@ -1,0 +1,193 @@
+/*
+ * include/eap_hip.h -- C ABI of libeap_hip.so, the MI355X (gfx950) implementation of the
+ * SE(3)-equivariant point-convolution hot path of Meowuu7/equi-articulated-pose.
+ *
+ * Drop-in boundary B2: every entry point below replaces one pybind11
+ * function of the reference's CUDA extensions (the .cpp files of vgtk/vgtk/cuda and extensions/chamfer_dist)
+ * or one stage of the Python "naive" operator path that the shipped models execute
+ * (vgtk/vgtk/so3conv/functional.py).  The reference interface each one replaces is cited as
+ * file:line (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers, tensors are
+ *     contiguous in the layout written next to each argument;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are
+ *     asynchronous, nothing synchronises;
+ *   - outputs are fully written by the call (no pre-zeroing needed) unless stated otherwise;
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch / argument
+ *     check (eap_last_error() returns a message).  The reference only printf()s launch errors
+ *     (vgtk/vgtk/cuda/zpconv_cuda_kernel.cu:L232-234); this ABI reports them.
+ *   - *_f32 / *_f64: the reference dispatches AT_DISPATCH_FLOATING_TYPES for its native ops.
+ */
+#ifndef EAP_HIP_H
+#define EAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *eap_stream_t;
+
+const char *eap_last_error(void);
+int eap_abi_version(void);
+
+/* ---- grouping (vgtk/vgtk/cuda/grouping_cuda.cpp) ------------------------------------------ */
+
+/* ball_query: grouping_cuda.cpp:L71-86, kernel grouping_cuda_kernel.cu:L68-113.
+ * new_xyz [b,3,m], xyz [b,3,n] -> idx int32 [b,m,nsample]: first `nsample` support indices in
+ * index order with d2 < radius^2; repeat-padding when fewer than nsample-1 hits. */
+int eap_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                       const float *xyz, int32_t *idx, eap_stream_t stream);
+int eap_ball_query_f64(int b, int n, int m, float radius, int nsample, const double *new_xyz,
+                       const double *xyz, int32_t *idx, eap_stream_t stream);
+
+/* furthest_point_sampling: grouping_cuda.cpp:L160-174, kernel .cu:L352-466.
+ * xyz [b,3,n] -> idx int32 [b,m]; temp [b,n] is scratch (initialised by the call). */
+int eap_furthest_point_sampling_f32(int b, int n, int m, const float *xyz, float *temp,
+                                    int32_t *idx, eap_stream_t stream);
+
+/* anchor_query (S^2 variant): grouping_cuda.cpp:L88-108, kernel .cu:L181-247.
+ * grouped_xyz [b,3,np,nn], anchors [na,3], kernel_pts [ks,2] -> w [b,np,na,ks,nn]. */
+int eap_anchor_query_f32(int b, int np, int nn, int na, int ks, const float *grouped_xyz,
+                         const float *anchors, const float *kernel_pts, float *w,
+                         eap_stream_t stream);
+
+/* initial_anchor_query: grouping_cuda.cpp:L138-158, kernel .cu:L117-167.
+ * centers [b,3,nc], xyz [m,3], kernel_pts [ks,na,3] -> w, cnt [b,ks,nc,na]. */
+int eap_initial_anchor_query_f32(int b, int nc, int m, int na, int ks, float radius, float sigma,
+                                 const float *centers, const float *xyz, const float *kernel_pts,
+                                 float *w, float *cnt, eap_stream_t stream);
+
+/* ---- gathering (vgtk/vgtk/cuda/gathering_cuda.cpp) ---------------------------------------- */
+
+/* gather_points_forward: gathering_cuda.cpp:L29-43. pts [b,c,n], idx [b,m] -> out f32 [b,c,m]. */
+int eap_gather_points_fwd_f32(int b, int c, int n, int m, const float *pts, const int32_t *idx,
+                              float *out, eap_stream_t stream);
+/* gather_points_backward: gathering_cuda.cpp:L45-60. grad_out [b,c,m] -> grad_pts [b,c,n]. */
+int eap_gather_points_bwd_f32(int b, int c, int n, int m, const float *grad_out,
+                              const int32_t *idx, float *grad_pts, eap_stream_t stream);
+int eap_gather_points_bwd_f64(int b, int c, int n, int m, const double *grad_out,
+                              const int32_t *idx, double *grad_pts, eap_stream_t stream);
+
+/* ---- zpconv (vgtk/vgtk/cuda/zpconv_cuda.cpp) ---------------------------------------------- */
+
+/* inter_zpconv_forward: zpconv_cuda.cpp:L41-56, kernel zpconv_cuda_kernel.cu:L33-73.
+ * idx,w [b,np,na,ks,ann], feats [b,c,nq,na] -> out [b,c,ks,np,na]. */
+int eap_inter_zpconv_fwd_f32(int b, int np, int nq, int na, int ks, int ann, int c,
+                             const int32_t *idx, const float *w, const float *feats, float *out,
+                             eap_stream_t stream);
+int eap_inter_zpconv_fwd_f64(int b, int np, int nq, int na, int ks, int ann, int c,
+                             const int32_t *idx, const double *w, const double *feats,
+                             double *out, eap_stream_t stream);
+/* inter_zpconv_backward: zpconv_cuda.cpp:L58-75, kernel .cu:L77-116.
+ * grad [b,c,ks,np,na] -> gfeats [b,c,nq,na]. */
+int eap_inter_zpconv_bwd_f32(int b, int np, int nq, int na, int ks, int ann, int c,
+                             const int32_t *idx, const float *w, const float *grad, float *gfeats,
+                             eap_stream_t stream);
+int eap_inter_zpconv_bwd_f64(int b, int np, int nq, int na, int ks, int ann, int c,
+                             const int32_t *idx, const double *w, const double *grad,
+                             double *gfeats, eap_stream_t stream);
+/* intra_zpconv_forward: zpconv_cuda.cpp:L77-92, kernel .cu:L120-156.
+ * idx [na_out,ann], w [na_out,ks,ann], feats [b,c,np,na_in] -> out [b,c,ks,np,na_out]. */
+int eap_intra_zpconv_fwd_f32(int b, int np, int na_in, int na_out, int ks, int ann, int c,
+                             const int32_t *idx, const float *w, const float *feats, float *out,
+                             eap_stream_t stream);
+int eap_intra_zpconv_fwd_f64(int b, int np, int na_in, int na_out, int ks, int ann, int c,
+                             const int32_t *idx, const double *w, const double *feats,
+                             double *out, eap_stream_t stream);
+/* intra_zpconv_backward: zpconv_cuda.cpp:L94-110, kernel .cu:L160-195. */
+int eap_intra_zpconv_bwd_f32(int b, int np, int na_in, int na_out, int ks, int ann, int c,
+                             const int32_t *idx, const float *w, const float *grad, float *gfeats,
+                             eap_stream_t stream);
+int eap_intra_zpconv_bwd_f64(int b, int np, int na_in, int na_out, int ks, int ann, int c,
+                             const int32_t *idx, const double *w, const double *grad,
+                             double *gfeats, eap_stream_t stream);
+
+/* ---- SO(3) inter convolution (vgtk/vgtk/so3conv/functional.py) ---------------------------- */
+
+/* so3_prep: relative offsets and relative-rotation anchor of every (point, neighbour) pair --
+ * so3conv/functional.py:L1061-1078 (gather + R_p R_n^T + rotate offsets) and the nearest-anchor
+ * half of L1199-1204.
+ * q_xyz [b,3,p], s_xyz [b,3,n], idx int32 [b,p,nn], pose [b,n,4,4] (q_pose [b,p,4,4]) or NULL
+ * for identity poses, anchors [na,3,3]
+ *  -> gx float4 [b,p,nn] = (gx,gy,gz, bit-cast int r) with g = R_rel (x_n - x_p) and
+ *     r = argmax_g tr(R_rel A_g)  (r = index of the identity anchor when pose == NULL). */
+int eap_so3_prep_f32(int b, int p, int n, int nn, int na, const float *q_xyz, const float *s_xyz,
+                     const int32_t *idx, const float *q_pose, const float *s_pose,
+                     const float *anchors, int identity_anchor, float *gx, eap_stream_t stream);
+
+/* so3_inter_weights: inter_so3conv_grouping_anchor, so3conv/functional.py:L2508-2549.
+ * gx float4 [b,p,nn] (from so3_prep), rk [na,ks,3] = A_a kappa_k
+ *  -> w [b,p,na,ks,nn] = relu(1 - |g - rk|^2 / sigma). */
+int eap_so3_inter_weights_f32(int b, int p, int nn, int na, int ks, float sigma, const float *gx,
+                              const float *rk, float *w, eap_stream_t stream);
+
+/* so3_anchor_perm: the full index of so3conv/functional.py:L1199-1204,
+ * perm[b,p,n,a] = mult[r[b,p,n]][a] as int64 (what torch.argmax returns). */
+int eap_so3_anchor_perm(int b, int p, int nn, int na, const float *gx, const uint8_t *mult,
+                        int64_t *perm, eap_stream_t stream);
+
+/* so3_inter_group_fwd: fused kernel-weight + anchor-permutation + gather + weighted sum,
+ * so3conv/functional.py:L1112-1261 (einsum 'bcpna,bpakn->bckpa' at L1261) without materialising
+ * the [b,p,na,ks,nn] weights.
+ * feats [b,c,n,na], idx [b,p,nn], gx float4 [b,p,nn], rk [na,ks,3], mult [na,na] (NULL = no
+ * permutation, permute_modes == 0) -> out [b,c,ks,p,na]. */
+int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                const float *feats, const int32_t *idx, const float *gx,
+                                const float *rk, const uint8_t *mult, float *out,
+                                eap_stream_t stream);
+/* so3_inter_group_bwd: transpose of the above w.r.t. feats.
+ * gout [b,c,ks,p,na] -> gfeats [b,c,n,na] (zero-initialised by the call, fp32 atomics). */
+int eap_so3_inter_group_bwd_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                const float *gout, const int32_t *idx, const float *gx,
+                                const float *rk, const uint8_t *mult, float *gfeats,
+                                eap_stream_t stream);
+
+/* ---- SO(3) intra convolution -------------------------------------------------------------- */
+
+/* so3_intra_group_fwd: intra_so3conv_grouping, so3conv/functional.py:L2553-2602.
+ * feats [b,c,p,na], intra_idx int32 [na,t] -> out [b,c,t,p,na] = feats[b,c,p,intra_idx[a,t]]. */
+int eap_so3_intra_group_fwd_f32(int b, int c, int p, int na, int t, const float *feats,
+                                const int32_t *intra_idx, float *out, eap_stream_t stream);
+/* transpose: gout [b,c,t,p,na] -> gfeats [b,c,p,na] (deterministic, inverse index). */
+int eap_so3_intra_group_bwd_f32(int b, int c, int p, int na, int t, const float *gout,
+                                const int32_t *intra_idx, float *gfeats, eap_stream_t stream);
+
+/* ---- dense contraction (BasicSO3Conv.forward, so3conv/modules.py:L48-55) ------------------- */
+
+/* Batched fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32), row-major:
+ *   C_z[M,N] = op(A_z)[M,K] * op(B_z)[K,N]       z = 0..batch-1
+ * transA = 0: A_z is [M,K] with leading dimension lda; 1: A_z is stored [K,M].  Same for B.
+ * stride* are element offsets between consecutive batch items (0 = shared operand).
+ * BasicSO3Conv:  C = y [b][O, P*A], A = W [O, C*K] (strideA 0), B = x [b][C*K, P*A]. */
+int eap_gemm_f32(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                 int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
+                 int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+
+/* Split-K / batch-reduced GEMM for the weight gradient:
+ *   C[M,N] = sum_z sum_k op(A_z)[M,k] * op(B_z)[k,N]
+ * `workspace` holds batch*splits partial [M,N] slabs (eap_gemm_f32_reduce_workspace floats);
+ * the reduction over slabs is a second deterministic kernel. */
+int64_t eap_gemm_f32_reduce_workspace(int M, int N, int K, int batch);
+int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                        int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
+                        int64_t ldc, int batch, float *workspace, eap_stream_t stream);
+
+/* ---- chamfer distance (extensions/chamfer_dist) ------------------------------------------- */
+
+/* chamfer.forward: chamfer_cuda.cpp:L22-25, chamfer.cu:L15-171.
+ * xyz1 [b,n,3], xyz2 [b,m,3] -> dist1 [b,n], dist2 [b,m], idx1 int32 [b,n], idx2 int32 [b,m]. */
+int eap_chamfer_fwd_f32(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                        float *dist2, int32_t *idx1, int32_t *idx2, eap_stream_t stream);
+/* chamfer.backward: chamfer_cuda.cpp:L27-34, chamfer.cu:L173-231.
+ * -> gxyz1 [b,n,3], gxyz2 [b,m,3] (zero-initialised by the call). */
+int eap_chamfer_bwd_f32(int b, int n, int m, const float *xyz1, const float *xyz2,
+                        const int32_t *idx1, const int32_t *idx2, const float *g1, const float *g2,
+                        float *gxyz1, float *gxyz2, eap_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAP_HIP_H */

@@ -1,0 +1,321 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the vgtk operator layer) against the
+CPU oracle and the golden fixtures generated from the reference.  Run with `-m gpu` on an MI355X.
+
+Bars: integer outputs (neighbour lists, permutation indices) bit-exact; floating point within
+the tolerance written next to each assert (the north star asks for 1e-4 relative on poses; the
+operator-level bars here are tighter)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import native, so3_ref  # noqa: E402  (checker only)
+
+T = torch.from_numpy
+INTER_CASES = ['inter_pose_l0_identity', 'inter_pose_identity', 'inter_pose_random_pm1',
+               'inter_pose_parts_pm1', 'inter_pose_random_pm0', 'inter_pose_bigball']
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def vg():
+    import vgtk
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    return vgtk, sptk, zptk, L
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ------------------------------------------------------------------------------------------------
+# native ops (boundary B2)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,m,radius,nsample,dtype', [
+    (512, 512, 0.08, 64, np.float32), (512, 512, 0.16, 64, np.float32), (700, 333, 0.3, 16, np.float32),
+    (4096, 4096, 0.08, 64, np.float32), (4096, 4096, 0.45, 64, np.float32), (256, 256, 0.2, 32, np.float64),
+    (1500, 40, 0.05, 8, np.float32)])
+def test_ball_query_exact(dev, vg, n, m, radius, nsample, dtype):
+    import synth_clouds
+    import vgtk.cuda.grouping as G
+    xyz = synth_clouds.laptop_batch(0, 2, n)[0].astype(dtype)
+    q = xyz[:, :, :m].copy() if m <= n else xyz
+    if m == 40:   # queries off the surface: some balls are empty, some hold exactly a few points
+        q = q + np.asarray([0.03, 0.0, 0.0], dtype)[None, :, None]
+    ref = native.ball_query(q, xyz, radius, nsample)
+    got = G.ball_query(T(q).to(dev), T(xyz).to(dev), radius, nsample)
+    assert got.dtype == torch.int32
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_ball_query_known_answers(dev):
+    """Hand-built cases of grouping_cuda_kernel.cu:L68-113 semantics."""
+    import vgtk.cuda.grouping as G
+    xyz = np.zeros((1, 3, 8), np.float32)
+    xyz[0, 0] = [0, 1, 2, 3, 4, 5, 6, 7]
+    q = np.zeros((1, 3, 3), np.float32)
+    q[0, 0] = [0, 3, 100]
+    # radius 1.5 around x=0 -> {0,1}; around x=3 -> {2,3,4}; around 100 -> {}
+    got = G.ball_query(T(q).to(dev), T(xyz).to(dev), 1.5, 4).cpu().numpy()[0]
+    np.testing.assert_array_equal(got[0], [0, 1, 0, 1])      # cnt=2 < 3: cyclic repeat
+    np.testing.assert_array_equal(got[1], [2, 3, 4, 0])      # cnt=3 == nsample-1: last slot stays 0
+    np.testing.assert_array_equal(got[2], [0, 0, 0, 0])      # empty ball
+    # strict '<': a point at distance exactly r is excluded; more hits than nsample -> first in index order
+    got = G.ball_query(T(q).to(dev), T(xyz).to(dev), 1.0, 2).cpu().numpy()[0]
+    np.testing.assert_array_equal(got[0], [0, 0])            # only x=0 (x=1 is at d == r); cnt=1 == nsample-1
+    got = G.ball_query(T(q).to(dev), T(xyz).to(dev), 10.0, 3).cpu().numpy()[0]
+    np.testing.assert_array_equal(got[1], [0, 1, 2])
+
+
+def test_gather_points(dev):
+    import vgtk.cuda.gathering as GA
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((3, 5, 97)).astype(np.float32)
+    idx = rng.integers(0, 97, (3, 211)).astype(np.int32)
+    out = GA.gather_points_forward(T(pts).to(dev), T(idx).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(out, native.gather_points_forward(pts, idx))
+    for dt, tol in ((np.float32, 1e-5), (np.float64, 1e-12)):
+        g = rng.standard_normal((3, 5, 211)).astype(dt)
+        got = GA.gather_points_backward(T(g).to(dev), T(idx).to(dev), 97).cpu().numpy()
+        np.testing.assert_allclose(got, native.gather_points_backward(g, idx, 97), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float32, 2e-6), (np.float64, 1e-13)])
+@pytest.mark.parametrize('shape', [(2, 9, 11, 12, 5, 8, 3), (1, 17, 20, 60, 24, 64, 10), (2, 4, 4, 1, 3, 7, 2)])
+def test_inter_zpconv(dev, dtype, tol, shape):
+    import vgtk.cuda.zpconv as Z
+    b, p, q, a, k, ann, c = shape
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, q, (b, p, a, k, ann)).astype(np.int32)
+    w = rng.random((b, p, a, k, ann)).astype(dtype)
+    feats = rng.standard_normal((b, c, q, a)).astype(dtype)
+    out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
+    ref = native.inter_zpconv_forward(idx, w, feats)
+    assert rel_err(out, ref) < tol
+    g = rng.standard_normal(ref.shape).astype(dtype)
+    got = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q).cpu().numpy()
+    assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 10 * tol
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float32, 2e-6), (np.float64, 1e-13)])
+def test_intra_zpconv(dev, dtype, tol):
+    import vgtk.cuda.zpconv as Z
+    rng = np.random.default_rng(2)
+    b, c, p, a_in, a_out, k, ann = 2, 5, 33, 60, 60, 4, 12
+    idx = rng.integers(0, a_in, (a_out, ann)).astype(np.int32)
+    w = rng.random((a_out, k, ann)).astype(dtype)
+    feats = rng.standard_normal((b, c, p, a_in)).astype(dtype)
+    out = Z.intra_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
+    ref = native.intra_zpconv_forward(idx, w, feats)
+    assert rel_err(out, ref) < tol
+    g = rng.standard_normal(ref.shape).astype(dtype)
+    got = Z.intra_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), a_in).cpu().numpy()
+    assert rel_err(got, native.intra_zpconv_backward(idx, w, g, a_in)) < 10 * tol
+
+
+def test_native_ops_reject_host_tensors(vg):
+    import vgtk.cuda.zpconv as Z
+    with pytest.raises(RuntimeError):
+        Z.inter_zpconv_forward(torch.zeros(1, 1, 1, 1, 1, dtype=torch.int32), torch.zeros(1, 1, 1, 1, 1),
+                               torch.zeros(1, 1, 1, 1))
+
+
+def test_zpconv_naive_golden(dev, vg, golden):
+    _, _, zptk, _ = vg
+    g = golden('zpconv_naive.npz')
+    out = zptk.inter_zpconv_grouping_naive(T(g['inter_idx']).to(dev), T(g['inter_w']).to(dev), T(g['inter_feats']).to(dev))
+    assert rel_err(out.cpu().numpy(), g['inter_out']) < 2e-6
+    out = zptk.intra_zpconv_grouping_naive(T(g['intra_idx']).to(dev), T(g['intra_w']).to(dev), T(g['intra_feats']).to(dev))
+    assert rel_err(out.cpu().numpy(), g['intra_out']) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# dense contraction (fp32 MFMA GEMM)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,batch', [(128, 256, 64, 1), (64, 128, 24, 2), (8, 3840, 144, 2), (512, 1920, 3072, 1),
+                                        (100, 333, 50, 3), (7, 60, 5, 1), (130, 129, 17, 2)])
+def test_gemm_variants(dev, M, N, K, batch):
+    from vgtk import _hip
+    gen = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=gen); B = torch.randn(batch, K, N, generator=gen)
+    ref = torch.matmul(A.double(), B.double())
+    tol = 2e-6 if K <= 256 else 1e-5   # sequential fp32 accumulation: error grows ~ sqrt(K) ulp
+    Ad, Bd = A.to(dev), B.to(dev)
+    C = torch.empty(batch, M, N, device=dev)
+    _hip.gemm(0, 0, M, N, K, Ad, K, 0, Bd, N, K * N, C, N, M * N, batch)
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < tol
+    # A^T variant: A stored [K, M]
+    At = A.t().contiguous().to(dev)
+    C.zero_()
+    _hip.gemm(1, 0, M, N, K, At, M, 0, Bd, N, K * N, C, N, M * N, batch)
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < tol
+    # B^T variant: B stored [N, K]
+    Bt = B.transpose(1, 2).contiguous().to(dev)
+    C.zero_()
+    _hip.gemm(0, 1, M, N, K, Ad, K, 0, Bt, K, K * N, C, N, M * N, batch)
+    assert rel_err(C.cpu().numpy(), ref.numpy()) < tol
+    # batch-reduced (weight-gradient shape): sum_b A_b B_b^T with a long K
+    A2 = torch.randn(batch, M, N, generator=gen); B2 = torch.randn(batch, K, N, generator=gen)
+    ref2 = torch.einsum('bmn,bkn->mk', A2.double(), B2.double())
+    C2 = torch.empty(M, K, device=dev)
+    _hip.gemm_reduce(0, 1, M, K, N, A2.to(dev), N, M * N, B2.to(dev), N, K * N, C2, K, batch)
+    assert rel_err(C2.cpu().numpy(), ref2.numpy()) < 3e-6
+
+
+def test_gemm_is_transpose_detecting(dev):
+    """A = I with an asymmetric B: catches a swapped C/D fragment layout."""
+    from vgtk import _hip
+    n = 128
+    A = torch.eye(n, device=dev)
+    B = (torch.arange(n * n, dtype=torch.float32).view(1, n, n) % 251).to(dev)
+    C = torch.empty(1, n, n, device=dev)
+    _hip.gemm(0, 0, n, n, n, A, n, 0, B, n, n * n, C, n, n * n, 1)
+    assert torch.equal(C, B)
+
+
+# ------------------------------------------------------------------------------------------------
+# SO(3) conv stages against golden fixtures (generated by running the reference)
+# ------------------------------------------------------------------------------------------------
+def test_kernel_weights_golden(dev, vg, golden):
+    _, _, _, L = vg
+    g = golden('weights.npz')
+    w = L.inter_so3conv_grouping_anchor(T(g['grouped_xyz']).to(dev), T(g['anchors']).to(dev),
+                                        T(g['kernels']).to(dev), float(g['sigma']))
+    # same operation order as the reference (sub, square, ordered sum, divide, relu): tight bar
+    np.testing.assert_allclose(w.cpu().numpy(), g['inter_w'], rtol=0, atol=2e-6)
+
+
+def _run_layer(vg, dev, g):
+    _, sptk, zptk, L = vg
+    C, O = g['feats'].shape[1], g['W'].shape[0]
+    conv = sptk.InterSO3PoseConv(C, O, 1, 1, float(g['radius']), float(g['sigma']), int(g['nn']), kanchor=60,
+                                 permute_modes=int(g['permute_modes'])).to(dev)
+    with torch.no_grad():
+        conv.basic_conv.W.copy_(T(g['W']))
+        conv.kernels.copy_(T(g['kernels']))
+        conv.anchors.copy_(T(g['anchors']))
+    feats = T(g['feats']).to(dev).requires_grad_(True)
+    x = zptk.SphericalPointCloudPose(T(g['xyz']).to(dev), feats, None, T(g['pose']).to(dev))
+    return conv, feats, conv(x)
+
+
+@pytest.mark.parametrize('name', INTER_CASES)
+def test_inter_pose_layer_golden(dev, vg, golden, name):
+    g = golden(name + '.npz')
+    conv, feats, (inter_idx, inter_w, sample_idx, y) = _run_layer(vg, dev, g)
+    assert inter_idx is None and sample_idx is None            # reference stride-1 return values
+    assert tuple(inter_w.shape) == (2, 64, 60, 24, int(g['nn']))
+    w = inter_w.materialize()
+    np.testing.assert_allclose(w[:, :4].cpu().numpy(), g['inter_w_head'], rtol=0, atol=5e-6)
+    assert y.feats.shape == g['out'].shape and y.pose.shape == g['pose'].shape
+    assert rel_err(y.feats.detach().cpu().numpy(), g['out']) < 1e-5
+    gf, gW = torch.autograd.grad(y.feats, [feats, conv.basic_conv.W], T(g['grad_out']).to(dev))
+    assert rel_err(gf.cpu().numpy(), g['grad_feats']) < 1e-5
+    assert rel_err(gW.cpu().numpy(), g['grad_W']) < 2e-5
+
+
+@pytest.mark.parametrize('name', INTER_CASES)
+def test_inter_group_stage_golden(dev, vg, golden, name):
+    _, _, _, L = vg
+    g = golden(name + '.npz')
+    _, w, _, nf, _, _ = L.inter_so3poseconv_grouping_strided(
+        T(g['xyz']).to(dev), T(g['pose']).to(dev), T(g['feats']).to(dev), 1, int(g['nn']),
+        T(g['anchors']).to(dev), T(g['kernels']).to(dev), float(g['radius']), float(g['sigma']),
+        permute_modes=int(g['permute_modes']))
+    assert rel_err(nf[:, :, :, :8].cpu().numpy(), g['new_feats_head']) < 5e-6
+
+
+def test_anchor_permutation_matches_reference_search(dev, vg, golden):
+    """mult[r][a] against the oracle's 60x60 trace arg-max (so3conv/functional.py:L1199-1204)."""
+    _, _, _, L = vg
+    for name in ('inter_pose_random_pm1', 'inter_pose_parts_pm1', 'inter_pose_identity'):
+        g = golden(name + '.npz')
+        xyz, pose, A = T(g['xyz']), T(g['pose']), T(g['anchors'])
+        perm = L.anchor_permutation_index(xyz.to(dev), pose.to(dev), int(g['nn']), A.to(dev), float(g['radius']))
+        ref = so3_ref.inter_so3poseconv_grouping_strided(xyz, pose, T(g['feats']), int(g['nn']), A, T(g['kernels']),
+                                                         float(g['radius']), float(g['sigma']), permute_modes=1)
+        np.testing.assert_array_equal(perm.cpu().numpy(), ref['rotated_anchor_idx'].numpy())
+
+
+def test_inter_nopose_golden(dev, vg, golden):
+    _, sptk, zptk, _ = vg
+    g = golden('inter_nopose.npz')
+    conv = sptk.InterSO3Conv(5, 7, 1, 1, float(g['radius']), float(g['sigma']), int(g['nn']), kanchor=60).to(dev)
+    with torch.no_grad():
+        conv.basic_conv.W.copy_(T(g['W']))
+    inter_idx, inter_w, sample_idx, y = conv(zptk.SphericalPointCloud(T(g['xyz']).to(dev), T(g['feats']).to(dev), None))
+    np.testing.assert_array_equal(inter_idx.cpu().numpy(), g['inter_idx'])
+    assert rel_err(y.feats.detach().cpu().numpy(), g['out']) < 1e-5
+
+
+def test_intra_golden(dev, vg, golden):
+    _, sptk, zptk, L = vg
+    g = golden('intra.npz')
+    conv = sptk.IntraSO3Conv(6, 9).to(dev)
+    with torch.no_grad():
+        conv.basic_conv.W.copy_(T(g['W']))
+    assert np.array_equal(conv.intra_idx.cpu().numpy(), g['intra_idx'])
+    feats = T(g['feats']).to(dev).requires_grad_(True)
+    grouped = L.intra_so3conv_grouping(conv.intra_idx, feats)
+    np.testing.assert_array_equal(grouped[:, :, :, :8].detach().cpu().numpy(), g['grouped_head'])
+    y = conv(zptk.SphericalPointCloud(None, feats, None))
+    assert rel_err(y.feats.detach().cpu().numpy(), g['out']) < 1e-5
+    gf, gW = torch.autograd.grad(y.feats, [feats, conv.basic_conv.W], T(g['grad_out']).to(dev))
+    assert rel_err(gf.cpu().numpy(), g['grad_feats']) < 1e-5
+    assert rel_err(gW.cpu().numpy(), g['grad_W']) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# larger shapes against the oracle (sizes the oracle finishes in seconds)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('P,C,O,layer', [(512, 1, 64, 0), (512, 64, 128, 1), (384, 128, 64, 2)])
+def test_layer_vs_oracle_512(dev, vg, P, C, O, layer):
+    import synth_clouds
+    _, sptk, zptk, L = vg
+    _, _, radius, sigma = synth_clouds.backbone_layers(512)[layer]
+    xyz, _, pose = synth_clouds.laptop_batch(3, 2, P)
+    torch.manual_seed(2913)
+    conv = sptk.InterSO3PoseConv(C, O, 1, 1, radius, sigma, 64, kanchor=60, permute_modes=1)
+    feats = torch.ones(2, 1, P, 60) if C == 1 else torch.randn(2, C, P, 60)
+    ref = so3_ref.inter_so3poseconv_layer(T(xyz), T(pose), feats, conv.basic_conv.W.detach(), conv.anchors,
+                                          conv.kernels, radius, sigma, 64, permute_modes=1, chunk=64,
+                                          skip_perm_search=True)
+    conv = conv.to(dev)
+    y = conv(zptk.SphericalPointCloudPose(T(xyz).to(dev), feats.to(dev), None, T(pose).to(dev)))[3].feats
+    assert rel_err(y.detach().cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_equivariance_property(dev, vg):
+    """Rotating the cloud by anchor A_j permutes the anchor axis: out'[..., a] = out[..., pi(a)]
+    with A_pi(a) = A_j^T A_a (probed on the reference)."""
+    import synth_clouds
+    _, sptk, zptk, L = vg
+    from vgtk.functional import anchor_group_tables
+    xyz = T(synth_clouds.laptop_batch(7, 1, 256)[0])
+    anchors = torch.from_numpy(L.get_anchors())
+    mult, inv = anchor_group_tables(anchors.numpy())
+    torch.manual_seed(0)
+    inter = sptk.InterSO3PoseConv(1, 16, 1, 1, 0.16, 0.0128, 32, kanchor=60, permute_modes=1).to(dev)
+    intra = sptk.IntraSO3Conv(16, 8).to(dev)
+
+    def run(x):
+        pose = torch.eye(4).repeat(1, x.shape[2], 1, 1).to(dev)
+        f = torch.ones(1, 1, x.shape[2], 60, device=dev)
+        y = inter(zptk.SphericalPointCloudPose(x.to(dev).contiguous(), f, None, pose))[3]
+        return y.feats, intra(y).feats
+
+    a0, b0 = run(xyz)
+    for j in (3, 17, 44):
+        a1, b1 = run(torch.einsum('ij,bjn->bin', anchors[j], xyz))
+        pi = torch.from_numpy(mult[inv[j]].astype(np.int64)).to(dev)     # A_pi(a) = A_j^T A_a
+        assert rel_err(a1.detach().cpu().numpy(), a0[..., pi].detach().cpu().numpy()) < 2e-5
+        assert rel_err(b1.detach().cpu().numpy(), b0[..., pi].detach().cpu().numpy()) < 2e-5
