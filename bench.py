@@ -1,0 +1,239 @@
+"""bench.py -- headline benchmark of the SE(3)-equivariant point-convolution hot path.
+
+Metric (BASELINE.json): point-clouds/sec (4096 pts, 60 anchors) fwd+bwd.
+One "step" = one batch of synthetic 4096-point 'laptop' clouds through the reference's 3-block
+inter backbone (channels 1->64->128->512, NN=64, K=24, A=60; each block = InterSO3PoseConv ->
+BatchNorm2d -> leaky_relu as in SPConvNets/utils/base_so3poseconv.py:L205-222), forward +
+backward + Adam step on the conv weights, with identity per-point poses and anchor permutation
+enabled (what the shipped model runs).  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--points P] [--fwd-only]
+For N > 1 launch through torch.distributed.run (one rank per GPU, RCCL): every rank processes
+its own B clouds (weak scaling, no data-path collective), then one pose-hypothesis all-gather
+and one bucketed gradient all-reduce per step.
+
+Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant kernel
+(the fp32-MFMA contraction; achieved = algorithmic flops / measured launch time from HIP events
+recorded on the launch stream inside the timed region) and a `cpu_baseline` object (the CPU
+oracle -- an op-for-op restatement of the reference's torch path -- timed on the host cores on a
+bounded sample; checker/baseline only, never part of the measured path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'equi-articulated-pose_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+NN, KS, NA, SLOTS = 64, 24, 60, 2
+
+
+class Backbone(nn.Module):
+    """3 x (InterSO3PoseConv -> BatchNorm2d -> leaky_relu): the `backbone` of
+    SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L505-508 with build_model's
+    hyper-parameters (L2089-2225)."""
+
+    def __init__(self, input_num):
+        super().__init__()
+        import synth_clouds
+        import vgtk.so3conv as sptk
+        self.convs = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        for (c, o, r, s) in synth_clouds.backbone_layers(input_num):
+            self.convs.append(sptk.InterSO3PoseConv(c, o, 1, 1, r, s, NN, kanchor=NA, permute_modes=1))
+            self.norms.append(nn.BatchNorm2d(o))
+        # stand-in for the pose head's output layer: pooled features -> per-slot, per-anchor
+        # (R as 9 numbers, T as 3) hypotheses -- only so the all-gather moves real data
+        self.pose_head = nn.Linear(512, SLOTS * 12)
+
+    def forward(self, xyz, pose):
+        import vgtk.so3conv as sptk
+        import vgtk.spconv as zptk
+        feats = sptk.get_occupancy_features(xyz.transpose(1, 2), NA, False)
+        x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
+        for conv, norm in zip(self.convs, self.norms):
+            _, _, _, x = conv(x)
+            x = zptk.SphericalPointCloudPose(x.xyz, F.leaky_relu(norm(x.feats)), x.anchors, x.pose)
+        return x.feats
+
+    def hypotheses(self, feats):
+        pooled = feats.mean(2).transpose(1, 2)                       # [B, A, 512]
+        h = self.pose_head(pooled).view(feats.shape[0], NA, SLOTS, 12).transpose(1, 2)
+        return h[..., :9].reshape(feats.shape[0], SLOTS, NA, 3, 3).contiguous(), h[..., 9:].contiguous()
+
+
+CPU_BASELINE_MAX_THREADS = 16   # torch CPU ops of this path slow down beyond ~8-16 threads (measured on the 256-core GPU host)
+
+
+def cpu_baseline(points, slab=64):
+    """Oracle (oracle/so3_ref.py) fwd+bwd of the 3 layers on a slab of `slab` query points of one
+    `points`-point cloud, scaled to the whole cloud.  Faithful = with the reference's 60x60
+    anchor-permutation search; `short_circuit` = search skipped (identity poses)."""
+    import synth_clouds
+    from oracle import so3_ref
+    threads = min(os.cpu_count() or 1, CPU_BASELINE_MAX_THREADS)
+    torch.set_num_threads(threads)
+    consts = np.load(os.path.join(PKG, 'vgtk', 'data', 'anchors', 'constants.npz'))
+    import vgtk.so3conv.functional as L
+    anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors()))
+    xyz, _, pose = synth_clouds.laptop_batch(0, 1, points)
+    xyz, pose = torch.from_numpy(xyz), torch.from_numpy(pose)
+    out = {}
+    for label, skip in (('faithful', False), ('short_circuit', True)):
+        total = 0.0
+        gen = torch.Generator().manual_seed(2913)
+        for (c, o, r, s) in synth_clouds.backbone_layers(points):
+            kern = torch.from_numpy(so3_ref.kernel_points(consts['kpsphere24'], 0.7 * r))
+            feats = (torch.ones(1, 1, points, NA) if c == 1 else torch.randn(1, c, points, NA, generator=gen)).requires_grad_(c > 1)
+            W = torch.randn(o, c * KS, generator=gen).requires_grad_(True)
+            t0 = time.perf_counter()
+            fs = so3_ref.add_shadow_feature(feats)
+            res = so3_ref._poseconv_slab(xyz[:, :, :slab].contiguous(), pose[:, :slab].contiguous(), xyz, pose,
+                                         fs, NN, anchors, kern, r, s, 1, skip)
+            y = so3_ref.basic_so3conv(W, res[3])
+            y.square().mean().backward()
+            total += time.perf_counter() - t0
+        out[label] = 1.0 / (total * points / slab)
+    return {'value': out['faithful'], 'unit': 'point-clouds/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle fwd+bwd of the 3 backbone layers on {slab} of {points} query points of 1 cloud, '
+                      f'scaled x{points // slab}; includes the reference\'s 60x60 anchor-permutation search',
+            'value_perm_search_short_circuited': out['short_circuit']}
+
+
+def summarize_kernels(records, steps):
+    """records of (name, tag, e0, e1) -> per-kernel totals; picks the dominant kernel."""
+    agg = {}
+    for name, tag, e0, e1 in records:
+        ms = e0.elapsed_time(e1)
+        key = (name, tag)
+        a = agg.setdefault(key, [0.0, 0])
+        a[0] += ms
+        a[1] += 1
+    by_name = {}
+    for (name, tag), (ms, cnt) in agg.items():
+        b = by_name.setdefault(name, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
+        b['ms'] += ms
+        b['launches'] += cnt
+        if tag is not None:
+            ta, tb, M, N, K, batch = tag
+            b['flops'] += 2.0 * M * N * K * batch * cnt
+    return by_name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='clouds per GPU per step')
+    ap.add_argument('--points', type=int, default=4096)
+    ap.add_argument('--fwd-only', action='store_true', help='BASELINE config 2 (forward only)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import synth_clouds
+    from vgtk import _hip, sharding
+
+    torch.manual_seed(2913)
+    model = Backbone(args.points).to(dev)
+    conv_params = [p for p in model.parameters()]
+    opt = torch.optim.Adam(conv_params, lr=1e-4)
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(rank * args.batch, args.batch, args.points)
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    pose = torch.from_numpy(pose_np).to(dev)
+
+    def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                feats = model(xyz, pose)
+                R, T = model.hypotheses(feats)
+                sharding.all_gather_pose_hypotheses(R, T)
+            return
+        opt.zero_grad(set_to_none=True)
+        feats = model(xyz, pose)
+        R, T = model.hypotheses(feats)
+        allR, allT = sharding.all_gather_pose_hypotheses(R.detach(), T.detach())
+        loss = feats.square().mean() + R.square().mean() + T.square().mean()
+        loss.backward()
+        sharding.all_reduce_gradients(conv_params)
+        opt.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _hip.KERNEL_TIMES = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        kern = summarize_kernels(records, args.steps)
+        dom_name = max(kern, key=lambda k: kern[k]['ms'])
+        gemm = {'ms': 0.0, 'launches': 0, 'flops': 0.0}
+        for n in ('eap_gemm_f32', 'eap_gemm_f32_reduce'):
+            if n in kern:
+                for k in gemm:
+                    gemm[k] += kern[n][k]
+        achieved = gemm['flops'] / (gemm['ms'] * 1e-3) / 1e12 if gemm['ms'] > 0 else 0.0
+        clouds = args.batch * world * args.steps
+        line = {
+            'metric': 'point-clouds/sec (4096 pts, 60 anchors) ' + ('fwd' if args.fwd_only else 'fwd+bwd'),
+            'value': clouds / dt, 'unit': 'point-clouds/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.batch} x {args.points}-pt synthetic laptop clouds per GPU, 3-block inter '
+                                   f'backbone 1->64->128->512 (NN=64,K=24,A=60), '
+                                   + ('forward' if args.fwd_only else 'forward+backward+Adam'),
+                       'clouds_per_gpu': args.batch, 'points': args.points, 'anchors': NA,
+                       'sharding': f'clouds x{world}, pose all-gather + 1 gradient all-reduce' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'launches': gemm['launches'], 'avg_launch_ms': gemm['ms'] / max(gemm['launches'], 1),
+                         'share_of_kernel_time': gemm['ms'] / max(sum(k['ms'] for k in kern.values()), 1e-9)},
+            'kernel_ms_per_step': {n: k['ms'] / args.steps for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])},
+            'dominant_kernel': dom_name,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.points)
+            line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

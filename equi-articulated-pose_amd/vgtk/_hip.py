@@ -50,11 +50,25 @@ def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def call(name, ref_tensor, *args):
+# Optional per-launch timing (bench.py): when KERNEL_TIMES is a list, every launch is bracketed
+# by two HIP events recorded on the launch stream and (name, tag, start, stop) is appended.
+KERNEL_TIMES = None
+
+
+def call(name, ref_tensor, *args, tag=None):
     """Invoke lib.<name>(*args, stream) under the device of `ref_tensor`; raise on error."""
     fn = getattr(lib, name)
     with torch.cuda.device(ref_tensor.device):
-        rc = fn(*args, stream_of(ref_tensor))
+        if KERNEL_TIMES is not None:
+            stream = torch.cuda.current_stream(ref_tensor.device)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = fn(*args, stream_of(ref_tensor))
+            e1.record(stream)
+            KERNEL_TIMES.append((name, tag, e0, e1))
+        else:
+            rc = fn(*args, stream_of(ref_tensor))
     if rc != 0:
         raise RuntimeError(f'{name} failed (hip error {rc}): {lib.eap_last_error().decode()}')
 
@@ -71,14 +85,16 @@ def suffix(t):
 
 def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch):
     call('eap_gemm_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
-         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch)
+         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch,
+         tag=(int(transA), int(transB), M, N, K, batch))
 
 
 def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch):
     n_ws = lib.eap_gemm_f32_reduce_workspace(M, N, K, batch)
     ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=C.device)
     call('eap_gemm_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
-         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws))
+         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws),
+         tag=(int(transA), int(transB), M, N, K, batch))
 
 
 def so3_prep(q_xyz, s_xyz, idx, q_pose, s_pose, anchors, identity_anchor):
