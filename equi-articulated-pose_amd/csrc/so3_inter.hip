@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void so3_prep_kernel(
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float kernel_weight_exact(float gx, float gy, float gz, float kx, float ky,
                                                      float kz, float sigma) {
+#pragma clang fp contract(off)
     // same operation order as torch: sum((g - rk)^2) then 1 - d/sigma, one rounding each
     const float dx = __fsub_rn(gx, kx), dy = __fsub_rn(gy, ky), dz = __fsub_rn(gz, kz);
     const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));

@@ -319,3 +319,59 @@ def test_equivariance_property(dev, vg):
         pi = torch.from_numpy(mult[inv[j]].astype(np.int64)).to(dev)     # A_pi(a) = A_j^T A_a
         assert rel_err(a1.detach().cpu().numpy(), a0[..., pi].detach().cpu().numpy()) < 2e-5
         assert rel_err(b1.detach().cpu().numpy(), b0[..., pi].detach().cpu().numpy()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# remaining native entry points
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,m', [(64, 128), (512, 4096), (1500, 777)])
+def test_chamfer(dev, vg, n, m):
+    from extensions.chamfer_dist import ChamferDistance, ChamferFunction
+    rng = np.random.default_rng(5)
+    x1 = rng.standard_normal((3, n, 3)).astype(np.float32)
+    x2 = rng.standard_normal((3, m, 3)).astype(np.float32)
+    d1, d2, i1, i2 = native.chamfer_forward(x1, x2)
+    t1 = T(x1).to(dev).requires_grad_(True); t2 = T(x2).to(dev).requires_grad_(True)
+    import chamfer
+    o1, o2, j1, j2 = chamfer.forward(t1.detach(), t2.detach())
+    np.testing.assert_array_equal(j1.cpu().numpy(), i1)
+    np.testing.assert_array_equal(j2.cpu().numpy(), i2)
+    np.testing.assert_array_equal(o1.cpu().numpy(), d1)
+    np.testing.assert_array_equal(o2.cpu().numpy(), d2)
+    g1 = rng.standard_normal(d1.shape).astype(np.float32); g2 = rng.standard_normal(d2.shape).astype(np.float32)
+    a, b = ChamferFunction.apply(t1, t2)
+    (a * T(g1).to(dev)).sum().add((b * T(g2).to(dev)).sum()).backward()
+    r1, r2 = native.chamfer_backward(x1, x2, i1, i2, g1, g2)
+    assert rel_err(t1.grad.cpu().numpy(), r1) < 1e-5 and rel_err(t2.grad.cpu().numpy(), r2) < 1e-5
+    loss = ChamferDistance()(t1, t2)
+    assert abs(loss.item() - (d1.mean() + d2.mean())) < 1e-5
+
+
+@pytest.mark.parametrize('n,m', [(100, 17), (1024, 256), (4096, 64), (333, 333)])
+def test_furthest_point_sampling(dev, n, m):
+    import synth_clouds
+    import vgtk.cuda.grouping as G
+    xyz = synth_clouds.laptop_batch(11, 2, n)[0]
+    xyz[:, :, 5] = 0.0    # a point at the origin is skipped by the reference (|x|^2 <= 1e-3)
+    got = G.furthest_point_sampling(T(xyz).to(dev), m).cpu().numpy()
+    np.testing.assert_array_equal(got, native.furthest_point_sampling(xyz, m))
+
+
+def test_anchor_queries(dev):
+    import vgtk.cuda.grouping as G
+    rng = np.random.default_rng(6)
+    gx = (rng.random((2, 3, 9, 8)).astype(np.float32) - 0.5)
+    anchors = rng.standard_normal((12, 3)).astype(np.float32)
+    anchors /= np.linalg.norm(anchors, axis=1, keepdims=True)
+    kp = rng.random((5, 2)).astype(np.float32)
+    z = torch.zeros(2, 9, dtype=torch.int32, device=dev)
+    got = G.anchor_query(z, torch.zeros(2, 9, 8, dtype=torch.int32, device=dev), T(gx).to(dev), T(anchors).to(dev), T(kp).to(dev), 10)[0]
+    ref = native.anchor_query(None, None, gx, anchors, kp, 10)[0]
+    assert rel_err(got.cpu().numpy(), ref) < 1e-5
+    centers = (rng.random((2, 3, 6)).astype(np.float32) - 0.5)
+    frag = (rng.random((200, 3)).astype(np.float32) - 0.5)
+    kpts = (rng.random((4, 7, 3)).astype(np.float32) - 0.5) * 0.3
+    w, cnt = G.initial_anchor_query(T(centers).to(dev), T(frag).to(dev), T(kpts).to(dev), 0.4, 0.05)
+    rw, rc = native.initial_anchor_query(centers, frag, kpts, 0.4, 0.05)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
+    assert rel_err(w.cpu().numpy(), rw) < 1e-5

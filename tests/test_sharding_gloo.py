@@ -1,0 +1,72 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the hot path -- clouds sharded across ranks
+with no data-path collective, one pose-hypothesis all-gather, one bucketed gradient all-reduce."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, os.path.join(root, 'equi-articulated-pose_amd'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vgtk import sharding
+    import synth_clouds
+
+    # 1. contiguous cloud shards cover the batch exactly once
+    start, stop = sharding.shard_range(7)
+    # 2. pose-hypothesis all-gather: every rank ends with all clouds, rank-major
+    b_loc, S, A = 3, 2, 60
+    gen = torch.Generator().manual_seed(100 + rank)
+    R = torch.randn(b_loc, S, A, 3, 3, generator=gen)
+    Tt = torch.randn(b_loc, S, A, 3, generator=gen)
+    allR, allT = sharding.all_gather_pose_hypotheses(R, Tt)
+    # 3. bucketed gradient all-reduce (average)
+    params = [torch.nn.Parameter(torch.zeros(4, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+    params[0].grad = torch.full((4, 5), float(rank + 1))
+    params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+    sharding.all_reduce_gradients(params)   # params[2] has no grad: skipped
+    # 4. sharded synthetic clouds are the global batch, split
+    xyz = synth_clouds.laptop_batch(rank * 2, 2, 64)[0]
+    np.savez(os.path.join(out_dir, f'r{rank}.npz'), start=start, stop=stop, allR=allR.numpy(), allT=allT.numpy(),
+             R=R.numpy(), T=Tt.numpy(), g0=params[0].grad.numpy(), g1=params[1].grad.numpy(), xyz=xyz)
+    dist.destroy_process_group()
+
+
+def test_world_size_2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(tmp_path / f'r{i}.npz')) for i in range(world)]
+    assert (int(r[0]['start']), int(r[0]['stop'])) == (0, 4) and (int(r[1]['start']), int(r[1]['stop'])) == (4, 7)
+    for i in range(world):
+        np.testing.assert_array_equal(r[i]['allR'], np.concatenate([r[0]['R'], r[1]['R']]))
+        np.testing.assert_array_equal(r[i]['allT'], np.concatenate([r[0]['T'], r[1]['T']]))
+        np.testing.assert_allclose(r[i]['g0'], np.full((4, 5), 1.5))
+        np.testing.assert_allclose(r[i]['g1'], np.arange(7) * 1.5)
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'equi-articulated-pose_amd'))
+    import synth_clouds
+    full = synth_clouds.laptop_batch(0, 4, 64)[0]
+    np.testing.assert_array_equal(np.concatenate([r[0]['xyz'], r[1]['xyz']]), full)
+
+
+def test_single_process_is_identity():
+    from vgtk import sharding
+    R, Tt = torch.randn(2, 2, 60, 3, 3), torch.randn(2, 2, 60, 3)
+    a, b = sharding.all_gather_pose_hypotheses(R, Tt)
+    assert a is R and b is Tt
+    assert sharding.shard_range(10) == (0, 10)
+    assert sharding.shard_range(10, rank=1, world=4) == (3, 6)
