@@ -26,6 +26,7 @@ if not os.path.exists(LIB_PATH):
 lib = ctypes.CDLL(LIB_PATH)
 lib.eap_last_error.restype = ctypes.c_char_p
 lib.eap_gemm_f32_reduce_workspace.restype = ctypes.c_int64
+lib.eap_so3_inter_group_bwd_workspace.restype = ctypes.c_int64
 
 _I64 = ctypes.c_int64
 _F32 = ctypes.c_float
@@ -133,10 +134,19 @@ def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma):
     return out
 
 
-def so3_inter_group_bwd(gout, idx, gx, rk, mult, sigma, n):
+FORCE_ATOMIC_BWD = False
+
+
+def so3_inter_group_bwd(gout, idx, gx, rk, mult, sigma, n, identity_anchor=0):
     b, c, ks, p, na = gout.shape
     nn = idx.shape[2]
     gfeats = torch.empty(b, c, n, na, dtype=torch.float32, device=gout.device)
+    if ks <= 24 and na % 4 == 0 and not FORCE_ATOMIC_BWD:
+        ws = torch.empty(int(lib.eap_so3_inter_group_bwd_workspace(b, c, p, n, na)), dtype=torch.float32,
+                         device=gout.device)
+        call('eap_so3_inter_group_bwd_slab_f32', gfeats, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(gout), _ptr(idx),
+             _ptr(gx), _ptr(rk), _ptr(mult), int(identity_anchor), _ptr(gfeats), _ptr(ws))
+        return gfeats
     call('eap_so3_inter_group_bwd_f32', gfeats, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(gout), _ptr(idx),
          _ptr(gx), _ptr(rk), _ptr(mult), _ptr(gfeats))
     return gfeats

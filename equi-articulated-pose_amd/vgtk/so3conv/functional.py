@@ -158,8 +158,9 @@ class _InterGroup(torch.autograd.Function):
     """new_feats[b,c,k,p,a] = sum_n feats[b,c,idx_n,perm_n(a)] w(p,a,k,n)  (functional.py:L1221-1261)."""
 
     @staticmethod
-    def forward(ctx, feats, idx, gx, rk, mult, sigma):
+    def forward(ctx, feats, idx, gx, rk, mult, sigma, ident=0):
         feats = feats.contiguous()
+        ctx.ident = ident
         ctx.save_for_backward(idx, gx, rk, mult if mult is not None else torch.empty(0))
         ctx.has_mult = mult is not None
         ctx.sigma = sigma
@@ -170,8 +171,8 @@ class _InterGroup(torch.autograd.Function):
     def backward(ctx, gout):
         idx, gx, rk, mult = ctx.saved_tensors
         g = _hip.so3_inter_group_bwd(gout.contiguous(), idx, gx, rk, mult if ctx.has_mult else None,
-                                     ctx.sigma, ctx.n)
-        return g, None, None, None, None, None
+                                     ctx.sigma, ctx.n, ctx.ident)
+        return g, None, None, None, None, None, None
 
 
 class _IntraGroup(torch.autograd.Function):
@@ -258,7 +259,7 @@ def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, 
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
     gx = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
-    new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma))
+    new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), new_feats
 

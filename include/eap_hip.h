@@ -145,6 +145,15 @@ int eap_so3_inter_group_bwd_f32(int b, int c, int p, int n, int nn, int na, int 
                                 const float *rk, const uint8_t *mult, float *gfeats,
                                 eap_stream_t stream);
 
+/* Atomics-free variant of so3_inter_group_bwd (ks <= 24, na % 4 == 0): every block owns a private slab of
+ * partial sums in `workspace` (eap_so3_inter_group_bwd_workspace floats, zeroed by the call) and
+ * a second kernel reduces the slabs -- deterministic, and ~4x faster than fp32 row atomics. */
+int64_t eap_so3_inter_group_bwd_workspace(int b, int c, int p, int n, int na);
+int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                     const float *gout, const int32_t *idx, const float *gx,
+                                     const float *rk, const uint8_t *mult, int identity_anchor,
+                                     float *gfeats, float *workspace, eap_stream_t stream);
+
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 
 /* so3_intra_group_fwd: intra_so3conv_grouping, so3conv/functional.py:L2553-2602.

@@ -48,5 +48,5 @@ for li, (c, o, r, s) in enumerate(synth_clouds.backbone_layers(P)):
         gW = torch.empty_like(W)
         timed(f'L{li} gemm dW', lambda: _hip.gemm_reduce(0, 1, o, c * 24, P * 60, gy, P * 60, o * P * 60, Xv, P * 60, c * 24 * P * 60, gW, c * 24, B))
         if c > 1:
-            timed(f'L{li} group_bwd', lambda: _hip.so3_inter_group_bwd(gX.view(B, c, 24, P, 60), idx, gx, rk, mult, s, P), reps=1)
+            timed(f'L{li} group_bwd', lambda: _hip.so3_inter_group_bwd(gX.view(B, c, 24, P, 60), idx, gx, rk, mult, s, P, ident), reps=1)
     del X, Y
