@@ -39,3 +39,15 @@ static inline hipStream_t S(eap_stream_t s) { return (hipStream_t)s; }
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace eap
+
+#ifdef __HIPCC__
+// Consecutive points must land on the SAME XCD: each (channel, k) output row of a point is only
+// 4*na bytes, so neighbouring points share cache lines; with the default round-robin dispatch
+// (block b -> XCD b % 8) they would sit half-written in eight different L2s and reach HBM as
+// partial lines (measured: X written at ~1 TB/s).  Remap so that XCD x gets a contiguous range
+// of points (bijective for any P).
+__device__ __forceinline__ int xcd_point(int bx, int p) {
+    const int q = p >> 3, r = p & 7, xcd = bx & 7, j = bx >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+#endif

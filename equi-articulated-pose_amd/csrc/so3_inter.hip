@@ -128,7 +128,7 @@ __global__ __launch_bounds__(G_THREADS) void so3_inter_group_fwd_kernel(
     int32_t *s_q = reinterpret_cast<int32_t *>(smem + 16 * (size_t)nn);  // [nn]
     uint8_t *s_mult = smem + 20 * (size_t)nn;                      // [na*na] (only if mult)
 
-    const int pi = blockIdx.x, bi = blockIdx.y;
+    const int pi = xcd_point(blockIdx.x, p), bi = blockIdx.y;
     const size_t pn = ((size_t)bi * p + pi) * nn;
     for (int i = threadIdx.x; i < nn; i += G_THREADS) {
         s_g[i] = gx[pn + i];
@@ -321,6 +321,21 @@ extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, i
     if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd: at most 32 kernel points (use the zpconv op)");
+    if (nn <= 0)
+        return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, eap::S(stream)), "so3_inter_group_fwd memset");
+    // >= 16 channels: matrix-core formulation (csrc/so3_inter_mfma.hip); fewer: the VALU kernel
+    // below (a 32-channel MFMA tile would be mostly padding)
+    if (c >= 16) return eap_so3_inter_group_fwd_mfma_f32(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, stream);
+    if (ks <= 24) return launch_group_fwd<6>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
+    return launch_group_fwd<8>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
+}
+
+extern "C" int eap_so3_inter_group_fwd_valu_f32(int b, int c, int p, int n, int nn, int na, int ks,
+                                                float sigma, const float *feats, const int32_t *idx,
+                                                const float *gx, const float *rk, const uint8_t *mult,
+                                                float *out, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
+    if (na > 64 || ks > 32) return eap::bad_arg("so3_inter_group_fwd_valu: at most 64 anchors / 32 kernel points");
     if (nn <= 0)
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, eap::S(stream)), "so3_inter_group_fwd memset");
     if (ks <= 24) return launch_group_fwd<6>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));

@@ -138,6 +138,18 @@ int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, int na, int 
                                 const float *feats, const int32_t *idx, const float *gx,
                                 const float *rk, const uint8_t *mult, float *out,
                                 eap_stream_t stream);
+/* The two implementations behind so3_inter_group_fwd, exported for tests and profiling:
+ * _mfma (c >= 16): v_mfma_f32_32x32x2_f32 with the kernel weights generated in registers as the
+ * B operand; _valu: lanes = anchors, register tile of channels x kernel points. */
+int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                     const float *feats, const int32_t *idx, const float *gx,
+                                     const float *rk, const uint8_t *mult, float *out,
+                                     eap_stream_t stream);
+int eap_so3_inter_group_fwd_valu_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                     const float *feats, const int32_t *idx, const float *gx,
+                                     const float *rk, const uint8_t *mult, float *out,
+                                     eap_stream_t stream);
+
 /* so3_inter_group_bwd: transpose of the above w.r.t. feats.
  * gout [b,c,ks,p,na] -> gfeats [b,c,n,na] (zero-initialised by the call, fp32 atomics). */
 int eap_so3_inter_group_bwd_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,

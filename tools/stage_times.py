@@ -17,13 +17,15 @@ xyz, _, pose = synth_clouds.laptop_batch(0, B, P)
 xyz, pose = torch.from_numpy(xyz).to(dev), torch.from_numpy(pose).to(dev)
 
 
-def timed(label, fn, reps=2):
+def timed(label, fn, reps=5):
     fn(); torch.cuda.synchronize()
-    t = time.perf_counter()
+    ts = []
     for _ in range(reps):
-        out = fn()
-    torch.cuda.synchronize()
-    print(f'{label:40s} {(time.perf_counter() - t) / reps * 1e3:10.2f} ms', flush=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    print(f'{label:40s} min {ts[0]:9.2f}  med {ts[len(ts) // 2]:9.2f}  max {ts[-1]:9.2f} ms', flush=True)
     return out
 
 
@@ -48,5 +50,5 @@ for li, (c, o, r, s) in enumerate(synth_clouds.backbone_layers(P)):
         gW = torch.empty_like(W)
         timed(f'L{li} gemm dW', lambda: _hip.gemm_reduce(0, 1, o, c * 24, P * 60, gy, P * 60, o * P * 60, Xv, P * 60, c * 24 * P * 60, gW, c * 24, B))
         if c > 1:
-            timed(f'L{li} group_bwd', lambda: _hip.so3_inter_group_bwd(gX.view(B, c, 24, P, 60), idx, gx, rk, mult, s, P, ident), reps=1)
+            timed(f'L{li} group_bwd', lambda: _hip.so3_inter_group_bwd(gX.view(B, c, 24, P, 60), idx, gx, rk, mult, s, P, ident))
     del X, Y
