@@ -7,8 +7,8 @@
 // fp32-input MFMA is bit-for-bit an fmaf chain (no reduced-precision path), so results carry
 // plain fp32 rounding -- required by the 1e-4 pose tolerance after three layers.
 //
-// Structure: 256 threads = 4 waves (2x2), block tile BM x 128 x 16, wave tile (BM/2) x 64 made
-// of 32x32 MFMA tiles, LDS double-buffered with register prefetch of the next k-tile (one
+// Structure: NWM x NWN waves per block (default 4x2 = 512 threads, block tile 256 x 128 x 16), wave
+// tile 64 x 64 made of 32x32 MFMA tiles, LDS double-buffered with register prefetch of the next k-tile (one
 // barrier per k-tile).  LDS tiles are stored k-major ([BK][BM+4] / [BK][BN+4]) so a wave's
 // fragment read (lane -> row/col l&31, k = l>>5) is 32 consecutive floats per half-wave:
 // conflict-free ds_read_b32.  The block -> tile map is XCD-aware: blocks that share a column
@@ -16,13 +16,15 @@
 // so the panel is fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BN = 128, BK = 16, PAD = 4, NT = 256;
+constexpr int BK = 16, PAD = 4;
 
-template <int BM>
+template <int BM, int BN>
 struct Smem {
     float a[2][BK][BM + PAD];
     float b[2][BK][BN + PAD];
@@ -58,12 +60,15 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ base, long lon
     return v;
 }
 
-template <int BM, bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ Smem<BM> sm;
-    constexpr int MT = BM / 64;           // 32x32 MFMA tiles per wave along M
+// NWM x NWN waves per block, every wave owns a WTM x 64 tile (WTM = 64, or 32 for the small-M variant)
+template <int NWM, int NWN, int WTM, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = WTM * NWM, BN = 64 * NWN, NT = 64 * NWM * NWN;
+    __shared__ Smem<BM, BN> sm;
+    constexpr int MT = WTM / 32;          // 32x32 MFMA tiles per wave along M
     constexpr int A_V4 = BM * BK / 4 / NT;  // float4 loads per thread for the A tile
     constexpr int B_V4 = BN * BK / 4 / NT;
+    static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for the thread count");
 
     // ---- XCD-aware tile mapping -------------------------------------------------------------
     // linear id -> (xcd = id % 8, slot = id / 8); the tiles_m row tiles of one column panel sit
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs g) {
     float *C = g.C + (long long)z * g.sC;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
 
     float4 ra[A_V4], rb[B_V4];
 
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int u = 0; u < B_V4; ++u) {
             if (!TB) {   // B [K,N]: n contiguous
-                const int k = (t >> 5) + u * (NT / 32), jq = (t & 31) * 4;
+                const int k = (t / (BN / 4)) + u * (NT / (BN / 4)), jq = (t % (BN / 4)) * 4;
                 rb[u] = load4<VEC>(B, g.ldb, k0 + k, n0 + jq, kend, g.N);
             } else {     // B stored [N,K]: k contiguous
                 const int r = (t >> 2) + u * (NT / 4), kq = (t & 3) * 4;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int u = 0; u < B_V4; ++u) {
             if (!TB) {
-                const int k = (t >> 5) + u * (NT / 32), jq = (t & 31) * 4;
+                const int k = (t / (BN / 4)) + u * (NT / (BN / 4)), jq = (t % (BN / 4)) * 4;
                 *reinterpret_cast<float4 *>(&sm.b[buf][k][jq]) = rb[u];
             } else {
                 const int r = (t >> 2) + u * (NT / 4), kq = (t & 3) * 4;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs g) {
         for (int kk = 0; kk < BK; kk += 2) {
             float af[MT], bf[2];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = sm.a[buf][kk + lk][wm * (BM / 2) + i * 32 + li];
+            for (int i = 0; i < MT; ++i) af[i] = sm.a[buf][kk + lk][wm * WTM + i * 32 + li];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = sm.b[buf][kk + lk][wn * 64 + j * 32 + li];
 #pragma unroll
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + li;
-            const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+            const int rbase = m0 + wm * WTM + i * 32 + 4 * lk;
             if (col < g.N) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -203,15 +208,15 @@ __global__ void reduce_slabs_kernel(long long mn, int N, int slabs, const float 
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int BM>
+template <int NWM, int NWN, int WTM>
 int launch(bool ta, bool tb, const GemmArgs &g, int zcount, hipStream_t s) {
     const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
                      g.sA % 4 == 0 && g.sB % 4 == 0;
-    dim3 grid(g.tiles_m * g.tiles_n, zcount), block(NT);
-#define EAP_GEMM_LAUNCH(TA, TB)                                                                  \
-    do {                                                                                         \
-        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, TA, TB, true>), grid, block, 0, s, g);  \
-        else hipLaunchKernelGGL((gemm_f32_kernel<BM, TA, TB, false>), grid, block, 0, s, g);     \
+    dim3 grid(g.tiles_m * g.tiles_n, zcount), block(64 * NWM * NWN);
+#define EAP_GEMM_LAUNCH(TA, TB)                                                                              \
+    do {                                                                                                     \
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<NWM, NWN, WTM, TA, TB, true>), grid, block, 0, s, g);   \
+        else hipLaunchKernelGGL((gemm_f32_kernel<NWM, NWN, WTM, TA, TB, false>), grid, block, 0, s, g);      \
     } while (0)
     if (!ta && !tb) EAP_GEMM_LAUNCH(false, false);
     else if (ta && !tb) EAP_GEMM_LAUNCH(true, false);
@@ -221,18 +226,31 @@ int launch(bool ta, bool tb, const GemmArgs &g, int zcount, hipStream_t s) {
     return eap::check_launch("gemm_f32");
 }
 
+int tile_config() {   // dev knob: EAP_GEMM_TILE = 0 (128x128) | 1 (256x128, default: +2% on the L2-layer shape) | 2 (128x256)
+    static int cfg = -1;
+    if (cfg < 0) { const char *e = getenv("EAP_GEMM_TILE"); cfg = e ? atoi(e) : 1; }
+    return cfg;
+}
+
 int run(bool ta, bool tb, GemmArgs g, int zcount, hipStream_t s) {
-    const bool small_m = g.M <= 64;
-    const int bm = small_m ? 64 : 128;
-    g.tiles_m = (g.M + bm - 1) / bm;
-    g.tiles_n = (g.N + BN - 1) / BN;
     if (zcount > 65535) return eap::bad_arg("gemm_f32: batch*splits exceeds 65535");
-    return small_m ? launch<64>(ta, tb, g, zcount, s) : launch<128>(ta, tb, g, zcount, s);
+    int bm, bn;
+    const int cfg = tile_config();
+    if (g.M <= 64) { bm = 64; bn = 128; }
+    else if (cfg == 1 && g.M >= 256) { bm = 256; bn = 128; }
+    else if (cfg == 2 && g.N >= 256) { bm = 128; bn = 256; }
+    else { bm = 128; bn = 128; }
+    g.tiles_m = (g.M + bm - 1) / bm;
+    g.tiles_n = (g.N + bn - 1) / bn;
+    if (bm == 64) return launch<2, 2, 32>(ta, tb, g, zcount, s);
+    if (bm == 256) return launch<4, 2, 64>(ta, tb, g, zcount, s);
+    if (bn == 256) return launch<2, 4, 64>(ta, tb, g, zcount, s);
+    return launch<2, 2, 64>(ta, tb, g, zcount, s);
 }
 
 int pick_splits(int M, int N, int K, int batch) {
     // enough blocks to fill 256 CUs twice over, at least 4 k-tiles per split
-    const int tiles = ((M + 127) / 128) * ((N + BN - 1) / BN) * batch;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128) * batch;
     int splits = (2048 + tiles - 1) / tiles;
     const int max_splits = (K + 4 * BK - 1) / (4 * BK);
     if (splits > max_splits) splits = max_splits;

@@ -375,3 +375,89 @@ def test_anchor_queries(dev):
     rw, rc = native.initial_anchor_query(centers, frag, kpts, 0.4, 0.05)
     np.testing.assert_array_equal(cnt.cpu().numpy(), rc)
     assert rel_err(w.cpu().numpy(), rw) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json sizes (4096 points): size-independent properties instead of an oracle run
+# ------------------------------------------------------------------------------------------------
+def _raw_group(dev, B, P, C, layer, valu=False):
+    import ctypes
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.so3conv.functional as L
+    import vgtk.cuda.grouping as G
+    from vgtk import _hip
+    c, o, r, s = synth_clouds.backbone_layers(P)[layer]
+    xyz, _, pose = synth_clouds.laptop_batch(20, B, P)
+    xyz, pose = T(xyz).to(dev), T(pose).to(dev)
+    conv = sptk.InterSO3PoseConv(C, 8, 1, 1, r, s, 64, kanchor=60, permute_modes=1).to(dev)
+    idx = G.ball_query(xyz, xyz, r, 64)
+    mult, ident = L._group_tables(conv.anchors)
+    rk = L.rotated_kernels(conv.anchors, conv.kernels)
+    gx = _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident)
+    return idx, gx, rk, mult, s, ident
+
+
+def test_full_size_group_mfma_equals_valu_and_is_linear(dev, vg):
+    """4096-point clouds, C=64 (BASELINE config 2 shapes): the matrix-core grouping against the
+    independent VALU kernel, linearity in the features, and run-to-run bit reproducibility."""
+    import ctypes
+    from vgtk import _hip
+    B, P, C = 2, 4096, 64
+    idx, gx, rk, mult, sigma, ident = _raw_group(dev, B, P, C, 1)
+    gen = torch.Generator().manual_seed(9)
+    f1 = torch.randn(B, C, P, 60, generator=gen).to(dev)
+    f2 = torch.randn(B, C, P, 60, generator=gen).to(dev)
+    x1 = _hip.so3_inter_group_fwd(f1, idx, gx, rk, mult, sigma)
+    x1b = _hip.so3_inter_group_fwd(f1, idx, gx, rk, mult, sigma)
+    assert torch.equal(x1, x1b)                                    # deterministic (no atomics)
+    ref = torch.empty_like(x1)
+    _hip.call('eap_so3_inter_group_fwd_valu_f32', ref, B, C, P, P, 64, 60, 24, ctypes.c_float(sigma), _hip._ptr(f1),
+              _hip._ptr(idx), _hip._ptr(gx), _hip._ptr(rk), _hip._ptr(mult), _hip._ptr(ref))
+    scale = ref.abs().max().item()
+    assert (x1 - ref).abs().max().item() < 2e-5 * scale
+    x2 = _hip.so3_inter_group_fwd(f2, idx, gx, rk, mult, sigma)
+    x12 = _hip.so3_inter_group_fwd(2.0 * f1 - 0.5 * f2, idx, gx, rk, mult, sigma)
+    assert (x12 - (2.0 * x1 - 0.5 * x2)).abs().max().item() < 2e-5 * scale
+
+
+def test_full_size_backward_is_the_adjoint(dev, vg):
+    """<G(f), g> == <f, G^T(g)> at 4096 points for both backward implementations (slab / atomics)."""
+    from vgtk import _hip
+    B, P, C = 1, 4096, 32
+    idx, gx, rk, mult, sigma, ident = _raw_group(dev, B, P, C, 2)
+    gen = torch.Generator().manual_seed(10)
+    f = torch.randn(B, C, P, 60, generator=gen).to(dev)
+    x = _hip.so3_inter_group_fwd(f, idx, gx, rk, mult, sigma)
+    g = torch.randn(x.shape, generator=gen).to(dev)
+    lhs = (x.double() * g.double()).sum().item()
+    for force_atomic in (False, True):
+        _hip.FORCE_ATOMIC_BWD = force_atomic
+        try:
+            gf = _hip.so3_inter_group_bwd(g, idx, gx, rk, mult, sigma, P, ident)
+        finally:
+            _hip.FORCE_ATOMIC_BWD = False
+        rhs = (f.double() * gf.double()).sum().item()
+        assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0), (force_atomic, lhs, rhs)
+    a = _hip.so3_inter_group_bwd(g, idx, gx, rk, mult, sigma, P, ident)
+    b = _hip.so3_inter_group_bwd(g, idx, gx, rk, mult, sigma, P, ident)
+    assert torch.equal(a, b)                                       # slab backward is bit-reproducible
+
+
+def test_full_size_ball_query_properties(dev):
+    """4096 points, all three radii: every returned neighbour is inside the ball, lists are sorted
+    until the padding starts, and the query itself is among its neighbours when it fits."""
+    import synth_clouds
+    import vgtk.cuda.grouping as G
+    xyz = T(synth_clouds.laptop_batch(30, 4, 4096)[0]).to(dev)
+    for (_, _, r, _) in synth_clouds.backbone_layers(4096):
+        idx = G.ball_query(xyz, xyz, r, 64).long()
+        nb = torch.gather(xyz.unsqueeze(2).expand(-1, -1, 4096, -1), 3, idx.unsqueeze(1).expand(-1, 3, -1, -1))
+        d2 = ((nb - xyz.unsqueeze(3)) ** 2).sum(1)
+        outside = d2 >= r * r * (1 + 1e-5)
+        # the reference's padding quirk: with exactly nsample-1 hits the last slot is index 0,
+        # which need not be inside the ball (grouping_cuda_kernel.cu:L100-105)
+        assert not outside[:, :, :-1].any()
+        assert (idx[:, :, -1][outside[:, :, -1]] == 0).all()
+        first = idx[:, :, 0]
+        assert (first <= torch.arange(4096, device=dev)).all()      # index order: first hit <= self
