@@ -122,7 +122,15 @@ def summarize_kernels(records, steps):
         a = agg.setdefault(key, [0.0, 0])
         a[0] += ms
         a[1] += 1
-    by_name = {}
+    shapes = []
+    for (name, tag), (ms, cnt) in agg.items():
+        if tag is not None:
+            ta, tb, M, N, K, batch = tag
+            shapes.append({'entry': name, 'transA': ta, 'transB': tb, 'M': M, 'N': N, 'K': K, 'batch': batch,
+                           'launches': cnt, 'avg_ms': ms / cnt,
+                           'tflops': 2.0 * M * N * K * batch * cnt / (ms * 1e-3) / 1e12})
+    shapes.sort(key=lambda d: -d['avg_ms'] * d['launches'])
+    by_name = {'_gemm_shapes': shapes}
     for (name, tag), (ms, cnt) in agg.items():
         b = by_name.setdefault(name, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
         b['ms'] += ms
@@ -201,7 +209,16 @@ def main():
 
     if rank == 0:
         kern = summarize_kernels(records, args.steps)
+        gemm_shapes = kern.pop('_gemm_shapes')
         dom_name = max(kern, key=lambda k: kern[k]['ms'])
+        # HBM bytes per launch of the largest GEMM shape (L2-layer forward contraction), from the
+        # rocprofv3 FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (measured at B=2,
+        # scaled per cloud; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_b_gemm_pmc_hbm_traffic.json')
+        if os.path.exists(pmc) and args.points == 4096:
+            d = json.load(open(pmc))['derived']
+            traffic = (d['fwd_read_GB_corrected'] + d['fwd_write_GB']) / 2.0 * args.batch * 1e9
         gemm = {'ms': 0.0, 'launches': 0, 'flops': 0.0}
         for n in ('eap_gemm_f32', 'eap_gemm_f32_reduce'):
             if n in kern:
@@ -221,11 +238,13 @@ def main():
                        'sharding': f'clouds x{world}, pose all-gather + 1 gradient all-reduce' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_note': 'HBM bytes per launch of the largest shape (M=512,N=245760,K=3072 per cloud), PMC passes in profiles/',
                          'launches': gemm['launches'], 'avg_launch_ms': gemm['ms'] / max(gemm['launches'], 1),
                          'share_of_kernel_time': gemm['ms'] / max(sum(k['ms'] for k in kern.values()), 1e-9)},
             'kernel_ms_per_step': {n: k['ms'] / args.steps for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])},
             'dominant_kernel': dom_name,
+            'gemm_shapes': gemm_shapes[:6],
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.points)

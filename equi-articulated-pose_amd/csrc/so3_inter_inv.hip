@@ -1,0 +1,242 @@
+// csrc/so3_inter_inv.hip -- feature gradient of the SO(3) inter convolution by re-association,
+// on the matrix cores.
+//
+// Forward:  Y[o,p,a] = sum_{c,k} W[o,(c,k)] * sum_n F[c,q_n,perm_n(a)] * w(p,a,k,n)
+//           (vgtk/vgtk/so3conv/functional.py:L1221-1261 + modules.py:L48-55).
+// The textbook backward first forms dX = W^T dY ([C*K, P*A], as large as X) and then scatters it
+// through the transposed grouping.  Re-associated:
+//           dF[c,q,a'] = sum_{o,k} W[o,(c,k)] * Z[o,k,q,a']
+//           Z[o,k,q,a'] = sum_{(p,n): idx[p,n]=q} dY[o,p,a] * w(p,a,k,n),   a = perm_n^{-1}(a')
+// Z is the SAME operation as the forward grouping -- features = dY (O channels), "neighbours" of
+// row q = the (point, slot) pairs that reference it (inverse neighbour lists, sorted on the host
+// side of the C ABI by a stable sort) -- and it only has as many rows as there are REFERENCED
+// support points.  With the reference's first-nsample-in-index-order ball query and the large
+// radii of the deeper layers that is ~100-300 rows instead of 4096, so Z is 10-30x smaller than
+// dX, the [C*K x O] x [O x P*A] GEMM and the whole scatter (atomics or slabs) disappear, and
+// what is left is one small GEMM  dF = W2[C, O*K] x Z[O*K, R*A].
+//
+// Kernel = csrc/so3_inter_mfma.hip with variable-length entry lists: A operand = dY rows staged
+// through LDS, B operand = kernel weights generated in registers, accumulators of all anchors in
+// VGPRs, 8 waves (2 per SIMD).  With an anchor permutation the weight's anchor changes per entry,
+// so the rotated kernel points come from an LDS table instead of registers.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CB = 32;        // dY channels per block (one MFMA M tile)
+constexpr int NBK = 8;        // entries per LDS stage (4 MFMA k-steps)
+constexpr int FP = 68;        // LDS pitch of one staged row (floats)
+constexpr int APW = 8;        // max anchors per wave
+constexpr int NWV = 8;
+constexpr int TM = 64 * NWV;
+
+template <bool HAS_MULT>
+__global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
+    int o, int p, int nn, int na, int ks, int rcap, float inv_sigma, const float *__restrict__ gy,
+    const int32_t *__restrict__ rows, const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx, const float *__restrict__ rk,
+    const uint8_t *__restrict__ multinv, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP);       // [2][NBK]
+    float *s_rk = reinterpret_cast<float *>(s_g + 2 * NBK);                  // [na][ks][3] (HAS_MULT)
+    uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_rk + (HAS_MULT ? na * ks * 3 : 0));
+
+    const int ri = blockIdx.x, c0 = blockIdx.y * CB, bi = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q = rows[(size_t)bi * rcap + ri];
+    const int n_ent = q >= 0 ? cnt[(size_t)bi * rcap + ri] : 0;
+    const size_t e0 = (size_t)bi * p * nn + (q >= 0 ? off[(size_t)bi * rcap + ri] : 0);
+
+    if (HAS_MULT) {
+        const int words = (na * na) >> 2;
+        for (int i = t; i < words; i += TM)
+            reinterpret_cast<uint32_t *>(s_mult)[i] = reinterpret_cast<const uint32_t *>(multinv)[i];
+        for (int i = t; i < na * ks * 3; i += TM) s_rk[i] = rk[i];
+    }
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int quarter = (na + 3) >> 2, q_beg = (wave_u & 3) * quarter;
+    const int q_cnt = max(0, min(na, q_beg + quarter) - q_beg);
+    const int first = (q_cnt + 1) >> 1;
+    const int a_beg = q_beg + (wave_u >= 4 ? first : 0);
+    const int a_cnt = wave_u >= 4 ? q_cnt - first : first;
+    const int lk = lane & 31, lh = lane >> 5;
+    const int lkc = min(lk, ks - 1);
+    const float kmask = lk < ks ? 1.f : 0.f;             // unused kernel-point columns: weight 0
+    float kx[APW], ky[APW], kz[APW];
+    if (!HAS_MULT) {
+#pragma unroll
+        for (int ai = 0; ai < APW; ++ai) {
+            const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + lkc) * 3;
+            kx[ai] = r3[0]; ky[ai] = r3[1]; kz[ai] = r3[2];
+        }
+    }
+
+    f32x16 acc[APW];
+#pragma unroll
+    for (int ai = 0; ai < APW; ++ai)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
+
+    const int piece = t & 15, rgrp = t >> 4;
+    const int npiece = na >> 2;                          // na % 4 == 0 (checked by the launcher)
+    const int pc = min(piece, npiece - 1);
+    const float *fb = gy + (size_t)bi * o * p * na;
+    constexpr int NST = NBK * CB * 16 / TM;
+    float4 stage[NST];
+    int stage_p[NST];
+    float4 gtmp = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int row = u * (TM / 16) + rgrp;       // row = nl * CB + cl
+            const int nl = row / CB, cl = row - nl * CB;
+            const int pe = j0 + nl < n_ent ? ent_p[e0 + j0 + nl] : -1;
+            stage_p[u] = pe;
+            const float *src = fb + ((size_t)min(c0 + cl, o - 1) * p + max(pe, 0)) * na + 4 * pc;
+            stage[u] = *reinterpret_cast<const float4 *>(src);
+        }
+        if (t < NBK) gtmp = j0 + t < n_ent ? ent_gx[e0 + j0 + t] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int row = u * (TM / 16) + rgrp;
+            const int cl = row % CB;
+            const bool live = stage_p[u] >= 0 && c0 + cl < o && piece < npiece;
+            *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
+                live ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (t < NBK) s_g[buf * NBK + t] = gtmp;
+    };
+
+    const int nchunk = (n_ent + NBK - 1) / NBK;
+    if (nchunk > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+
+    auto gather = [&](const float *fbuf, int buf, int s, float (&fa)[APW], int (&aw)[APW]) {
+        const int nl = 2 * s + lh;
+        const float *frow = fbuf + ((size_t)nl * CB + lk) * FP;
+        const int r = __float_as_int(s_g[buf * NBK + nl].w);
+#pragma unroll
+        for (int ai = 0; ai < APW; ++ai) {
+            const int a = min(a_beg + ai, na - 1);
+            aw[ai] = HAS_MULT ? (int)s_mult[r * na + a] : a;
+            fa[ai] = frow[aw[ai]];
+        }
+    };
+    auto step = [&](int buf, int s, const float (&fa)[APW], const int (&aw)[APW]) {
+        const float4 g = s_g[buf * NBK + 2 * s + lh];
+#pragma unroll
+        for (int ai = 0; ai < APW; ++ai) {
+            float rx, ry, rz;
+            if (HAS_MULT) {
+                const float *r3 = s_rk + (aw[ai] * ks + lkc) * 3;
+                rx = r3[0]; ry = r3[1]; rz = r3[2];
+            } else {
+                rx = kx[ai]; ry = ky[ai]; rz = kz[ai];
+            }
+            const float dx = g.x - rx, dy = g.y - ry, dz = g.z - rz;
+            const float wv = kmask * fmaxf(1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma, 0.0f);
+            if (ai < a_cnt)                              // wave-uniform
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv, acc[ai], 0, 0, 0);
+        }
+    };
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) fetch((ch + 1) * NBK);
+        const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
+        float fa0[APW], fa1[APW];
+        int aw0[APW], aw1[APW];
+        gather(fbuf, buf, 0, fa0, aw0);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(fbuf, buf, 1, fa1, aw1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(buf, 0, fa0, aw0);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(fbuf, buf, 2, fa0, aw0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(buf, 1, fa1, aw1);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(fbuf, buf, 3, fa1, aw1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(buf, 2, fa0, aw0);
+        __builtin_amdgcn_sched_barrier(0);
+        step(buf, 3, fa1, aw1);
+        if (ch + 1 < nchunk) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: Z[b, o, k, ri, a'] (rows that are not referenced write zeros) ----------------
+    float *s_o = s_f;
+    float *ob = out + (size_t)bi * o * ks * rcap * na + (size_t)ri * na;
+    const size_t o_ks = (size_t)rcap * na, o_cs = (size_t)ks * rcap * na;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        if (lk < ks) {
+#pragma unroll
+            for (int ai = 0; ai < APW; ++ai) {
+                if (ai < a_cnt) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int cl8 = rr + 4 * lh;
+                        s_o[((size_t)cl8 * ks + lk) * na + a_beg + ai] = acc[ai][ps * 4 + rr];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int nrows = 8 * ks;
+            int cl8 = rgrp / ks, k = rgrp - cl8 * ks;
+            for (int row = rgrp; row < nrows; row += TM / 16) {
+                const int ci = c0 + ps * 8 + cl8;
+                if (ci < o && piece < npiece)
+                    *reinterpret_cast<float4 *>(ob + (size_t)ci * o_cs + (size_t)k * o_ks + 4 * pc) =
+                        *reinterpret_cast<const float4 *>(s_o + (size_t)row * na + 4 * pc);
+                k += TM / 16;
+                while (k >= ks) { k -= ks; ++cl8; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int rcap,
+                                           float sigma, const float *gy, const int32_t *rows,
+                                           const int32_t *off, const int32_t *cnt,
+                                           const int32_t *ent_p, const float *ent_gx, const float *rk,
+                                           const uint8_t *multinv, float *z, eap_stream_t stream) {
+    if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
+    if (na > 64 || (na & 3) != 0) return eap::bad_arg("so3_inter_group_inv: the anchor count must be a multiple of 4, at most 64");
+    if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
+    hipStream_t s = eap::S(stream);
+    const size_t stage_b = sizeof(float) * 2 * NBK * CB * FP;
+    if (sizeof(float) * 8 * (size_t)ks * na > stage_b) return eap::bad_arg("so3_inter_group_inv: epilogue tile too large");
+    size_t shmem = stage_b + 16 * 2 * NBK + (multinv ? sizeof(float) * (size_t)na * ks * 3 + (size_t)na * na : 0);
+    if (shmem > 160 * 1024) return eap::bad_arg("so3_inter_group_inv: LDS budget exceeded");
+    dim3 grid(rcap, (o + CB - 1) / CB, b);
+    const float4 *g4 = reinterpret_cast<const float4 *>(ent_gx);
+    int e;
+    if (multinv) {
+        auto kern = so3_inter_group_inv_kernel<true>;
+        e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
+        if (e) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
+    } else {
+        auto kern = so3_inter_group_inv_kernel<false>;
+        e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
+        if (e) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
+    }
+    return eap::check_launch("so3_inter_group_inv");
+}

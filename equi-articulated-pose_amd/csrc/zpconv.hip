@@ -34,55 +34,60 @@ __global__ __launch_bounds__(ZP_THREADS) void inter_zpconv_kernel(
     T *s_w = reinterpret_cast<T *>(smem);
     int32_t *s_idx = reinterpret_cast<int32_t *>(smem + sizeof(T) * (size_t)na * pitch);
 
-    const int p = blockIdx.x, k0 = blockIdx.y * KC, bn = blockIdx.z;
-    const int kcnt = min(KC, ks - k0);
-    const int run = kcnt * ann;  // contiguous elements per anchor row in global memory
-    const size_t row0 = ((size_t)bn * np + p) * na;
-    for (int i = threadIdx.x; i < na * run; i += ZP_THREADS) {
-        const int a = i / run, e = i - a * run;
-        const size_t g = ((row0 + a) * ks + k0) * ann + e;
-        s_idx[a * pitch + e] = idx[g];
-        s_w[a * pitch + e] = w[g];
-    }
-    __syncthreads();
-
+    // one block per point walks over all kernel-point pairs: the feature rows it gathers again
+    // for the next pair are then served by this XCD's L2 instead of being re-fetched by a block
+    // on another XCD
+    const int p = xcd_point(blockIdx.x, np), bn = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kk = wave & (KC - 1), chalf = wave >> 1;
-    const int k = k0 + kk;
-    if (kk >= kcnt || lane >= na) return;
-    const int32_t *my_idx = s_idx + lane * pitch + kk * ann;
-    const T *my_w = s_w + lane * pitch + kk * ann;
+    const size_t row0 = ((size_t)bn * np + p) * na;
     // feats / gfeats: [b,c,nq,na]; out / gout: [b,c,ks,np,na]
     const size_t f_b = (size_t)bn * c * nq * na;
-    const size_t o_b = (size_t)bn * c * ks * np * na + ((size_t)k * np + p) * na + lane;
     const size_t f_cs = (size_t)nq * na, o_cs = (size_t)ks * np * na;
 
-    for (int c0 = chalf * CC; c0 < c; c0 += 2 * CC) {
-        if (!BWD) {
-            T acc[CC];
+    for (int k0 = 0; k0 < ks; k0 += KC) {
+        const int kcnt = min(KC, ks - k0);
+        const int run = kcnt * ann;  // contiguous elements per anchor row in global memory
+        __syncthreads();
+        for (int i = threadIdx.x; i < na * run; i += ZP_THREADS) {
+            const int a = i / run, e = i - a * run;
+            const size_t g = ((row0 + a) * ks + k0) * ann + e;
+            s_idx[a * pitch + e] = idx[g];
+            s_w[a * pitch + e] = w[g];
+        }
+        __syncthreads();
+        const int k = k0 + kk;
+        if (kk >= kcnt || lane >= na) continue;
+        const int32_t *my_idx = s_idx + lane * pitch + kk * ann;
+        const T *my_w = s_w + lane * pitch + kk * ann;
+        const size_t o_b = (size_t)bn * c * ks * np * na + ((size_t)k * np + p) * na + lane;
+
+        for (int c0 = chalf * CC; c0 < c; c0 += 2 * CC) {
+            if (!BWD) {
+                T acc[CC];
 #pragma unroll
-            for (int cc = 0; cc < CC; ++cc) acc[cc] = 0;
-            for (int n = 0; n < ann; ++n) {
-                const T wv = my_w[n];
-                const T *f = src + f_b + (size_t)my_idx[n] * na + lane;
+                for (int cc = 0; cc < CC; ++cc) acc[cc] = 0;
+                for (int n = 0; n < ann; ++n) {
+                    const T wv = my_w[n];
+                    const T *f = src + f_b + (size_t)my_idx[n] * na + lane;
+#pragma unroll
+                    for (int cc = 0; cc < CC; ++cc) acc[cc] += f[(size_t)min(c0 + cc, c - 1) * f_cs] * wv;
+                }
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc)
-                    if (c0 + cc < c) acc[cc] += f[(size_t)(c0 + cc) * f_cs] * wv;
-            }
-#pragma unroll
-            for (int cc = 0; cc < CC; ++cc)
-                if (c0 + cc < c) dst[o_b + (size_t)(c0 + cc) * o_cs] = acc[cc];
-        } else {
-            T g[CC];
-#pragma unroll
-            for (int cc = 0; cc < CC; ++cc)
-                g[cc] = (c0 + cc < c) ? src[o_b + (size_t)(c0 + cc) * o_cs] : (T)0;
-            for (int n = 0; n < ann; ++n) {
-                const T wv = my_w[n];
-                T *f = dst + f_b + (size_t)my_idx[n] * na + lane;
+                    if (c0 + cc < c) dst[o_b + (size_t)(c0 + cc) * o_cs] = acc[cc];
+            } else {
+                T g[CC];
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc)
-                    if (c0 + cc < c) atomicAdd(f + (size_t)(c0 + cc) * f_cs, g[cc] * wv);
+                    g[cc] = (c0 + cc < c) ? src[o_b + (size_t)(c0 + cc) * o_cs] : (T)0;
+                for (int n = 0; n < ann; ++n) {
+                    const T wv = my_w[n];
+                    T *f = dst + f_b + (size_t)my_idx[n] * na + lane;
+#pragma unroll
+                    for (int cc = 0; cc < CC; ++cc)
+                        if (c0 + cc < c) atomicAdd(f + (size_t)(c0 + cc) * f_cs, g[cc] * wv);
+                }
             }
         }
     }
@@ -110,7 +115,7 @@ int launch_inter(int b, int np, int nq, int na, int ks, int ann, int c, const in
     int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
                           "inter_zpconv shared memory");
     if (e) return e;
-    dim3 grid(np, eap::cdiv(ks, KC), b);
+    dim3 grid(np, 1, b);
     hipLaunchKernelGGL(kern, grid, dim3(ZP_THREADS), shmem, s, np, nq, na, ks, ann, c, idx, w, src, dst);
     return eap::check_launch(BWD ? "inter_zpconv_backward" : "inter_zpconv_forward");
 }

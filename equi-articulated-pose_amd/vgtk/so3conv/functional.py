@@ -219,6 +219,96 @@ class _Contract(torch.autograd.Function):
         return gW, gx
 
 
+# Feature-gradient strategy of the fused inter convolution: "auto" picks the re-associated
+# (inverse-list) path when at most 1/INV_ROW_FRACTION of the support points are referenced by
+# any neighbour list, else dX = W^T dY followed by the transposed grouping.
+BACKWARD_MODE = 'auto'      # 'auto' | 'inverse' | 'dx'
+INV_ROW_FRACTION = 4
+
+
+def _inverse_lists(idx, gx, n_sup):
+    """Inverse neighbour lists of idx [b,p,nn] (which (point, slot) pairs reference each support
+    row), with the referenced rows compacted.  Small torch plumbing on the device; ONE host sync
+    (the number of referenced rows sizes the workspace)."""
+    b, p, nn = idx.shape
+    keys = idx.reshape(b, p * nn).long()
+    skeys, order = torch.sort(keys, dim=1, stable=True)          # entries of a row stay in (p,n) order
+    counts = torch.zeros(b, n_sup + 1, dtype=torch.int64, device=idx.device)
+    counts.scatter_add_(1, keys.clamp(max=n_sup), torch.ones_like(keys))
+    counts = counts[:, :n_sup]
+    offs = torch.cumsum(counts, 1) - counts
+    nonempty = counts > 0
+    n_rows = nonempty.sum(1)
+    rcap = int(n_rows.max().item())
+    rows = torch.argsort((~nonempty).to(torch.int8), dim=1, stable=True)[:, :rcap]
+    valid = torch.arange(rcap, device=idx.device)[None, :] < n_rows[:, None]
+    off_c = torch.gather(offs, 1, rows)
+    cnt_c = torch.gather(counts, 1, rows) * valid
+    rows_c = torch.where(valid, rows, torch.full_like(rows, -1))
+    ent_p = torch.div(order, nn, rounding_mode='floor').to(torch.int32).contiguous()
+    ent_gx = torch.gather(gx.reshape(b, p * nn, 4), 1, order[..., None].expand(-1, -1, 4)).contiguous()
+    return (rows_c.to(torch.int32).contiguous(), off_c.to(torch.int32).contiguous(),
+            cnt_c.to(torch.int32).contiguous(), ent_p, ent_gx, rcap)
+
+
+class _InterConv(torch.autograd.Function):
+    """Fused inter conv  y = W . group(feats)  (functional.py:L1221-1261 + modules.py:L48-55)
+    with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
+
+    @staticmethod
+    def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident):
+        feats = feats.contiguous()
+        W = W.contiguous()
+        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma)      # [b,c,k,p,a]
+        b, c, ks, p, na = x.shape
+        o = W.shape[0]
+        y = torch.empty(b, o, p, na, dtype=torch.float32, device=x.device)
+        _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b)
+        ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0))
+        ctx.has_mult = mult is not None
+        ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, x, idx, gx, rk, mult = ctx.saved_tensors
+        mult = mult if ctx.has_mult else None
+        gy = gy.contiguous()
+        b, c, ks, p, na = x.shape
+        o, ck, pa = W.shape[0], c * ks, p * na
+        gW = gF = None
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty_like(W)          # sum_b gy_b x_b^T
+            _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)
+        if ctx.needs_input_grad[0]:
+            n = ctx.n
+            inv = None
+            if BACKWARD_MODE != 'dx' and na % 4 == 0 and ks <= 32:
+                inv = _inverse_lists(idx, gx, n)
+                if BACKWARD_MODE == 'auto' and inv[5] * INV_ROW_FRACTION > n:
+                    inv = None
+            if inv is not None:
+                rows, off, cnt, ent_p, ent_gx, rcap = inv
+                multinv = None
+                if mult is not None:           # multinv[r][a'] = a  with  mult[r][a] = a'
+                    multinv = torch.empty_like(mult)
+                    multinv.scatter_(1, mult.long(), torch.arange(na, device=mult.device, dtype=torch.uint8).repeat(na, 1))
+                z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2])
+                W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
+                gFc = torch.empty(b, c, rcap * na, dtype=torch.float32, device=gy.device)
+                _hip.gemm(0, 0, c, rcap * na, o * ks, W2, o * ks, 0, z, rcap * na, o * ks * rcap * na,
+                          gFc, rcap * na, c * rcap * na, b)
+                gF = torch.zeros(b, c, n + 1, na, dtype=torch.float32, device=gy.device)
+                dest = torch.where(rows >= 0, rows, torch.full_like(rows, n)).long()
+                gF.scatter_(2, dest[:, None, :, None].expand(b, c, rcap, na), gFc.view(b, c, rcap, na))
+                gF = gF[:, :, :n].contiguous()
+            else:
+                gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
+                _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
+                gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
+        return gF, gW, None, None, None, None, None, None
+
+
 def so3_contract(W, x):
     """W [O, C*K], x [b, C*K, P*A] -> [b, O, P*A]."""
     _hip.check_input(x)
@@ -262,6 +352,32 @@ def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, 
     new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), new_feats
+
+
+def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute):
+    """ball query + prep + fused (grouping . contraction) -> (ball_idx, InterWeights, y [b,o,p,a]).
+    What InterSO3PoseConv / InterSO3Conv.forward run for stride 1."""
+    if feats.dtype != torch.float32 or xyz.dtype != torch.float32 or W.dtype != torch.float32:
+        raise RuntimeError('so3conv: float32 only')
+    _hip.check_input(xyz)
+    if not feats.is_cuda or not W.is_cuda:
+        raise RuntimeError('so3conv: feats and W must be device tensors')
+    ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
+    rk = rotated_kernels(anchors, kernels)
+    mult = ident = rot = None
+    if pose is not None:
+        rot = pose.contiguous()
+        if rot.shape[-2:] != (4, 4) or rot.dtype != torch.float32:
+            raise RuntimeError('so3conv: pose must be float32 [b,p,4,4]')
+        if permute:
+            mult, ident = _group_tables(anchors)
+            if mult is None:
+                raise NotImplementedError(
+                    'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
+    gx = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident)
+    inter_w = InterWeights(gx, rk, sigma)
+    return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 
 
 def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, radius, sigma,

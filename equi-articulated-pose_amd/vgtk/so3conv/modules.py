@@ -56,6 +56,14 @@ class InterSO3Conv(nn.Module):
         self.register_buffer('kernels', torch.from_numpy(kernels))
 
     def forward(self, x, inter_idx=None, inter_w=None):
+        if inter_idx is None and self.stride == 1:
+            # fused path: grouping + contraction in one autograd node (re-associated backward)
+            xyz = x.xyz
+            inter_idx, inter_w, feats = L.inter_so3conv_fused(xyz, None, x.feats, self.basic_conv.W,
+                                                              self.n_neighbor, self.anchors, self.kernels,
+                                                              self.radius, self.sigma, False)
+            sample_idx = torch.arange(xyz.shape[2], dtype=torch.long, device=xyz.device).unsqueeze(0).repeat(xyz.shape[0], 1)
+            return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, feats, self.anchors)
         inter_idx, inter_w, xyz, feats, sample_idx = \
             L.inter_so3conv_grouping(x.xyz, x.feats, self.stride, self.n_neighbor, self.anchors,
                                      self.kernels, self.radius, self.sigma, inter_idx, inter_w,
@@ -93,13 +101,15 @@ class InterSO3PoseConv(nn.Module):
         self.register_buffer('kernels', torch.from_numpy(kernels))
 
     def forward(self, x, inter_idx=None, inter_w=None, seg=None):
-        inter_idx, inter_w, xyz, feats, sample_idx, sampled_pose = \
-            L.inter_so3poseconv_grouping_strided(x.xyz, x.pose, x.feats, self.stride, self.n_neighbor,
-                                                 self.anchors, self.kernels, self.radius, self.sigma,
-                                                 inter_idx, inter_w, self.lazy_sample,
-                                                 pooling=self.pooling, permute_modes=self.permute_modes)
-        feats = self.basic_conv(feats)
-        return inter_idx, inter_w, sample_idx, SphericalPointCloudPose(xyz, feats, self.anchors, sampled_pose)
+        if self.stride != 1:
+            L._check_stride(self.stride, self.pooling, x.feats)
+        # stride-1 branch of the reference (functional.py:L1025-1286): the neighbourhood is recomputed
+        # on every call and the passed-in inter_idx is handed back unchanged; grouping + contraction
+        # run as one autograd node (csrc/so3_inter_*.hip + gemm_f32.hip)
+        _, w, feats = L.inter_so3conv_fused(x.xyz, x.pose, x.feats, self.basic_conv.W, self.n_neighbor,
+                                            self.anchors, self.kernels, self.radius, self.sigma,
+                                            self.permute_modes != 0)
+        return inter_idx, w, None, SphericalPointCloudPose(x.xyz, feats, self.anchors, x.pose)
 
 
 class IntraSO3Conv(nn.Module):

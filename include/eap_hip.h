@@ -166,6 +166,22 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
                                      const float *rk, const uint8_t *mult, int identity_anchor,
                                      float *gfeats, float *workspace, eap_stream_t stream);
 
+/* so3_inter_group_inv: the feature gradient of the whole inter convolution by re-association,
+ *   dF[c,q,a'] = sum_{o,k} W[o,(c,k)] Z[o,k,q,a'],
+ *   Z[o,k,q,a'] = sum_{(p,n): idx[p,n]=q} dY[o,p,a] w(p,a,k,n),  a = perm_n^-1(a')
+ * i.e. the forward grouping applied to dY over INVERSE neighbour lists (autograd of
+ * so3conv/functional.py:L1221-1261 + modules.py:L48-55 without ever forming dX = W^T dY).
+ * gy [b,o,p,na]; the referenced support rows of each batch item are compacted to `rcap` slots:
+ * rows [b,rcap] (support index or -1), off/cnt [b,rcap] (range of the row's entries in the
+ * per-item sorted entry list), ent_p [b,p*nn] (query point of each entry), ent_gx float4
+ * [b,p*nn] (its so3_prep word), rk [na,ks,3], multinv [na,na] (multinv[r][a'] = a, NULL = no
+ * permutation)  ->  z [b,o,ks,rcap,na].  The caller finishes with eap_gemm_f32. */
+int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma,
+                                const float *gy, const int32_t *rows, const int32_t *off,
+                                const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
+                                const float *rk, const uint8_t *multinv, float *z,
+                                eap_stream_t stream);
+
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 
 /* so3_intra_group_fwd: intra_so3conv_grouping, so3conv/functional.py:L2553-2602.

@@ -208,8 +208,13 @@ def _run_layer(vg, dev, g):
     return conv, feats, conv(x)
 
 
+@pytest.mark.parametrize('mode', ['dx', 'inverse'])
 @pytest.mark.parametrize('name', INTER_CASES)
-def test_inter_pose_layer_golden(dev, vg, golden, name):
+def test_inter_pose_layer_golden(dev, vg, golden, name, mode, monkeypatch):
+    """Forward + both feature-gradient strategies (dX + transposed grouping / re-associated
+    inverse-list grouping of dY) against the reference's autograd."""
+    _, _, _, L = vg
+    monkeypatch.setattr(L, 'BACKWARD_MODE', mode)
     g = golden(name + '.npz')
     conv, feats, (inter_idx, inter_w, sample_idx, y) = _run_layer(vg, dev, g)
     assert inter_idx is None and sample_idx is None            # reference stride-1 return values
@@ -419,6 +424,30 @@ def test_full_size_group_mfma_equals_valu_and_is_linear(dev, vg):
     x2 = _hip.so3_inter_group_fwd(f2, idx, gx, rk, mult, sigma)
     x12 = _hip.so3_inter_group_fwd(2.0 * f1 - 0.5 * f2, idx, gx, rk, mult, sigma)
     assert (x12 - (2.0 * x1 - 0.5 * x2)).abs().max().item() < 2e-5 * scale
+
+
+def test_full_size_layer_gradients_agree_between_strategies(dev, vg, monkeypatch):
+    """4096 points, L2-layer radius (the hot-row regime): dF from the inverse-list path equals dF
+    from dX + transposed grouping, and dW is identical."""
+    import synth_clouds
+    _, sptk, zptk, L = vg
+    P = 4096
+    _, _, r, s = synth_clouds.backbone_layers(P)[2]
+    xyz, _, pose = synth_clouds.laptop_batch(40, 2, P)
+    torch.manual_seed(4)
+    conv = sptk.InterSO3PoseConv(32, 64, 1, 1, r, s, 64, kanchor=60, permute_modes=1).to(dev)
+    f0 = torch.randn(2, 32, P, 60, device=dev)
+    gy = torch.randn(2, 64, P, 60, device=dev)
+    grads = {}
+    for mode in ('dx', 'inverse', 'auto'):
+        monkeypatch.setattr(L, 'BACKWARD_MODE', mode)
+        f = f0.clone().requires_grad_(True)
+        y = conv(zptk.SphericalPointCloudPose(T(xyz).to(dev), f, None, T(pose).to(dev)))[3].feats
+        grads[mode] = torch.autograd.grad(y, [f, conv.basic_conv.W], gy)
+    scale = grads['dx'][0].abs().max().item()
+    assert (grads['dx'][0] - grads['inverse'][0]).abs().max().item() < 2e-5 * scale
+    assert torch.equal(grads['inverse'][0], grads['auto'][0])        # auto picks the inverse path here
+    assert torch.equal(grads['dx'][1], grads['inverse'][1])
 
 
 def test_full_size_backward_is_the_adjoint(dev, vg):
