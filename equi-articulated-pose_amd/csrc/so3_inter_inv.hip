@@ -27,22 +27,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CB = 32;        // dY channels per block (one MFMA M tile)
 constexpr int NBK = 8;        // entries per LDS stage (4 MFMA k-steps)
-constexpr int FP = 68;        // LDS pitch of one staged row (floats)
+constexpr int FPMAX = 68;     // LDS pitch of one staged row: 60 floats for <= 60 anchors, 68 for 61..64 (16-byte
+                              // aligned, never a multiple of 32 banks)
 constexpr int APW = 8;        // max anchors per wave
 constexpr int NWV = 8;
 constexpr int TM = 64 * NWV;
 
 template <bool HAS_MULT>
 __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
-    int o, int p, int nn, int na, int ks, int rcap, float inv_sigma, const float *__restrict__ gy,
+    int o, int p, int nn, int na, int ks, int rcap, float inv_sigma, int identity_anchor,
+    const float *__restrict__ gy,
     const int32_t *__restrict__ rows, const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx, const float *__restrict__ rk,
     const uint8_t *__restrict__ multinv, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int FP = na <= 60 ? 60 : FPMAX, FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
-    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP);       // [2][NBK]
-    float *s_rk = reinterpret_cast<float *>(s_g + 2 * NBK);                  // [na][ks][3] (HAS_MULT)
-    uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_rk + (HAS_MULT ? na * ks * 3 : 0));
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP_);       // [2][NBK]
+    float4 *s_rk = s_g + 2 * NBK;                                           // [na][ks] scaled kernel points (HAS_MULT)
+    uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_rk + (HAS_MULT ? na * ks : 0));
 
     const int ri = blockIdx.x, c0 = blockIdx.y * CB, bi = blockIdx.z;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -54,7 +57,11 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         const int words = (na * na) >> 2;
         for (int i = t; i < words; i += TM)
             reinterpret_cast<uint32_t *>(s_mult)[i] = reinterpret_cast<const uint32_t *>(multinv)[i];
-        for (int i = t; i < na * ks * 3; i += TM) s_rk[i] = rk[i];
+        for (int i = t; i < na * ks; i += TM) {       // w = max(0, base_e + kc + g . k')  (see step())
+            const float x = rk[i * 3], y = rk[i * 3 + 1], z = rk[i * 3 + 2];
+            s_rk[i] = make_float4(2.f * inv_sigma * x, 2.f * inv_sigma * y, 2.f * inv_sigma * z,
+                                  -inv_sigma * (x * x + y * y + z * z));
+        }
     }
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -65,15 +72,20 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     const int a_cnt = wave_u >= 4 ? q_cnt - first : first;
     const int lk = lane & 31, lh = lane >> 5;
     const int lkc = min(lk, ks - 1);
-    const float kmask = lk < ks ? 1.f : 0.f;             // unused kernel-point columns: weight 0
-    float kx[APW], ky[APW], kz[APW];
-    if (!HAS_MULT) {
+    // kernel weight  w = relu(1 - |g - k|^2 / sigma) = relu(base_e + kc + g . k'),
+    //   base_e = 1 - |g|^2/sigma (once per entry),  k' = 2k/sigma,  kc = -|k|^2/sigma (constants):
+    // 3 FMAs + add + max per weight instead of 9 operations; unused kernel-point columns carry
+    // kc = -1e30 so their weight is 0
+    float kx[APW], ky[APW], kz[APW], kc[APW];
+    if (!HAS_MULT)
 #pragma unroll
-        for (int ai = 0; ai < APW; ++ai) {
-            const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + lkc) * 3;
-            kx[ai] = r3[0]; ky[ai] = r3[1]; kz[ai] = r3[2];
-        }
+    for (int ai = 0; ai < APW; ++ai) {   // register constants (no permutation: anchors map to themselves)
+        const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + lkc) * 3;
+        const float x = r3[0], y = r3[1], z = r3[2];
+        kx[ai] = 2.f * inv_sigma * x; ky[ai] = 2.f * inv_sigma * y; kz[ai] = 2.f * inv_sigma * z;
+        kc[ai] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
     }
+    const float kdead = lk < ks ? 0.f : -1e30f;          // permuted path: added to the LDS constant
 
     f32x16 acc[APW];
 #pragma unroll
@@ -87,19 +99,30 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     const float *fb = gy + (size_t)bi * o * p * na;
     constexpr int NST = NBK * CB * 16 / TM;
     float4 stage[NST];
-    int stage_p[NST];
+    int stage_p[NST], next_p[NST];
     float4 gtmp = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    // entry -> query point indices are requested ONE CHUNK AHEAD of the feature rows that depend
+    // on them, so a stage never waits for two dependent memory round trips
+    auto fetch_index = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int nl = (u * (TM / 16) + rgrp) / CB;
+            next_p[u] = ent_p[e0 + min(j0 + nl, max(n_ent - 1, 0))];
+            if (j0 + nl >= n_ent) next_p[u] = -1;
+        }
+    };
     auto fetch = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int row = u * (TM / 16) + rgrp;       // row = nl * CB + cl
-            const int nl = row / CB, cl = row - nl * CB;
-            const int pe = j0 + nl < n_ent ? ent_p[e0 + j0 + nl] : -1;
+            const int cl = row % CB;
+            const int pe = next_p[u];
             stage_p[u] = pe;
             const float *src = fb + ((size_t)min(c0 + cl, o - 1) * p + max(pe, 0)) * na + 4 * pc;
             stage[u] = *reinterpret_cast<const float4 *>(src);
         }
-        if (t < NBK) gtmp = j0 + t < n_ent ? ent_gx[e0 + j0 + t] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
+        if (t < NBK) gtmp = ent_gx[e0 + min(j0 + t, max(n_ent - 1, 0))];
+        if (t < NBK && j0 + t >= n_ent) gtmp = make_float4(1e18f, 1e18f, 1e18f, 0.f);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -107,51 +130,80 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             const int row = u * (TM / 16) + rgrp;
             const int cl = row % CB;
             const bool live = stage_p[u] >= 0 && c0 + cl < o && piece < npiece;
-            *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
-                live ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (piece < npiece)   // the row pitch has no slack for the idle 16th lane
+                *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
+                    live ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (t < NBK) s_g[buf * NBK + t] = gtmp;
     };
 
     const int nchunk = (n_ent + NBK - 1) / NBK;
     if (nchunk > 0) {
+        fetch_index(0);
         fetch(0);
+        fetch_index(NBK);
         stash(0);
     }
     __syncthreads();
 
+    // HAS_MULT = false (no permutation, or the caller found every relative rotation to be the
+    // identity): anchors map to themselves and the weight constants are per-lane registers.
+    // HAS_MULT = true: the permuted anchor of every (entry, anchor) pair comes from the LDS
+    // table, and so do its weight constants (read 4 at a time, one wait per group).
     auto gather = [&](const float *fbuf, int buf, int s, float (&fa)[APW], int (&aw)[APW]) {
         const int nl = 2 * s + lh;
         const float *frow = fbuf + ((size_t)nl * CB + lk) * FP;
-        const int r = __float_as_int(s_g[buf * NBK + nl].w);
+        if (!HAS_MULT) {
 #pragma unroll
-        for (int ai = 0; ai < APW; ++ai) {
-            const int a = min(a_beg + ai, na - 1);
-            aw[ai] = HAS_MULT ? (int)s_mult[r * na + a] : a;
-            fa[ai] = frow[aw[ai]];
+            for (int ai = 0; ai < APW; ++ai) fa[ai] = frow[min(a_beg + ai, na - 1)];
+        } else {
+            const int r = __float_as_int(s_g[buf * NBK + nl].w);
+#pragma unroll
+            for (int ai = 0; ai < APW; ++ai) {
+                const int a = (int)s_mult[r * na + min(a_beg + ai, na - 1)];
+                aw[ai] = a * ks + lkc;
+                fa[ai] = frow[a];
+            }
         }
     };
     auto step = [&](int buf, int s, const float (&fa)[APW], const int (&aw)[APW]) {
         const float4 g = s_g[buf * NBK + 2 * s + lh];
+        const float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
+        if (!HAS_MULT) {
 #pragma unroll
-        for (int ai = 0; ai < APW; ++ai) {
-            float rx, ry, rz;
-            if (HAS_MULT) {
-                const float *r3 = s_rk + (aw[ai] * ks + lkc) * 3;
-                rx = r3[0]; ry = r3[1]; rz = r3[2];
-            } else {
-                rx = kx[ai]; ry = ky[ai]; rz = kz[ai];
+            for (int ai = 0; ai < APW; ++ai) {
+                float t = fmaf(g.x, kx[ai], kc[ai]);
+                t = fmaf(g.y, ky[ai], t);
+                t = fmaf(g.z, kz[ai], t);
+                const float wv = fmaxf(t + base, 0.0f);
+                if (ai < a_cnt)                          // wave-uniform
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv, acc[ai], 0, 0, 0);
             }
-            const float dx = g.x - rx, dy = g.y - ry, dz = g.z - rz;
-            const float wv = kmask * fmaxf(1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma, 0.0f);
-            if (ai < a_cnt)                              // wave-uniform
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv, acc[ai], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < APW; h += 4) {
+                float4 k4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k4[j] = s_rk[aw[h + j]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = fmaf(g.x, k4[j].x, k4[j].w + kdead);
+                    t = fmaf(g.y, k4[j].y, t);
+                    t = fmaf(g.z, k4[j].z, t);
+                    const float wv = fmaxf(t + base, 0.0f);
+                    if (h + j < a_cnt)
+                        acc[h + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h + j], wv, acc[h + j], 0, 0, 0);
+                }
+            }
         }
     };
 
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunk) fetch((ch + 1) * NBK);
+        if (ch + 1 < nchunk) {
+            fetch((ch + 1) * NBK);
+            fetch_index((ch + 2) * NBK);
+        }
         const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
         float fa0[APW], fa1[APW];
         int aw0[APW], aw1[APW];
@@ -215,14 +267,16 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
                                            float sigma, const float *gy, const int32_t *rows,
                                            const int32_t *off, const int32_t *cnt,
                                            const int32_t *ent_p, const float *ent_gx, const float *rk,
-                                           const uint8_t *multinv, float *z, eap_stream_t stream) {
+                                           const uint8_t *multinv, int identity_anchor, float *z,
+                                           eap_stream_t stream) {
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64 || (na & 3) != 0) return eap::bad_arg("so3_inter_group_inv: the anchor count must be a multiple of 4, at most 64");
     if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
     hipStream_t s = eap::S(stream);
-    const size_t stage_b = sizeof(float) * 2 * NBK * CB * FP;
+    const int FP_ = na <= 60 ? 60 : FPMAX;
+    const size_t stage_b = sizeof(float) * 2 * NBK * CB * FP_;
     if (sizeof(float) * 8 * (size_t)ks * na > stage_b) return eap::bad_arg("so3_inter_group_inv: epilogue tile too large");
-    size_t shmem = stage_b + 16 * 2 * NBK + (multinv ? sizeof(float) * (size_t)na * ks * 3 + (size_t)na * na : 0);
+    size_t shmem = stage_b + 16 * 2 * NBK + (multinv ? 16 * (size_t)na * ks + (size_t)na * na : 0);
     if (shmem > 160 * 1024) return eap::bad_arg("so3_inter_group_inv: LDS budget exceeded");
     dim3 grid(rcap, (o + CB - 1) / CB, b);
     const float4 *g4 = reinterpret_cast<const float4 *>(ent_gx);
@@ -231,12 +285,12 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
         auto kern = so3_inter_group_inv_kernel<true>;
         e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
         if (e) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
     } else {
         auto kern = so3_inter_group_inv_kernel<false>;
         e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
         if (e) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
     }
     return eap::check_launch("so3_inter_group_inv");
 }

@@ -28,7 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CB = 32;        // channels per block (one MFMA M tile)
 constexpr int NBK = 8;        // neighbours per LDS stage (4 MFMA k-steps; the pipeline below is written for 4)
-constexpr int FP = 68;        // LDS pitch of one staged feature row (floats, 16-byte aligned)
+constexpr int FPMAX = 68;     // LDS pitch of one staged row: 60 floats for <= 60 anchors, 68 for 61..64 (16-byte
+                              // aligned, never a multiple of 32 banks)
 constexpr int NWV = 8;        // waves per block: 2 per SIMD, so one wave's weight VALU overlaps the other's MFMAs
 constexpr int TM = 64 * NWV;
 
@@ -40,8 +41,9 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     const float *__restrict__ feats, const int32_t *__restrict__ idx, const float4 *__restrict__ gx,
     const float *__restrict__ rk, const uint8_t *__restrict__ mult, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int FP = na <= 60 ? 60 : FPMAX, FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
-    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP);       // [nn_pad]
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP_);       // [nn_pad]
     const int nn_pad = (nn + NBK - 1) / NBK * NBK;
     int32_t *s_q = reinterpret_cast<int32_t *>(s_g + nn_pad);               // [nn_pad]
     uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_q + nn_pad);            // [na*na]
@@ -133,8 +135,9 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
                 if (4 * pc + 3 >= na) v.w = 0.f;
             }
             const bool live = s_q[n0 + nl] >= 0 && c0 + cl < c && piece < npiece;
-            *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
-                live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (piece < npiece)   // the row pitch has no slack for the idle 16th lane
+                *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
+                    live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -245,12 +248,13 @@ extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int 
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 32 kernel points");
     hipStream_t s = eap::S(stream);
+    const int FP_ = na <= 60 ? 60 : FPMAX;
     if (nn <= 0)
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, s), "so3_inter_group_fwd memset");
     const int nn_pad = (nn + NBK - 1) / NBK * NBK;
-    size_t shmem = sizeof(float) * 2 * NBK * CB * FP + 20 * (size_t)nn_pad + (mult ? (size_t)na * na : 0);
+    size_t shmem = sizeof(float) * 2 * NBK * CB * FP_ + 20 * (size_t)nn_pad + (mult ? (size_t)na * na : 0);
     const size_t epi = sizeof(float) * 8 * (size_t)ks * na;
-    if (epi > sizeof(float) * 2 * NBK * CB * FP) return eap::bad_arg("so3_inter_group_fwd_mfma: epilogue tile too large");
+    if (epi > sizeof(float) * 2 * NBK * CB * FP_) return eap::bad_arg("so3_inter_group_fwd_mfma: epilogue tile too large");
     dim3 grid(p, (c + CB - 1) / CB, b);
     const float4 *g4 = reinterpret_cast<const float4 *>(gx);
     const float inv_sigma = 1.0f / sigma;

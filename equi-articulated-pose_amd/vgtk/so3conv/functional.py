@@ -226,7 +226,7 @@ BACKWARD_MODE = 'auto'      # 'auto' | 'inverse' | 'dx'
 INV_ROW_FRACTION = 4
 
 
-def _inverse_lists(idx, gx, n_sup):
+def _inverse_lists(idx, gx, n_sup, ident):
     """Inverse neighbour lists of idx [b,p,nn] (which (point, slot) pairs reference each support
     row), with the referenced rows compacted.  Small torch plumbing on the device; ONE host sync
     (the number of referenced rows sizes the workspace)."""
@@ -239,7 +239,11 @@ def _inverse_lists(idx, gx, n_sup):
     offs = torch.cumsum(counts, 1) - counts
     nonempty = counts > 0
     n_rows = nonempty.sum(1)
-    rcap = int(n_rows.max().item())
+    # one host sync for both facts the launch needs: workspace rows, and whether any relative
+    # rotation differs from the identity (if none does, the permutation table is skipped)
+    all_ident = (gx[..., 3].contiguous().view(torch.int32) == ident).all()
+    rcap, all_ident = torch.stack([n_rows.max(), all_ident.to(n_rows.dtype)]).tolist()
+    rcap, all_ident = int(rcap), bool(all_ident)
     rows = torch.argsort((~nonempty).to(torch.int8), dim=1, stable=True)[:, :rcap]
     valid = torch.arange(rcap, device=idx.device)[None, :] < n_rows[:, None]
     off_c = torch.gather(offs, 1, rows)
@@ -248,7 +252,7 @@ def _inverse_lists(idx, gx, n_sup):
     ent_p = torch.div(order, nn, rounding_mode='floor').to(torch.int32).contiguous()
     ent_gx = torch.gather(gx.reshape(b, p * nn, 4), 1, order[..., None].expand(-1, -1, 4)).contiguous()
     return (rows_c.to(torch.int32).contiguous(), off_c.to(torch.int32).contiguous(),
-            cnt_c.to(torch.int32).contiguous(), ent_p, ent_gx, rcap)
+            cnt_c.to(torch.int32).contiguous(), ent_p, ent_gx, rcap, all_ident)
 
 
 class _InterConv(torch.autograd.Function):
@@ -284,16 +288,17 @@ class _InterConv(torch.autograd.Function):
             n = ctx.n
             inv = None
             if BACKWARD_MODE != 'dx' and na % 4 == 0 and ks <= 32:
-                inv = _inverse_lists(idx, gx, n)
+                inv = _inverse_lists(idx, gx, n, ctx.ident)
                 if BACKWARD_MODE == 'auto' and inv[5] * INV_ROW_FRACTION > n:
                     inv = None
             if inv is not None:
-                rows, off, cnt, ent_p, ent_gx, rcap = inv
+                rows, off, cnt, ent_p, ent_gx, rcap, all_ident = inv
                 multinv = None
-                if mult is not None:           # multinv[r][a'] = a  with  mult[r][a] = a'
+                if mult is not None and not all_ident:   # multinv[r][a'] = a  with  mult[r][a] = a'
                     multinv = torch.empty_like(mult)
                     multinv.scatter_(1, mult.long(), torch.arange(na, device=mult.device, dtype=torch.uint8).repeat(na, 1))
-                z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2])
+                z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
+                                             ctx.ident)
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, rcap * na, dtype=torch.float32, device=gy.device)
                 _hip.gemm(0, 0, c, rcap * na, o * ks, W2, o * ks, 0, z, rcap * na, o * ks * rcap * na,

@@ -179,8 +179,8 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
 int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma,
                                 const float *gy, const int32_t *rows, const int32_t *off,
                                 const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
-                                const float *rk, const uint8_t *multinv, float *z,
-                                eap_stream_t stream);
+                                const float *rk, const uint8_t *multinv, int identity_anchor,
+                                float *z, eap_stream_t stream);
 
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 
