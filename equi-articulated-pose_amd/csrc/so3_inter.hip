@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void so3_prep_kernel(
     int p, int n_sup, int nn, int na, const float *__restrict__ q_xyz,
     const float *__restrict__ s_xyz, const int32_t *__restrict__ idx,
     const float *__restrict__ q_pose, const float *__restrict__ s_pose,
-    const float *__restrict__ anchors, int identity_anchor, float4 *__restrict__ gx) {
+    const float *__restrict__ anchors, int identity_anchor, float4 *__restrict__ gx,
+    int32_t *__restrict__ nonident) {
     __shared__ float s_anchor[64 * 9];
     for (int i = threadIdx.x; i < na * 9; i += blockDim.x) s_anchor[i] = anchors[i];
     __syncthreads();
@@ -72,6 +73,10 @@ __global__ __launch_bounds__(256) void so3_prep_kernel(
         }
     }
     gx[(size_t)bi * p * nn + e] = make_float4(dx, dy, dz, __int_as_float(r));
+    // per-cloud flag for the grouping kernels: with identity rotations everywhere the anchor
+    // permutation is the identity and its table lookups are skipped
+    if (nonident != nullptr && __any(r != identity_anchor) && (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)
+        atomicOr(nonident + bi, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -267,13 +272,17 @@ __global__ __launch_bounds__(G_THREADS) void so3_inter_group_bwd_kernel(
 extern "C" int eap_so3_prep_f32(int b, int p, int n, int nn, int na, const float *q_xyz,
                                 const float *s_xyz, const int32_t *idx, const float *q_pose,
                                 const float *s_pose, const float *anchors, int identity_anchor,
-                                float *gx, eap_stream_t stream) {
+                                float *gx, int32_t *nonident, eap_stream_t stream) {
     if (b <= 0 || p <= 0 || nn <= 0) return 0;
     if (na > 64 || na <= 0) return eap::bad_arg("so3_prep: 1..64 anchors supported");
     if ((q_pose == nullptr) != (s_pose == nullptr)) return eap::bad_arg("so3_prep: pass both poses or none");
+    if (nonident != nullptr) {
+        int e = eap::hip_fail(hipMemsetAsync(nonident, 0, sizeof(int32_t) * b, eap::S(stream)), "so3_prep memset");
+        if (e) return e;
+    }
     dim3 grid(eap::cdiv((long long)p * nn, 256), b);
     hipLaunchKernelGGL(so3_prep_kernel, grid, dim3(256), 0, eap::S(stream), p, n, nn, na, q_xyz, s_xyz,
-                       idx, q_pose, s_pose, anchors, identity_anchor, reinterpret_cast<float4 *>(gx));
+                       idx, q_pose, s_pose, anchors, identity_anchor, reinterpret_cast<float4 *>(gx), nonident);
     return eap::check_launch("so3_prep");
 }
 
@@ -317,7 +326,7 @@ int launch_group_fwd(int b, int c, int p, int n, int nn, int na, int ks, float s
 extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, int na, int ks,
                                            float sigma, const float *feats, const int32_t *idx,
                                            const float *gx, const float *rk, const uint8_t *mult,
-                                           float *out, eap_stream_t stream) {
+                                           const int32_t *nonident, float *out, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd: at most 32 kernel points (use the zpconv op)");
@@ -325,7 +334,7 @@ extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, i
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, eap::S(stream)), "so3_inter_group_fwd memset");
     // >= 16 channels: matrix-core formulation (csrc/so3_inter_mfma.hip); fewer: the VALU kernel
     // below (a 32-channel MFMA tile would be mostly padding)
-    if (c >= 16) return eap_so3_inter_group_fwd_mfma_f32(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, stream);
+    if (c >= 16) return eap_so3_inter_group_fwd_mfma_f32(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, out, stream);
     if (ks <= 24) return launch_group_fwd<6>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
     return launch_group_fwd<8>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
 }

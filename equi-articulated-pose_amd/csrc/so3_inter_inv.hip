@@ -111,15 +111,18 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             if (j0 + nl >= n_ent) next_p[u] = -1;
         }
     };
+    unsigned row_off[NST];                            // 32-bit element offsets, channel part precomputed
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+        const int cl = (u * (TM / 16) + rgrp) % CB;
+        row_off[u] = (unsigned)min(c0 + cl, o - 1) * (unsigned)p * (unsigned)na + 4u * (unsigned)pc;
+    }
     auto fetch = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
-            const int row = u * (TM / 16) + rgrp;       // row = nl * CB + cl
-            const int cl = row % CB;
             const int pe = next_p[u];
             stage_p[u] = pe;
-            const float *src = fb + ((size_t)min(c0 + cl, o - 1) * p + max(pe, 0)) * na + 4 * pc;
-            stage[u] = *reinterpret_cast<const float4 *>(src);
+            stage[u] = *reinterpret_cast<const float4 *>(fb + (row_off[u] + __umul24((unsigned)max(pe, 0), (unsigned)na)));
         }
         if (t < NBK) gtmp = ent_gx[e0 + min(j0 + t, max(n_ent - 1, 0))];
         if (t < NBK && j0 + t >= n_ent) gtmp = make_float4(1e18f, 1e18f, 1e18f, 0.f);
@@ -272,6 +275,7 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64 || (na & 3) != 0) return eap::bad_arg("so3_inter_group_inv: the anchor count must be a multiple of 4, at most 64");
     if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
+    if ((long long)o * p * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_inv: one cloud's gradient exceeds 2^31 elements");
     hipStream_t s = eap::S(stream);
     const int FP_ = na <= 60 ? 60 : FPMAX;
     const size_t stage_b = sizeof(float) * 2 * NBK * CB * FP_;

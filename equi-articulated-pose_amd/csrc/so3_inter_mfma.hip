@@ -39,7 +39,8 @@ template <int APW, bool EXACT, bool HAS_MULT>
 __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     int c, int p, int n_sup, int nn, int na, int ks, float inv_sigma,
     const float *__restrict__ feats, const int32_t *__restrict__ idx, const float4 *__restrict__ gx,
-    const float *__restrict__ rk, const uint8_t *__restrict__ mult, float *__restrict__ out) {
+    const float *__restrict__ rk, const uint8_t *__restrict__ mult, const int32_t *__restrict__ nonident,
+    float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int FP = na <= 60 ? 60 : FPMAX, FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
@@ -79,14 +80,20 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     const int a_beg = q_beg + (wave_u >= 4 ? first : 0);
     const int a_cnt = wave_u >= 4 ? q_cnt - first : first;   // <= APW
     const int lk = lane & 31, lh = lane >> 5;
-    float kx[APW], ky[APW], kz[APW];
+    // kernel weight  w = relu(1 - |g - k|^2 / sigma) = relu(base_n + kc + g . k'),
+    //   base_n = 1 - |g|^2/sigma (once per neighbour),  k' = 2k/sigma,  kc = -|k|^2/sigma:
+    // 3 FMAs + add + max per weight; unused kernel-point columns carry kc = -1e30 (weight 0)
+    float kx[APW], ky[APW], kz[APW], kc[APW];
 #pragma unroll
     for (int ai = 0; ai < APW; ++ai) {
         const bool ok = ai < a_cnt && lk < ks;
         const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + min(lk, ks - 1)) * 3;   // clamped, always valid
         const float x = r3[0], y = r3[1], z = r3[2];
-        kx[ai] = ok ? x : -1e18f; ky[ai] = ok ? y : -1e18f; kz[ai] = ok ? z : -1e18f;   // unused k column: weight 0
+        kx[ai] = 2.f * inv_sigma * x; ky[ai] = 2.f * inv_sigma * y; kz[ai] = 2.f * inv_sigma * z;
+        kc[ai] = ok ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
     }
+    // identity relative rotations everywhere in this cloud (flag from so3_prep): no table lookups
+    const bool plain = !HAS_MULT || (nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) == 0);
 
     f32x16 acc[APW];
 #pragma unroll
@@ -106,13 +113,20 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     // fetch(): raw, UNCONDITIONAL loads from clamped (always valid) addresses -- nothing the
     // compiler could turn into 16 predicated, individually awaited loads; masking of shadow
     // rows / channel tail / idle lanes happens in stash(), right before the LDS write
+    // 32-bit element offsets (the launcher guarantees c*n_sup*na < 2^31): per staged row the
+    // channel part of the address is a per-thread constant, the neighbour part one 24-bit multiply
+    unsigned row_off[NBK * CB * 16 / TM];
+#pragma unroll
+    for (int u = 0; u < NBK * CB * 16 / TM; ++u) {
+        const int cl = (u * (TM / 16) + rgrp) % CB;
+        row_off[u] = (unsigned)min(c0 + cl, c - 1) * (unsigned)n_sup * (unsigned)na + 4u * (unsigned)pc;
+    }
     auto fetch = [&](int n0) {
 #pragma unroll
         for (int u = 0; u < NBK * CB * 16 / TM; ++u) {
-            const int row = u * (TM / 16) + rgrp;       // row = nl * CB + cl
-            const int nl = row / CB, cl = row - nl * CB;
+            const int nl = (u * (TM / 16) + rgrp) / CB;
             const int q = s_q[n0 + nl];
-            const float *src = fb + ((size_t)min(c0 + cl, c - 1) * n_sup + max(q, 0)) * na + 4 * pc;
+            const float *src = fb + (row_off[u] + __umul24((unsigned)max(q, 0), (unsigned)na));
             if constexpr (vec_ok) {
                 stage[u] = *reinterpret_cast<const float4 *>(src);
             } else {
@@ -152,19 +166,24 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     auto gather = [&](const float *fbuf, int n0, int s, float (&fa)[APW]) {
         const int nl = 2 * s + lh;
         const float *frow = fbuf + ((size_t)nl * CB + lk) * FP;
-        const int r = __float_as_int(s_g[n0 + nl].w);
+        if (plain) {                                     // wave-uniform
 #pragma unroll
-        for (int ai = 0; ai < APW; ++ai) {
-            const int a = min(a_beg + ai, na - 1);
-            fa[ai] = frow[HAS_MULT ? (int)s_mult[r * na + a] : a];
+            for (int ai = 0; ai < APW; ++ai) fa[ai] = frow[min(a_beg + ai, na - 1)];
+        } else {
+            const int r = __float_as_int(s_g[n0 + nl].w);
+#pragma unroll
+            for (int ai = 0; ai < APW; ++ai) fa[ai] = frow[(int)s_mult[r * na + min(a_beg + ai, na - 1)]];
         }
     };
     auto step = [&](int n0, int s, const float (&fa)[APW]) {
         const float4 g = s_g[n0 + 2 * s + lh];
+        const float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
 #pragma unroll
         for (int ai = 0; ai < APW; ++ai) {
-            const float dx = g.x - kx[ai], dy = g.y - ky[ai], dz = g.z - kz[ai];
-            const float wv = fmaxf(1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma, 0.0f);
+            float tt = fmaf(g.x, kx[ai], kc[ai]);
+            tt = fmaf(g.y, ky[ai], tt);
+            tt = fmaf(g.z, kz[ai], tt);
+            const float wv = fmaxf(tt + base, 0.0f);
             if (ai < a_cnt)                              // wave-uniform
                 acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv, acc[ai], 0, 0, 0);
         }
@@ -243,10 +262,11 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
 extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int nn, int na, int ks,
                                                 float sigma, const float *feats, const int32_t *idx,
                                                 const float *gx, const float *rk, const uint8_t *mult,
-                                                float *out, eap_stream_t stream) {
+                                                const int32_t *nonident, float *out, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 32 kernel points");
+    if ((long long)c * n * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_fwd_mfma: one cloud's features exceed 2^31 elements");
     hipStream_t s = eap::S(stream);
     const int FP_ = na <= 60 ? 60 : FPMAX;
     if (nn <= 0)
@@ -266,7 +286,7 @@ extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int 
                                               (int)shmem), "so3_inter_group_fwd_mfma shared memory");         \
         if (e) return e;                                                                                      \
         hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, c, p, n, nn, na, ks, inv_sigma, feats, idx, g4,    \
-                           rk, mult, out);                                                                    \
+                           rk, mult, nonident, out);                                                          \
     } while (0)
     if ((na & 3) == 0) { if (mult) EAP_MFMA_LAUNCH(8, true, true); else EAP_MFMA_LAUNCH(8, true, false); }
     else if (mult) EAP_MFMA_LAUNCH(8, false, true);

@@ -103,9 +103,10 @@ def so3_prep(q_xyz, s_xyz, idx, q_pose, s_pose, anchors, identity_anchor):
     n = s_xyz.shape[2]
     nn = idx.shape[2]
     gx = torch.empty(b, p, nn, 4, dtype=torch.float32, device=q_xyz.device)
+    nonident = torch.empty(b, dtype=torch.int32, device=q_xyz.device)
     call('eap_so3_prep_f32', gx, b, p, n, nn, anchors.shape[0], _ptr(q_xyz), _ptr(s_xyz), _ptr(idx),
-         _ptr(q_pose), _ptr(s_pose), _ptr(anchors), int(identity_anchor), _ptr(gx))
-    return gx
+         _ptr(q_pose), _ptr(s_pose), _ptr(anchors), int(identity_anchor), _ptr(gx), _ptr(nonident))
+    return gx, nonident
 
 
 def so3_inter_weights(gx, rk, sigma):
@@ -124,13 +125,13 @@ def so3_anchor_perm(gx, mult):
     return perm
 
 
-def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma):
+def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None):
     b, c, n, na = feats.shape
     p, nn = idx.shape[1], idx.shape[2]
     ks = rk.shape[1]
     out = torch.empty(b, c, ks, p, na, dtype=torch.float32, device=feats.device)
     call('eap_so3_inter_group_fwd_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
-         _ptr(gx), _ptr(rk), _ptr(mult), _ptr(out))
+         _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out))
     return out
 
 

@@ -158,21 +158,21 @@ class _InterGroup(torch.autograd.Function):
     """new_feats[b,c,k,p,a] = sum_n feats[b,c,idx_n,perm_n(a)] w(p,a,k,n)  (functional.py:L1221-1261)."""
 
     @staticmethod
-    def forward(ctx, feats, idx, gx, rk, mult, sigma, ident=0):
+    def forward(ctx, feats, idx, gx, rk, mult, sigma, ident=0, nonident=None):
         feats = feats.contiguous()
         ctx.ident = ident
         ctx.save_for_backward(idx, gx, rk, mult if mult is not None else torch.empty(0))
         ctx.has_mult = mult is not None
         ctx.sigma = sigma
         ctx.n = feats.shape[2]
-        return _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma)
+        return _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident)
 
     @staticmethod
     def backward(ctx, gout):
         idx, gx, rk, mult = ctx.saved_tensors
         g = _hip.so3_inter_group_bwd(gout.contiguous(), idx, gx, rk, mult if ctx.has_mult else None,
                                      ctx.sigma, ctx.n, ctx.ident)
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None
 
 
 class _IntraGroup(torch.autograd.Function):
@@ -226,7 +226,7 @@ BACKWARD_MODE = 'auto'      # 'auto' | 'inverse' | 'dx'
 INV_ROW_FRACTION = 4
 
 
-def _inverse_lists(idx, gx, n_sup, ident):
+def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
     """Inverse neighbour lists of idx [b,p,nn] (which (point, slot) pairs reference each support
     row), with the referenced rows compacted.  Small torch plumbing on the device; ONE host sync
     (the number of referenced rows sizes the workspace)."""
@@ -241,7 +241,10 @@ def _inverse_lists(idx, gx, n_sup, ident):
     n_rows = nonempty.sum(1)
     # one host sync for both facts the launch needs: workspace rows, and whether any relative
     # rotation differs from the identity (if none does, the permutation table is skipped)
-    all_ident = (gx[..., 3].contiguous().view(torch.int32) == ident).all()
+    if nonident is not None:
+        all_ident = (nonident == 0).all()
+    else:
+        all_ident = (gx[..., 3].contiguous().view(torch.int32) == ident).all()
     rcap, all_ident = torch.stack([n_rows.max(), all_ident.to(n_rows.dtype)]).tolist()
     rcap, all_ident = int(rcap), bool(all_ident)
     rows = torch.argsort((~nonempty).to(torch.int8), dim=1, stable=True)[:, :rcap]
@@ -260,23 +263,26 @@ class _InterConv(torch.autograd.Function):
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident):
+    def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident, nonident=None):
         feats = feats.contiguous()
         W = W.contiguous()
-        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma)      # [b,c,k,p,a]
+        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident)      # [b,c,k,p,a]
         b, c, ks, p, na = x.shape
         o = W.shape[0]
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=x.device)
         _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b)
-        ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0))
+        ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0),
+                              nonident if nonident is not None else torch.empty(0))
         ctx.has_mult = mult is not None
+        ctx.has_flag = nonident is not None
         ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        W, x, idx, gx, rk, mult = ctx.saved_tensors
+        W, x, idx, gx, rk, mult, nonident = ctx.saved_tensors
         mult = mult if ctx.has_mult else None
+        nonident = nonident if ctx.has_flag else None
         gy = gy.contiguous()
         b, c, ks, p, na = x.shape
         o, ck, pa = W.shape[0], c * ks, p * na
@@ -288,7 +294,7 @@ class _InterConv(torch.autograd.Function):
             n = ctx.n
             inv = None
             if BACKWARD_MODE != 'dx' and na % 4 == 0 and ks <= 32:
-                inv = _inverse_lists(idx, gx, n, ctx.ident)
+                inv = _inverse_lists(idx, gx, n, ctx.ident, nonident)
                 if BACKWARD_MODE == 'auto' and inv[5] * INV_ROW_FRACTION > n:
                     inv = None
             if inv is not None:
@@ -311,7 +317,7 @@ class _InterConv(torch.autograd.Function):
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
-        return gF, gW, None, None, None, None, None, None
+        return gF, gW, None, None, None, None, None, None, None
 
 
 def so3_contract(W, x):
@@ -353,8 +359,8 @@ def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, 
             if mult is None:
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
-    gx = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
-    new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident)
+    gx, nonident = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), new_feats
 
@@ -379,8 +385,8 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
             if mult is None:
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
-    gx = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
-    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident)
+    gx, nonident = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 
@@ -398,7 +404,7 @@ def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, rad
         return inter_idx, inter_w, xyz, new_feats, sample_idx
     # cached neighbourhood from an earlier layer (functional.py:L195-201)
     if isinstance(inter_w, InterWeights):
-        new_feats = _InterGroup.apply(feats, inter_idx, inter_w.gx, inter_w.rk, None, inter_w.sigma)
+        new_feats = _InterGroup.apply(feats, inter_idx, inter_w.gx, inter_w.rk, None, inter_w.sigma, 0, None)
     else:
         new_feats = inter_so3conv_feat_grouping(inter_idx, inter_w, zpconv.add_shadow_feature(feats))
     return inter_idx, inter_w, xyz, new_feats, None
@@ -429,5 +435,5 @@ def anchor_permutation_index(xyz, pose, n_neighbor, anchors, radius):
     """The reference's rotated_anchor_idx int64 [b,p,nn,na] (functional.py:L1199-1204); test hook."""
     ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
     mult, ident = _group_tables(anchors)
-    gx = _hip.so3_prep(xyz, xyz, ball_idx, pose.contiguous(), pose.contiguous(), anchors.contiguous(), ident)
+    gx, _ = _hip.so3_prep(xyz, xyz, ball_idx, pose.contiguous(), pose.contiguous(), anchors.contiguous(), ident)
     return _hip.so3_anchor_perm(gx, mult)

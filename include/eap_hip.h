@@ -113,10 +113,12 @@ int eap_intra_zpconv_bwd_f64(int b, int np, int na_in, int na_out, int ks, int a
  * q_xyz [b,3,p], s_xyz [b,3,n], idx int32 [b,p,nn], pose [b,n,4,4] (q_pose [b,p,4,4]) or NULL
  * for identity poses, anchors [na,3,3]
  *  -> gx float4 [b,p,nn] = (gx,gy,gz, bit-cast int r) with g = R_rel (x_n - x_p) and
- *     r = argmax_g tr(R_rel A_g)  (r = index of the identity anchor when pose == NULL). */
+ *     r = argmax_g tr(R_rel A_g)  (r = index of the identity anchor when pose == NULL);
+ *     nonident int32 [b] (optional): set to 1 for clouds where some r != identity_anchor. */
 int eap_so3_prep_f32(int b, int p, int n, int nn, int na, const float *q_xyz, const float *s_xyz,
                      const int32_t *idx, const float *q_pose, const float *s_pose,
-                     const float *anchors, int identity_anchor, float *gx, eap_stream_t stream);
+                     const float *anchors, int identity_anchor, float *gx, int32_t *nonident,
+                     eap_stream_t stream);
 
 /* so3_inter_weights: inter_so3conv_grouping_anchor, so3conv/functional.py:L2508-2549.
  * gx float4 [b,p,nn] (from so3_prep), rk [na,ks,3] = A_a kappa_k
@@ -133,18 +135,19 @@ int eap_so3_anchor_perm(int b, int p, int nn, int na, const float *gx, const uin
  * so3conv/functional.py:L1112-1261 (einsum 'bcpna,bpakn->bckpa' at L1261) without materialising
  * the [b,p,na,ks,nn] weights.
  * feats [b,c,n,na], idx [b,p,nn], gx float4 [b,p,nn], rk [na,ks,3], mult [na,na] (NULL = no
- * permutation, permute_modes == 0) -> out [b,c,ks,p,na]. */
+ * permutation, permute_modes == 0), nonident int32 [b] from so3_prep or NULL (clouds whose flag
+ * is 0 skip the table) -> out [b,c,ks,p,na]. */
 int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
                                 const float *feats, const int32_t *idx, const float *gx,
-                                const float *rk, const uint8_t *mult, float *out,
-                                eap_stream_t stream);
+                                const float *rk, const uint8_t *mult, const int32_t *nonident,
+                                float *out, eap_stream_t stream);
 /* The two implementations behind so3_inter_group_fwd, exported for tests and profiling:
  * _mfma (c >= 16): v_mfma_f32_32x32x2_f32 with the kernel weights generated in registers as the
  * B operand; _valu: lanes = anchors, register tile of channels x kernel points. */
 int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
                                      const float *feats, const int32_t *idx, const float *gx,
-                                     const float *rk, const uint8_t *mult, float *out,
-                                     eap_stream_t stream);
+                                     const float *rk, const uint8_t *mult, const int32_t *nonident,
+                                     float *out, eap_stream_t stream);
 int eap_so3_inter_group_fwd_valu_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
                                      const float *feats, const int32_t *idx, const float *gx,
                                      const float *rk, const uint8_t *mult, float *out,

@@ -399,7 +399,7 @@ def _raw_group(dev, B, P, C, layer, valu=False):
     idx = G.ball_query(xyz, xyz, r, 64)
     mult, ident = L._group_tables(conv.anchors)
     rk = L.rotated_kernels(conv.anchors, conv.kernels)
-    gx = _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident)
+    gx, nonident = _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident)
     return idx, gx, rk, mult, s, ident
 
 

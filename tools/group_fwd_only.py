@@ -19,7 +19,7 @@ feats = torch.randn(B, c, P, 60, device=dev)
 idx = G.ball_query(xyz, xyz, r, 64)
 mult, ident = L._group_tables(conv.anchors)
 rk = L.rotated_kernels(conv.anchors, conv.kernels)
-gx = _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident)
+gx, nonident = _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident)
 for _ in range(3):
-    X = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, s)
+    X = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, s, nonident)
 torch.cuda.synchronize()

@@ -37,8 +37,8 @@ for li, (c, o, r, s) in enumerate(synth_clouds.backbone_layers(P)):
     idx = timed(f'L{li} ball_query r={r:.3f}', lambda: G.ball_query(xyz, xyz, r, 64))
     mult, ident = L._group_tables(conv.anchors)
     rk = L.rotated_kernels(conv.anchors, conv.kernels)
-    gx = timed(f'L{li} so3_prep', lambda: _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident))
-    X = timed(f'L{li} group_fwd C={c}', lambda: _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, s))
+    gx, nonident = timed(f'L{li} so3_prep', lambda: _hip.so3_prep(xyz, xyz, idx, pose, pose, conv.anchors, ident))
+    X = timed(f'L{li} group_fwd C={c}', lambda: _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, s, nonident))
     Y = timed(f'L{li} gemm {o}x{c*24}', lambda: L.so3_contract(conv.basic_conv.W, X.view(B, c * 24, P * 60)))
     fl = 2.0 * o * c * 24 * P * 60 * B
     if bwd:
