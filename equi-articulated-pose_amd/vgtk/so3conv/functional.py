@@ -275,6 +275,7 @@ class _InterConv(torch.autograd.Function):
                               nonident if nonident is not None else torch.empty(0))
         ctx.has_mult = mult is not None
         ctx.has_flag = nonident is not None
+        ctx.feats_ref = feats          # needed by the re-associated weight gradient (not a new copy)
         ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
         return y
 
@@ -287,33 +288,47 @@ class _InterConv(torch.autograd.Function):
         b, c, ks, p, na = x.shape
         o, ck, pa = W.shape[0], c * ks, p * na
         gW = gF = None
-        if ctx.needs_input_grad[1]:
-            gW = torch.empty_like(W)          # sum_b gy_b x_b^T
-            _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)
-        if ctx.needs_input_grad[0]:
-            n = ctx.n
-            inv = None
-            if BACKWARD_MODE != 'dx' and na % 4 == 0 and ks <= 32:
-                inv = _inverse_lists(idx, gx, n, ctx.ident, nonident)
-                if BACKWARD_MODE == 'auto' and inv[5] * INV_ROW_FRACTION > n:
-                    inv = None
-            if inv is not None:
-                rows, off, cnt, ent_p, ent_gx, rcap, all_ident = inv
-                multinv = None
-                if mult is not None and not all_ident:   # multinv[r][a'] = a  with  mult[r][a] = a'
-                    multinv = torch.empty_like(mult)
-                    multinv.scatter_(1, mult.long(), torch.arange(na, device=mult.device, dtype=torch.uint8).repeat(na, 1))
-                z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
-                                             ctx.ident)
+        n = ctx.n
+        # Strategy: when few support rows are referenced (the reference's first-nsample-in-index-
+        # order ball query with large radii), BOTH gradients follow from
+        #     Z[o,k,q,a'] = sum_{(p,n)->q} dY[o,p,a] w(p,a,k,n)          (csrc/so3_inter_inv.hip)
+        #     dF[c,q,a'] = sum_{o,k} W[o,(c,k)] Z[o,k,q,a']       dW[o,(c,k)] = sum_{q,a'} Z[o,k,q,a'] F[c,q,a']
+        # two small GEMMs over the referenced rows only -- no dX = W^T dY, no scatter, and the
+        # [O x P*A] x [P*A x C*K] weight-gradient GEMM shrinks by P / (referenced rows).
+        inv = None
+        if BACKWARD_MODE != 'dx' and na % 4 == 0 and ks <= 32 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            inv = _inverse_lists(idx, gx, n, ctx.ident, nonident)
+            if BACKWARD_MODE == 'auto' and inv[5] * INV_ROW_FRACTION > n:
+                inv = None
+        if inv is not None:
+            rows, off, cnt, ent_p, ent_gx, rcap, all_ident = inv
+            multinv = None
+            if mult is not None and not all_ident:   # multinv[r][a'] = a  with  mult[r][a] = a'
+                multinv = torch.empty_like(mult)
+                multinv.scatter_(1, mult.long(), torch.arange(na, device=mult.device, dtype=torch.uint8).repeat(na, 1))
+            z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
+                                         ctx.ident)                                  # [b,o,ks,rcap,na]
+            ra = rcap * na
+            dest = torch.where(rows >= 0, rows, torch.full_like(rows, n)).long()   # unused slots -> dummy row n
+            if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
-                gFc = torch.empty(b, c, rcap * na, dtype=torch.float32, device=gy.device)
-                _hip.gemm(0, 0, c, rcap * na, o * ks, W2, o * ks, 0, z, rcap * na, o * ks * rcap * na,
-                          gFc, rcap * na, c * rcap * na, b)
+                gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
+                _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
                 gF = torch.zeros(b, c, n + 1, na, dtype=torch.float32, device=gy.device)
-                dest = torch.where(rows >= 0, rows, torch.full_like(rows, n)).long()
                 gF.scatter_(2, dest[:, None, :, None].expand(b, c, rcap, na), gFc.view(b, c, rcap, na))
                 gF = gF[:, :, :n].contiguous()
-            else:
+            if ctx.needs_input_grad[1]:
+                feats = ctx.feats_ref
+                fpad = torch.cat([feats, feats.new_zeros(b, c, 1, na)], 2)          # dummy row n = zeros
+                fc = torch.gather(fpad, 2, dest[:, None, :, None].expand(b, c, rcap, na)).reshape(b, c, ra).contiguous()
+                d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
+                _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
+                gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
+        else:
+            if ctx.needs_input_grad[1]:
+                gW = torch.empty_like(W)          # sum_b gy_b x_b^T
+                _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)
+            if ctx.needs_input_grad[0]:
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)

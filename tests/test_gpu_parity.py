@@ -427,8 +427,8 @@ def test_full_size_group_mfma_equals_valu_and_is_linear(dev, vg):
 
 
 def test_full_size_layer_gradients_agree_between_strategies(dev, vg, monkeypatch):
-    """4096 points, L2-layer radius (the hot-row regime): dF from the inverse-list path equals dF
-    from dX + transposed grouping, and dW is identical."""
+    """4096 points, L2-layer radius (the hot-row regime): dF and dW from the re-associated
+    (inverse-list) path equal dF from dX + transposed grouping and dW from dY X^T."""
     import synth_clouds
     _, sptk, zptk, L = vg
     P = 4096
@@ -447,7 +447,8 @@ def test_full_size_layer_gradients_agree_between_strategies(dev, vg, monkeypatch
     scale = grads['dx'][0].abs().max().item()
     assert (grads['dx'][0] - grads['inverse'][0]).abs().max().item() < 2e-5 * scale
     assert torch.equal(grads['inverse'][0], grads['auto'][0])        # auto picks the inverse path here
-    assert torch.equal(grads['dx'][1], grads['inverse'][1])
+    wscale = grads['dx'][1].abs().max().item()                      # dW: reduction over referenced rows vs over all points
+    assert (grads['dx'][1] - grads['inverse'][1]).abs().max().item() < 5e-5 * wscale
 
 
 def test_full_size_backward_is_the_adjoint(dev, vg):
