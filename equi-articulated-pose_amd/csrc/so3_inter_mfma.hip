@@ -74,11 +74,11 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     // around the MFMAs)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // a quarter of the anchors per SIMD, split between the two waves that share it (w, w + 4)
-    const int quarter = (na + 3) >> 2, q_beg = (wave_u & 3) * quarter;
-    const int q_cnt = max(0, min(na, q_beg + quarter) - q_beg);
-    const int first = (q_cnt + 1) >> 1;
-    const int a_beg = q_beg + (wave_u >= 4 ? first : 0);
-    const int a_cnt = wave_u >= 4 ? q_cnt - first : first;   // <= APW
+    // 8 waves, contiguous anchor ranges that all start at an EVEN anchor (8,8,8,8,8,8,6,6 at na = 60)
+    // so that a pair of anchors is one aligned 8-byte LDS read; waves w and w+4 share a SIMD
+    const int per = min(APW, (((na + NWV - 1) / NWV) + 1) & ~1);
+    const int a_beg = min(wave_u * per, na);
+    const int a_cnt = max(0, min(per, na - a_beg));
     const int lk = lane & 31, lh = lane >> 5;
     // kernel weight  w = relu(1 - |g - k|^2 / sigma) = relu(base_n + kc + g . k'),
     //   base_n = 1 - |g|^2/sigma (once per neighbour),  k' = 2k/sigma,  kc = -|k|^2/sigma:
@@ -166,9 +166,12 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     auto gather = [&](const float *fbuf, int n0, int s, float (&fa)[APW]) {
         const int nl = 2 * s + lh;
         const float *frow = fbuf + ((size_t)nl * CB + lk) * FP;
-        if (plain) {                                     // wave-uniform
+        if (plain) {                                     // wave-uniform; anchor pairs = one aligned 8-byte read
 #pragma unroll
-            for (int ai = 0; ai < APW; ++ai) fa[ai] = frow[min(a_beg + ai, na - 1)];
+            for (int ai = 0; ai < APW; ai += 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(frow + min(a_beg + ai, na - 2));
+                fa[ai] = v.x; fa[ai + 1] = v.y;
+            }
         } else {
             const int r = __float_as_int(s_g[n0 + nl].w);
 #pragma unroll
