@@ -113,32 +113,36 @@ def cpu_baseline(points, slab=64):
             'value_perm_search_short_circuited': out['short_circuit']}
 
 
-def summarize_kernels(records, steps):
-    """records of (name, tag, e0, e1) -> per-kernel totals; picks the dominant kernel."""
-    agg = {}
+KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
+    'eap_gemm_f32': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
+    'eap_gemm_f32_reduce': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K',
+    'eap_so3_inter_group_fwd_f32': 'so3_inter_group_fwd_mfma_kernel (v_mfma_f32_32x32x2_f32)',
+    'eap_so3_inter_group_inv_f32': 'so3_inter_group_inv_kernel (v_mfma_f32_32x32x2_f32)',
+}
+
+
+def summarize_kernels(records):
+    """(name, tag, e0, e1) records of the timed steps -> per C-ABI entry: total ms, launches,
+    algorithmic flops; and per launch shape."""
+    by_name, by_shape = {}, {}
     for name, tag, e0, e1 in records:
         ms = e0.elapsed_time(e1)
-        key = (name, tag)
-        a = agg.setdefault(key, [0.0, 0])
-        a[0] += ms
-        a[1] += 1
-    shapes = []
-    for (name, tag), (ms, cnt) in agg.items():
-        if tag is not None:
-            ta, tb, M, N, K, batch = tag
-            shapes.append({'entry': name, 'transA': ta, 'transB': tb, 'M': M, 'N': N, 'K': K, 'batch': batch,
-                           'launches': cnt, 'avg_ms': ms / cnt,
-                           'tflops': 2.0 * M * N * K * batch * cnt / (ms * 1e-3) / 1e12})
-    shapes.sort(key=lambda d: -d['avg_ms'] * d['launches'])
-    by_name = {'_gemm_shapes': shapes}
-    for (name, tag), (ms, cnt) in agg.items():
         b = by_name.setdefault(name, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
         b['ms'] += ms
-        b['launches'] += cnt
+        b['launches'] += 1
         if tag is not None:
-            ta, tb, M, N, K, batch = tag
-            b['flops'] += 2.0 * M * N * K * batch * cnt
-    return by_name
+            b['flops'] += tag['flops']
+            s = by_shape.setdefault((name, tag['shape']), {'entry': name, 'shape': list(tag['shape']), 'ms': 0.0,
+                                                           'launches': 0, 'flops': 0.0})
+            s['ms'] += ms
+            s['launches'] += 1
+            s['flops'] += tag['flops']
+    shapes = sorted(by_shape.values(), key=lambda d: -d['ms'])
+    for s in shapes:
+        s['avg_ms'] = s['ms'] / s['launches']
+        s['tflops'] = s['flops'] / (s['ms'] * 1e-3) / 1e12
+        del s['ms'], s['flops']
+    return by_name, shapes
 
 
 def main():
@@ -208,23 +212,17 @@ def main():
         dt = t.item()
 
     if rank == 0:
-        kern = summarize_kernels(records, args.steps)
-        gemm_shapes = kern.pop('_gemm_shapes')
+        kern, shapes = summarize_kernels(records)
         dom_name = max(kern, key=lambda k: kern[k]['ms'])
-        # HBM bytes per launch of the largest GEMM shape (L2-layer forward contraction), from the
-        # rocprofv3 FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (measured at B=2,
-        # scaled per cloud; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        dom = kern[dom_name]
+        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 and dom['flops'] > 0 else 0.0
+        # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes committed under
+        # profiles/ (only measured for the contraction GEMM so far; null otherwise)
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_b_gemm_pmc_hbm_traffic.json')
-        if os.path.exists(pmc) and args.points == 4096:
+        if dom_name == 'eap_gemm_f32' and os.path.exists(pmc) and args.points == 4096:
             d = json.load(open(pmc))['derived']
             traffic = (d['fwd_read_GB_corrected'] + d['fwd_write_GB']) / 2.0 * args.batch * 1e9
-        gemm = {'ms': 0.0, 'launches': 0, 'flops': 0.0}
-        for n in ('eap_gemm_f32', 'eap_gemm_f32_reduce'):
-            if n in kern:
-                for k in gemm:
-                    gemm[k] += kern[n][k]
-        achieved = gemm['flops'] / (gemm['ms'] * 1e-3) / 1e12 if gemm['ms'] > 0 else 0.0
         clouds = args.batch * world * args.steps
         line = {
             'metric': 'point-clouds/sec (4096 pts, 60 anchors) ' + ('fwd' if args.fwd_only else 'fwd+bwd'),
@@ -236,15 +234,18 @@ def main():
                                    + ('forward' if args.fwd_only else 'forward+backward+Adam'),
                        'clouds_per_gpu': args.batch, 'points': args.points, 'anchors': NA,
                        'sharding': f'clouds x{world}, pose all-gather + 1 gradient all-reduce' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
+            'roofline': {'bound': 'mfma', 'kernel': KERNEL_OF_ENTRY.get(dom_name, dom_name), 'entry': dom_name,
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'traffic_note': 'HBM bytes per launch of the largest shape (M=512,N=245760,K=3072 per cloud), PMC passes in profiles/',
-                         'launches': gemm['launches'], 'avg_launch_ms': gemm['ms'] / max(gemm['launches'], 1),
-                         'share_of_kernel_time': gemm['ms'] / max(sum(k['ms'] for k in kern.values()), 1e-9)},
-            'kernel_ms_per_step': {n: k['ms'] / args.steps for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])},
+                         'flops_definition': 'algorithmic: 2*M*N*K*batch for GEMMs; 2*channels*K(24)*P*NN*A*B for '
+                                             'the grouping kernels (the MFMA tiles pad K 24->32, not counted)',
+                         'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
+                         'share_of_kernel_time': dom['ms'] / max(sum(k['ms'] for k in kern.values()), 1e-9)},
+            'kernels': {n: {'ms_per_step': k['ms'] / args.steps, 'launches_per_step': k['launches'] / args.steps,
+                            'tflops': (k['flops'] / (k['ms'] * 1e-3) / 1e12) if k['flops'] > 0 else None}
+                        for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])},
             'dominant_kernel': dom_name,
-            'gemm_shapes': gemm_shapes[:6],
+            'launch_shapes': shapes[:8],
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.points)

@@ -21,6 +21,13 @@
 // so the rotated kernel points come from an LDS table instead of registers.
 #include "common.h"
 
+#ifdef EAP_INV_TRACE
+__device__ unsigned long long eap_inv_trace[8 * 16];
+#define TR(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tr[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TR(i)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,7 +54,23 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     float4 *s_rk = s_g + 2 * NBK;                                           // [na][ks] scaled kernel points (HAS_MULT)
     uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_rk + (HAS_MULT ? na * ks : 0));
 
-    const int ri = blockIdx.x, c0 = blockIdx.y * CB, bi = blockIdx.z;
+    // Block -> (row, channel slice, cloud).  Every entry list walks the query points in ascending
+    // order, so blocks that work on the SAME channel slice of the SAME cloud at the same time read
+    // the same window of dY.  Workgroups go to the 8 XCDs round-robin by linear id: hand each XCD
+    // whole slices (its 32 CUs then share one window in their own L2) instead of one row in eight
+    // of every slice.  Rows arrive sorted by entry count, so neighbours advance at the same pace.
+    int ri = blockIdx.x, cy = blockIdx.y, bi = blockIdx.z;
+    {
+        const int ny = gridDim.y, nsl = ny * gridDim.z;
+        if ((nsl & 7) == 0) {
+            const unsigned lin = blockIdx.x + (unsigned)rcap * (blockIdx.y + (unsigned)ny * blockIdx.z);
+            const unsigned j = lin >> 3, sl = (lin & 7u) + 8u * (j / (unsigned)rcap);
+            ri = (int)(j % (unsigned)rcap);
+            cy = (int)(sl % (unsigned)ny);
+            bi = (int)(sl / (unsigned)ny);
+        }
+    }
+    const int c0 = cy * CB;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int q = rows[(size_t)bi * rcap + ri];
     const int n_ent = q >= 0 ? cnt[(size_t)bi * rcap + ri] : 0;
@@ -204,12 +227,17 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         }
     };
 
+#ifdef EAP_INV_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
+        TR(0);
         if (ch + 1 < nchunk) {
             fetch((ch + 1) * NBK);
             fetch_index((ch + 2) * NBK);
         }
+        TR(1);
         const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
         float fa0[APW], fa1[APW];
         int aw0[APW], aw1[APW];
@@ -228,9 +256,18 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         step(buf, 2, fa0, aw0);
         __builtin_amdgcn_sched_barrier(0);
         step(buf, 3, fa1, aw1);
+        TR(2);
         if (ch + 1 < nchunk) stash(buf ^ 1);
+        TR(3);
         __syncthreads();
+        TR(4);
     }
+#ifdef EAP_INV_TRACE
+    if (blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0) {
+        for (int i = 0; i < 8; ++i) eap_inv_trace[wave * 16 + i] = tr[i];
+        eap_inv_trace[wave * 16 + 8] = nchunk;
+    }
+#endif
 
     // ---- epilogue: Z[b, o, k, ri, a'] (rows that are not referenced write zeros) ----------------
     float *s_o = s_f;
@@ -299,5 +336,16 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
         if (e) return e;
         hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
     }
+#ifdef EAP_INV_TRACE
+    {
+        unsigned long long h[8 * 16];
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(eap_inv_trace), sizeof(h));
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "inv trace wave %d: chunks %llu  fetch %llu  compute %llu  stash %llu  barrier %llu  (cycles/chunk)\n", w,
+                    h[w * 16 + 8], h[w * 16 + 1] / h[w * 16 + 8], h[w * 16 + 2] / h[w * 16 + 8], h[w * 16 + 3] / h[w * 16 + 8],
+                    h[w * 16 + 4] / h[w * 16 + 8]);
+    }
+#endif
     return eap::check_launch("so3_inter_group_inv");
 }

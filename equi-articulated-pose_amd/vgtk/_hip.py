@@ -87,7 +87,7 @@ def suffix(t):
 def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch):
     call('eap_gemm_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
          _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch,
-         tag=(int(transA), int(transB), M, N, K, batch))
+         tag={'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)})
 
 
 def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch):
@@ -95,7 +95,7 @@ def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ld
     ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=C.device)
     call('eap_gemm_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
          _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws),
-         tag=(int(transA), int(transB), M, N, K, batch))
+         tag={'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)})
 
 
 def so3_prep(q_xyz, s_xyz, idx, q_pose, s_pose, anchors, identity_anchor):
@@ -131,7 +131,8 @@ def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None):
     ks = rk.shape[1]
     out = torch.empty(b, c, ks, p, na, dtype=torch.float32, device=feats.device)
     call('eap_so3_inter_group_fwd_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
-         _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out))
+         _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out),
+         tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd', b, c, p, nn, na, ks)})
     return out
 
 
@@ -175,5 +176,6 @@ def so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, sigma, n
     ks = rk.shape[1]
     z = torch.empty(b, o, ks, rcap, na, dtype=torch.float32, device=gy.device)
     call('eap_so3_inter_group_inv_f32', z, b, o, p, nn, na, ks, rcap, _F32(sigma), _ptr(gy), _ptr(rows), _ptr(off),
-         _ptr(cnt), _ptr(ent_p), _ptr(ent_gx), _ptr(rk), _ptr(multinv), int(identity_anchor), _ptr(z))
+         _ptr(cnt), _ptr(ent_p), _ptr(ent_gx), _ptr(rk), _ptr(multinv), int(identity_anchor), _ptr(z),
+         tag={'flops': 2.0 * b * o * ks * p * nn * na, 'shape': ('group_inv', b, o, p, nn, na, ks, rcap)})
     return z

@@ -247,7 +247,9 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
         all_ident = (gx[..., 3].contiguous().view(torch.int32) == ident).all()
     rcap, all_ident = torch.stack([n_rows.max(), all_ident.to(n_rows.dtype)]).tolist()
     rcap, all_ident = int(rcap), bool(all_ident)
-    rows = torch.argsort((~nonempty).to(torch.int8), dim=1, stable=True)[:, :rcap]
+    # referenced rows first, longest entry list first: neighbouring blocks then walk the query
+    # points at the same pace (shared L2 window, csrc/so3_inter_inv.hip) and the long lists start early
+    rows = torch.argsort(counts, dim=1, descending=True, stable=True)[:, :rcap]
     valid = torch.arange(rcap, device=idx.device)[None, :] < n_rows[:, None]
     off_c = torch.gather(offs, 1, rows)
     cnt_c = torch.gather(counts, 1, rows) * valid
