@@ -40,7 +40,27 @@ constexpr int APW = 8;        // max anchors per wave
 constexpr int NWV = 8;
 constexpr int TM = 64 * NWV;
 
-template <bool HAS_MULT>
+// LDS byte address of a __shared__ object (what M0 takes for the LDS-DMA loads)
+__device__ inline unsigned lds_addr(const void *ptr) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
+}
+
+// One wave-wide 16-byte-per-lane global -> LDS DMA: lane l's 16 bytes land at lds_dst + 16*l.
+// Inline asm on purpose: hipcc tracks the builtin as an LDS store and drains vmcnt before every
+// later ds_read, which would serialise the next chunk's rows behind this chunk's operand reads;
+// an asm load is invisible to its bookkeeping and the kernel waits for it explicitly (dma_wait)
+// before the chunk barrier.  M0 is saved and restored in the same statement.
+__device__ inline void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// DMA = true: dY rows go global -> LDS directly (row pitch = na, no padding possible), issued
+// between the MFMA steps of the previous chunk; DMA = false: register-staged rows with a padded
+// pitch (anchor counts whose pitch would be a multiple of 32 banks).
+template <bool HAS_MULT, bool DMA>
 __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     int o, int p, int nn, int na, int ks, int rcap, float inv_sigma, int identity_anchor,
     const float *__restrict__ gy,
@@ -48,10 +68,11 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx, const float *__restrict__ rk,
     const uint8_t *__restrict__ multinv, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int FP = na <= 60 ? 60 : FPMAX, FP_ = FP;
+    const int FP = DMA ? na : (na <= 60 ? 60 : FPMAX), FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
-    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP_);       // [2][NBK]
-    float4 *s_rk = s_g + 2 * NBK;                                           // [na][ks] scaled kernel points (HAS_MULT)
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP_);       // [3][NBK] (ring; [2][NBK] used without DMA)
+    int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] entry -> query point (DMA), 16-byte multiple
+    float4 *s_rk = reinterpret_cast<float4 *>(s_p + 4 * NBK);               // [na][ks] scaled kernel points (HAS_MULT)
     uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_rk + (HAS_MULT ? na * ks : 0));
 
     // Block -> (row, channel slice, cloud).  Every entry list walks the query points in ascending
@@ -164,7 +185,68 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     };
 
     const int nchunk = (n_ent + NBK - 1) / NBK;
-    if (nchunk > 0) {
+
+    // ---- DMA path state: every thread owns NSTD fixed 16-byte pieces of a chunk's LDS image
+    // (piece f = u*TM + t of [NBK][CB][na/4]); only the entry's query point changes per chunk.
+    constexpr int NSTD = 8;                               // NBK*CB*(na/4)/TM <= 8 for na <= 64
+    const int total4 = NBK * CB * npiece;                 // a multiple of 64: whole waves are in or out
+    const unsigned lds_f = lds_addr(s_f);
+    const unsigned buf_bytes = (unsigned)(NBK * CB) * (unsigned)FP * 4u;
+    unsigned dma_off[NSTD], src_off[NSTD];
+    int dma_nl[NSTD];
+    int idx_p = 0;
+    float4 idx_g = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    if constexpr (DMA) {
+#pragma unroll
+        for (int u = 0; u < NSTD; ++u) {
+            const int f = min(u * TM + t, total4 - 1);
+            const int nl = f / (CB * npiece), rem = f - nl * (CB * npiece);
+            const int cl = rem / npiece, pcs = rem - cl * npiece;
+            dma_off[u] = (unsigned)min(c0 + cl, o - 1) * (unsigned)p * (unsigned)na + 4u * (unsigned)pcs;
+            dma_nl[u] = nl;
+        }
+    }
+    // wave 0 keeps the ring of entry -> (query point, offset vector) two chunks ahead of the MFMAs;
+    // entries past the end of the list repeat the last one with a dead offset vector (weight 0)
+    auto load_idx = [&](int j0) {
+        if (wave_u == 0) {
+            const int j = j0 + (lane & (NBK - 1));
+            const size_t e = e0 + min(j, max(n_ent - 1, 0));
+            idx_p = ent_p[e];
+            idx_g = ent_gx[e];
+            if (j >= n_ent) idx_g = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+        }
+    };
+    auto store_idx = [&](int slot) {
+        if (wave_u == 0 && lane < NBK) {
+            s_p[slot * NBK + lane] = idx_p;
+            s_g[slot * NBK + lane] = idx_g;
+        }
+    };
+    auto prep_rows = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < NSTD; ++u)
+            src_off[u] = dma_off[u] + __umul24((unsigned)s_p[slot * NBK + dma_nl[u]], (unsigned)na);
+    };
+    auto issue = [&](int u, int buf) {
+        const int f0 = u * TM + wave_u * 64;              // wave-uniform
+        if (f0 < total4)
+            glds16(fb + src_off[u], __builtin_amdgcn_readfirstlane(lds_f + (unsigned)buf * buf_bytes + (unsigned)f0 * 16u));
+    };
+
+    if constexpr (DMA) {
+        if (nchunk > 0) {
+            load_idx(0);
+            store_idx(0);
+            load_idx(NBK);
+            store_idx(1);
+            __syncthreads();
+            prep_rows(0);
+#pragma unroll
+            for (int u = 0; u < NSTD; ++u) issue(u, 0);
+            dma_wait();
+        }
+    } else if (nchunk > 0) {
         fetch_index(0);
         fetch(0);
         fetch_index(NBK);
@@ -176,7 +258,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     // identity): anchors map to themselves and the weight constants are per-lane registers.
     // HAS_MULT = true: the permuted anchor of every (entry, anchor) pair comes from the LDS
     // table, and so do its weight constants (read 4 at a time, one wait per group).
-    auto gather = [&](const float *fbuf, int buf, int s, float (&fa)[APW], int (&aw)[APW]) {
+    auto gather = [&](const float *fbuf, int gb, int s, float (&fa)[APW], int (&aw)[APW]) {
         const int nl = 2 * s + lh;
         const float *frow = fbuf + ((size_t)nl * CB + lk) * FP;
         if (!HAS_MULT) {   // anchors map to themselves: pairs of anchors = one aligned 8-byte read
@@ -186,7 +268,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
                 fa[ai] = v.x; fa[ai + 1] = v.y;
             }
         } else {
-            const int r = __float_as_int(s_g[buf * NBK + nl].w);
+            const int r = __float_as_int(s_g[gb * NBK + nl].w);
 #pragma unroll
             for (int ai = 0; ai < APW; ++ai) {
                 const int a = (int)s_mult[r * na + min(a_beg + ai, na - 1)];
@@ -195,41 +277,139 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             }
         }
     };
-    auto step = [&](int buf, int s, const float (&fa)[APW], const int (&aw)[APW]) {
-        const float4 g = s_g[buf * NBK + 2 * s + lh];
+    auto nothing = [] {};
+    // mid() / end() run after the first / second half of the step's MFMAs (the DMA path requests
+    // the next chunk's rows there, a few at a time, so the memory pipe never backs up into a wave)
+    auto step_g = [&](const float4 g, const float (&fa)[APW], const int (&aw)[APW], auto mid, auto end) {
         const float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
         if (!HAS_MULT) {
+            // all weights of the step first (independent chains), then the MFMAs back to back: a
+            // per-anchor guard between them would fence every weight chain behind the previous MFMA
+            float wv[APW];
 #pragma unroll
             for (int ai = 0; ai < APW; ++ai) {
                 float t = fmaf(g.x, kx[ai], kc[ai]);
                 t = fmaf(g.y, ky[ai], t);
                 t = fmaf(g.z, kz[ai], t);
-                const float wv = fmaxf(t + base, 0.0f);
-                if (ai < a_cnt)                          // wave-uniform
-                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv, acc[ai], 0, 0, 0);
+                wv[ai] = fmaxf(t + base, 0.0f);
             }
+            // no per-anchor guard: a wave with fewer than APW anchors repeats its last one into
+            // accumulators the epilogue never stores (its SIMD partner owns a full set anyway)
+#pragma unroll
+            for (int ai = 0; ai < APW / 2; ++ai)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+            mid();
+#pragma unroll
+            for (int ai = APW / 2; ai < APW; ++ai)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+            end();
         } else {
 #pragma unroll
             for (int h = 0; h < APW; h += 4) {
                 float4 k4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) k4[j] = s_rk[aw[h + j]];
+                float wv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float t = fmaf(g.x, k4[j].x, k4[j].w + kdead);
                     t = fmaf(g.y, k4[j].y, t);
                     t = fmaf(g.z, k4[j].z, t);
-                    const float wv = fmaxf(t + base, 0.0f);
-                    if (h + j < a_cnt)
-                        acc[h + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h + j], wv, acc[h + j], 0, 0, 0);
+                    wv[j] = fmaxf(t + base, 0.0f);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[h + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h + j], wv[j], acc[h + j], 0, 0, 0);
+                if (h == 0) mid(); else end();
             }
         }
+    };
+
+    auto step = [&](int gb, int s, const float (&fa)[APW], const int (&aw)[APW], auto mid, auto end) {
+        step_g(s_g[gb * NBK + 2 * s + lh], fa, aw, mid, end);
     };
 
 #ifdef EAP_INV_TRACE
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
+    if constexpr (DMA && !HAS_MULT) {
+        // No permutation: every LDS read of the chunk (operands of all four steps, offset vectors,
+        // the next chunk's query points) is issued right after the barrier -- reads queued behind
+        // an in-flight LDS DMA of the same wave wait for it -- and the next chunk's rows are then
+        // requested one at a time, after every fourth MFMA, so the memory pipe never backs up into
+        // a wave that still has matrix work (tools/microbench/glds.hip has the measurements).
+        int g0 = 0, g1 = 1, g2 = 2;                       // ring slots of chunks ch, ch+1, ch+2
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int buf = ch & 1, nb = buf ^ 1;
+            TR(0);
+            const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
+            float fa[4][APW];
+            float4 gv[4];
+            int aw[APW];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                gv[st] = s_g[g0 * NBK + 2 * st + lh];
+                gather(fbuf, g0, st, fa[st], aw);
+            }
+            prep_rows(g1);
+            load_idx((ch + 2) * NBK);
+            __builtin_amdgcn_sched_barrier(0);
+            TR(1);
+            step_g(gv[0], fa[0], aw, [&] { issue(0, nb); }, [&] { issue(1, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            step_g(gv[1], fa[1], aw, [&] { issue(2, nb); }, [&] { issue(3, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            step_g(gv[2], fa[2], aw, [&] { issue(4, nb); }, [&] { issue(5, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            step_g(gv[3], fa[3], aw, [&] { issue(6, nb); }, [&] { issue(7, nb); });
+            TR(2);
+            store_idx(g2);
+            dma_wait();
+            TR(3);
+            __syncthreads();
+            TR(4);
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
+        }
+    } else if constexpr (DMA) {
+        int g0 = 0, g1 = 1, g2 = 2;                       // ring slots of chunks ch, ch+1, ch+2
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int buf = ch & 1, nb = buf ^ 1;
+            TR(0);
+            const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
+            float fa0[APW], fa1[APW];
+            int aw0[APW], aw1[APW];
+            // operands of the first two steps before anything else, so the matrix pipe restarts
+            // right after the barrier; the next chunk's row addresses follow in their shadow.
+            // The rows themselves are requested unconditionally (past the end of the list the
+            // ring repeats the last entry: a harmless reload into the idle buffer).
+            gather(fbuf, g0, 0, fa0, aw0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_idx((ch + 2) * NBK);
+            gather(fbuf, g0, 1, fa1, aw1);
+            __builtin_amdgcn_sched_barrier(0);
+            prep_rows(g1);
+            __builtin_amdgcn_sched_barrier(0);
+            TR(1);
+            step(g0, 0, fa0, aw0, [&] { issue(0, nb); }, [&] { issue(1, nb); issue(2, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            gather(fbuf, g0, 2, fa0, aw0);
+            __builtin_amdgcn_sched_barrier(0);
+            step(g0, 1, fa1, aw1, [&] { issue(3, nb); }, [&] { issue(4, nb); issue(5, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            gather(fbuf, g0, 3, fa1, aw1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(g0, 2, fa0, aw0, [&] { issue(6, nb); }, [&] { issue(7, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            step(g0, 3, fa1, aw1, nothing, nothing);
+            TR(2);
+            store_idx(g2);
+            dma_wait();
+            TR(3);
+            __syncthreads();
+            TR(4);
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
+        }
+    } else
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
         TR(0);
@@ -245,17 +425,17 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         __builtin_amdgcn_sched_barrier(0);
         gather(fbuf, buf, 1, fa1, aw1);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 0, fa0, aw0);
+        step(buf, 0, fa0, aw0, nothing, nothing);
         __builtin_amdgcn_sched_barrier(0);
         gather(fbuf, buf, 2, fa0, aw0);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 1, fa1, aw1);
+        step(buf, 1, fa1, aw1, nothing, nothing);
         __builtin_amdgcn_sched_barrier(0);
         gather(fbuf, buf, 3, fa1, aw1);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 2, fa0, aw0);
+        step(buf, 2, fa0, aw0, nothing, nothing);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 3, fa1, aw1);
+        step(buf, 3, fa1, aw1, nothing, nothing);
         TR(2);
         if (ch + 1 < nchunk) stash(buf ^ 1);
         TR(3);
@@ -263,7 +443,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         TR(4);
     }
 #ifdef EAP_INV_TRACE
-    if (blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0 && lane == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
         for (int i = 0; i < 8; ++i) eap_inv_trace[wave * 16 + i] = tr[i];
         eap_inv_trace[wave * 16 + 8] = nchunk;
     }
@@ -317,31 +497,33 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
     if ((long long)o * p * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_inv: one cloud's gradient exceeds 2^31 elements");
     hipStream_t s = eap::S(stream);
-    const int FP_ = na <= 60 ? 60 : FPMAX;
+    // row pitch = na (direct global -> LDS rows) when that pitch spreads the 32 channel lanes of
+    // an operand read over 16 bank pairs (na = 4 mod 8, e.g. the 60 icosahedral anchors);
+    // other anchor counts take the register-staged variant with a padded pitch
+    const bool dma = (na & 7) == 4;
+    const int FP_ = dma ? na : (na <= 60 ? 60 : FPMAX);
     const size_t stage_b = sizeof(float) * 2 * NBK * CB * FP_;
     if (sizeof(float) * 8 * (size_t)ks * na > stage_b) return eap::bad_arg("so3_inter_group_inv: epilogue tile too large");
-    size_t shmem = stage_b + 16 * 2 * NBK + (multinv ? 16 * (size_t)na * ks + (size_t)na * na : 0);
+    size_t shmem = stage_b + 16 * 3 * NBK + 16 * NBK + (multinv ? 16 * (size_t)na * ks + (size_t)na * na : 0);
     if (shmem > 160 * 1024) return eap::bad_arg("so3_inter_group_inv: LDS budget exceeded");
     dim3 grid(rcap, (o + CB - 1) / CB, b);
     const float4 *g4 = reinterpret_cast<const float4 *>(ent_gx);
+    auto launch = [&](auto kern) {
+        int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
+        if (e) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
+        return 0;
+    };
     int e;
-    if (multinv) {
-        auto kern = so3_inter_group_inv_kernel<true>;
-        e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
-        if (e) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
-    } else {
-        auto kern = so3_inter_group_inv_kernel<false>;
-        e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
-        if (e) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
-    }
+    if (multinv) e = dma ? launch(so3_inter_group_inv_kernel<true, true>) : launch(so3_inter_group_inv_kernel<true, false>);
+    else e = dma ? launch(so3_inter_group_inv_kernel<false, true>) : launch(so3_inter_group_inv_kernel<false, false>);
+    if (e) return e;
 #ifdef EAP_INV_TRACE
     {
         unsigned long long h[8 * 16];
         hipDeviceSynchronize();
         hipMemcpyFromSymbol(h, HIP_SYMBOL(eap_inv_trace), sizeof(h));
-        for (int w = 0; w < 8; ++w)
+        for (int w = 0; w < 8 && h[w * 16 + 8] > 0; ++w)
             fprintf(stderr, "inv trace wave %d: chunks %llu  fetch %llu  compute %llu  stash %llu  barrier %llu  (cycles/chunk)\n", w,
                     h[w * 16 + 8], h[w * 16 + 1] / h[w * 16 + 8], h[w * 16 + 2] / h[w * 16 + 8], h[w * 16 + 3] / h[w * 16 + 8],
                     h[w * 16 + 4] / h[w * 16 + 8]);

@@ -1,0 +1,254 @@
+// tools/microbench/glds.hip -- per-CU throughput of the row-gather load patterns used by the
+// SO(3) grouping kernels: 512-thread workgroups (one per CU), 8 x 16-byte loads per thread and
+// round, either global -> LDS DMA or global -> registers, rows of `rowb` bytes taken from `nrows`
+// channel rows that are `cstride` bytes apart.  Prints bytes / clock / CU.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+__device__ inline void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int MODE>   // 0 = LDS DMA, 1 = registers (+ ds_write), 2 = registers only
+__global__ __launch_bounds__(512) void k(const char *src, int rounds, int rowb, long cstride, int nrows, int pwin,
+                                         float *sink, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int per_row = rowb / 16;
+    float4 acc = make_float4(0, 0, 0, 0);
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)smem;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        const int buf = r & 1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = u * 512 + t;                     // 16-byte piece index in the LDS image
+            const int row = f / per_row, pc = f - row * per_row;
+            const int ch = row % nrows, ent = row / nrows;   // [entry][channel][piece]
+            const long pidx = ((long)(r * 8 + ent) * 7 + blockIdx.x * 13) % pwin;
+            const char *g = src + (long)ch * cstride + pidx * rowb + pc * 16;
+            if (MODE == 0) glds16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * 61440 + (u * 512 + wave * 64) * 16));
+            else {
+                const float4 v = *reinterpret_cast<const float4 *>(g);
+                if (MODE == 1) *reinterpret_cast<float4 *>(smem + buf * 61440 + f * 16) = v;
+                else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (t == 0) cyc[blockIdx.x] = t1 - t0;
+    if (MODE != 2) acc.x = reinterpret_cast<float *>(smem)[t];
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) sink[0] = acc.x;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// MIX: bit0 = MFMAs (32 per wave and round, 8 accumulators), bit1 = LDS operand reads (b64 per MFMA),
+// bit2 = DMA loads (8 per wave and round, one after every 4th MFMA)
+template <int MIX, int ORDER, int SCHED>
+__global__ __launch_bounds__(512) void kmix(const char *src, int rounds, int pwin, float *sink, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)smem;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = (float)t, b = 1.0f;
+    float kx[8], ky[8], kz[8], kc[8];
+    for (int j = 0; j < 8; ++j) { kx[j] = src[j + t] * 1e-3f; ky[j] = src[j + 64 + t]; kz[j] = src[j + 128 + t]; kc[j] = src[j + 192 + t] + 1.f; }
+    unsigned goff[8]; int gent[8];
+    for (int u = 0; u < 8; ++u) {
+        const int f = min(u * 512 + t, 3839);
+        const int row = f / 15, pc = f - row * 15;
+        goff[u] = (unsigned)(row & 31) * 983040u + pc * 16 + ((blockIdx.x * 13) & 63) * 240;
+        gent[u] = row >> 5;
+    }
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        const int buf = r & 1;
+        const float *fbuf = reinterpret_cast<const float *>(smem + buf * 61440);
+        float2 fall[4][4];
+        if (ORDER == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fall[s][j] = *reinterpret_cast<const float2 *>(fbuf + ((2 * s + (lane >> 5)) * 32 + (lane & 31)) * 60 + wave * 8 + 2 * j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float2 fa[4];
+            if (ORDER == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[j] = fall[s][j];
+            } else if (MIX & 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fa[j] = *reinterpret_cast<const float2 *>(fbuf + ((2 * s + (lane >> 5)) * 32 + (lane & 31)) * 60 + wave * 8 + 2 * j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[j] = make_float2(a, b);
+            }
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = b;
+            if (MIX & 8) {                                  // the kernel-weight chains of one step
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = fmaf(a, kx[j], kc[j]);
+                    x = fmaf(b, ky[j], x);
+                    x = fmaf(a, kz[j], x);
+                    wv[j] = fmaxf(x + b, 0.0f);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (MIX & 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[h * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? fa[j].y : fa[j].x, wv[h * 4 + j], acc[h * 4 + j], 0, 0, 0);
+                }
+                if (MIX & 4) {
+                    const int grp = s * 2 + h;
+                    // SCHED 0: one load after every group; 1: two after each of the first four groups;
+                    // 2: all eight after the first group; 3: 2,2,2,1,1 after groups 0..4
+                    constexpr int first[4][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 2, 4, 6, 8, 8, 8, 8, 8}, {0, 8, 8, 8, 8, 8, 8, 8, 8}, {0, 2, 4, 6, 7, 8, 8, 8, 8}};
+#pragma unroll
+                    for (int u = first[SCHED][grp]; u < first[SCHED][grp + 1]; ++u)
+                        if (u * 512 + wave * 64 < 3840)
+                            glds16(src + goff[u] + (size_t)(((r * 8 + gent[u]) * 7) & (pwin - 1)) * 240,
+                                   __builtin_amdgcn_readfirstlane(lds0 + (buf ^ 1) * 61440 + (u * 512 + wave * 64) * 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (t == 0) cyc[blockIdx.x] = t1 - t0;
+    float sum = 0; for (int i = 0; i < 8; ++i) sum += acc[i][0];
+    if (sum == 12345.f) sink[0] = sum;
+}
+
+// 32 MFMAs per wave and round, operands read up front, DMA load u issued after MFMA number
+// STRIDE*u + OFF (+ SKEW for waves 4..7, which share SIMDs with waves 0..3)
+template <int STRIDE, int OFF, int SKEW>
+__global__ __launch_bounds__(512) void kflat(const char *src, int rounds, int pwin, float *sink, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)smem;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    unsigned goff[8]; int gent[8];
+    for (int u = 0; u < 8; ++u) {
+        const int f = min(u * 512 + t, 3839);
+        const int row = f / 15, pc = f - row * 15;
+        goff[u] = (unsigned)(row & 31) * 983040u + pc * 16 + ((blockIdx.x * 13) & 63) * 240;
+        gent[u] = row >> 5;
+    }
+    const bool late = wave >= 4;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        const int buf = r & 1;
+        const float *fbuf = reinterpret_cast<const float *>(smem + buf * 61440);
+        float2 fall[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fall[s][j] = *reinterpret_cast<const float2 *>(fbuf + ((2 * s + (lane >> 5)) * 32 + (lane & 31)) * 60 + wave * 8 + 2 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const int s = m >> 3, j = (m >> 1) & 3;
+            acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32((m & 1) ? fall[s][j].y : fall[s][j].x, 1.0f, acc[m & 7], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool mine = SKEW == 0 ? (m == STRIDE * u + OFF) : (late ? m == STRIDE * u + OFF + SKEW : m == STRIDE * u + OFF);
+                if ((m == STRIDE * u + OFF || m == STRIDE * u + OFF + SKEW) && mine && u * 512 + wave * 64 < 3840)
+                    glds16(src + goff[u] + (size_t)(((r * 8 + gent[u]) * 7) & (pwin - 1)) * 240,
+                           __builtin_amdgcn_readfirstlane(lds0 + (buf ^ 1) * 61440 + (u * 512 + wave * 64) * 16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (t == 0) cyc[blockIdx.x] = t1 - t0;
+    float sum = 0; for (int i = 0; i < 8; ++i) sum += acc[i][0];
+    if (sum == 12345.f) sink[0] = sum;
+}
+
+template <int STRIDE, int OFF, int SKEW>
+void run_flat(const char *src, int pwin, float *sink, unsigned long long *cyc) {
+    const int rounds = 2000, nblk = 256;
+    auto kern = kflat<STRIDE, OFF, SKEW>;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 122880, 0, src, 50, pwin, sink, cyc);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 122880, 0, src, rounds, pwin, sink, cyc);
+    hipDeviceSynchronize();
+    unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0; for (int i = 0; i < nblk; ++i) avg += h[i]; avg /= nblk;
+    printf("flat: load u after MFMA %d*u+%d (+%d for waves 4..7) window %4d: %7.1f cyc/round\n", STRIDE, OFF, SKEW, pwin, avg / rounds);
+}
+
+template <int MIX, int ORDER = 0, int SCHED = 0>
+void run_mix(const char *src, int pwin, float *sink, unsigned long long *cyc) {
+    const int rounds = 2000, nblk = 256;
+    auto kern = kmix<MIX, ORDER, SCHED>;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 122880, 0, src, 50, pwin, sink, cyc);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 122880, 0, src, rounds, pwin, sink, cyc);
+    hipDeviceSynchronize();
+    unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0; for (int i = 0; i < nblk; ++i) avg += h[i]; avg /= nblk;
+    printf("sched %d order %d mix %2d (mfma %d, lds reads %d, dma %d, valu %d) window %4d: %7.1f cyc/round\n", SCHED, ORDER, MIX, MIX & 1, (MIX >> 1) & 1, (MIX >> 2) & 1, (MIX >> 3) & 1, pwin, avg / rounds);
+}
+
+int main(int argc, char **argv) {
+    const int rounds = 2000, nblk = 256;
+    const size_t bytes = (size_t)1 << 30;
+    char *src; float *sink; unsigned long long *cyc;
+    hipMalloc(&src, bytes); hipMemset(src, 0, bytes);
+    hipMalloc(&sink, 4); hipMalloc(&cyc, 8 * nblk);
+    struct { const char *name; int rowb; long cstride; int nrows; int pwin; } cfg[] = {
+        {"240B rows, 32 ch x 983040B stride, window 4096", 240, 983040, 32, 4096},
+        {"240B rows, 32 ch x 983040B stride, window 64", 240, 983040, 32, 64},
+        {"256B rows, 32 ch x 1048576B stride, window 4096", 256, 1048576, 32, 4096},
+        {"256B rows, 32 ch x 1048832B stride, window 4096", 256, 1048832, 32, 4096},
+        {"256B rows, 32 ch x 1048832B stride, window 64", 256, 1048832, 32, 64},
+        {"1024B rows, 8 ch x 4195328B stride, window 1024", 1024, 4195328, 8, 1024},
+        {"7680B rows (whole entry contiguous), 1 ch, window 4096", 7680, 0, 1, 4096},
+    };
+    for (int pwin : {64, 4096}) {
+        run_mix<15, 1, 0>(src, pwin, sink, cyc);
+        run_flat<4, 3, 0>(src, pwin, sink, cyc); run_flat<4, 1, 2>(src, pwin, sink, cyc); run_flat<3, 1, 1>(src, pwin, sink, cyc);
+        run_flat<3, 0, 0>(src, pwin, sink, cyc); run_flat<2, 0, 1>(src, pwin, sink, cyc); run_flat<2, 0, 0>(src, pwin, sink, cyc);
+        run_flat<3, 0, 2>(src, pwin, sink, cyc);
+    }
+    if (argc > 1)
+    for (auto &c : cfg)
+        for (int mode = 0; mode < 3; ++mode) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : k<2>;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 122880);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 122880, 0, src, 50, c.rowb, c.cstride, c.nrows, c.pwin, sink, cyc);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 122880, 0, src, rounds, c.rowb, c.cstride, c.nrows, c.pwin, sink, cyc);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+            double avg = 0; for (int i = 0; i < nblk; ++i) avg += h[i]; avg /= nblk;
+            const double per_round = 8.0 * 512 * 16;
+            printf("%-58s mode %d: %7.1f cyc/round  %5.1f B/clk/CU  %6.2f TB/s  (err %d)\n", c.name, mode, avg / rounds,
+                   per_round / (avg / rounds), per_round * rounds * nblk / (ms * 1e-3) / 1e12, (int)hipGetLastError());
+        }
+    return 0;
+}
