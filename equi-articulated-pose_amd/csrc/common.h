@@ -50,4 +50,19 @@ __device__ __forceinline__ int xcd_point(int bx, int p) {
     const int q = p >> 3, r = p & 7, xcd = bx & 7, j = bx >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
+
+// csrc/so3_inter_lists.hip: the two-workgroups-per-CU grouping kernel (no anchor permutation)
+namespace eap {
+bool group_lists_supported(int na, int ks);
+int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                    const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, float *out,
+                    hipStream_t s);
+int group_lists_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
+                    const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
+                    const float *ent_gx, const float *rk, float *z, hipStream_t s);
+// csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped
+int group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                   const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,
+                   const int32_t *nonident, int skip_plain, float *out, hipStream_t s);
+}
 #endif

@@ -334,7 +334,19 @@ extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, i
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, eap::S(stream)), "so3_inter_group_fwd memset");
     // >= 16 channels: matrix-core formulation (csrc/so3_inter_mfma.hip); fewer: the VALU kernel
     // below (a 32-channel MFMA tile would be mostly padding)
-    if (c >= 16) return eap_so3_inter_group_fwd_mfma_f32(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, out, stream);
+    if (c >= 16) {
+        // no permutation (no pose, or a cloud whose relative rotations are all the identity -- the
+        // flag eap_so3_prep_f32 leaves in nonident): the two-workgroups-per-CU kernel
+        // (csrc/so3_inter_lists.hip); permuted clouds: csrc/so3_inter_mfma.hip.  With a flag array
+        // both kernels are launched and each skips the other's clouds -- no host round trip.
+        const bool lists = eap::group_lists_supported(na, ks) && (long long)c * n * na < (1ll << 31);
+        if (lists && (!mult || nonident)) {
+            int e = eap::group_lists_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, out, eap::S(stream));
+            if (e || !mult) return e;
+            return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 1, out, eap::S(stream));
+        }
+        return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, out, eap::S(stream));
+    }
     if (ks <= 24) return launch_group_fwd<6>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
     return launch_group_fwd<8>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
 }

@@ -497,6 +497,9 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
     if ((long long)o * p * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_inv: one cloud's gradient exceeds 2^31 elements");
     hipStream_t s = eap::S(stream);
+    // no anchor permutation: the two-workgroups-per-CU kernel of csrc/so3_inter_lists.hip
+    if (!multinv && eap::group_lists_supported(na, ks))
+        return eap::group_lists_inv(b, o, p, nn, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
     // row pitch = na (direct global -> LDS rows) when that pitch spreads the 32 channel lanes of
     // an operand read over 16 bank pairs (na = 4 mod 8, e.g. the 60 icosahedral anchors);
     // other anchor counts take the register-staged variant with a padded pitch

@@ -1,0 +1,365 @@
+// csrc/so3_inter_lists.hip -- SO(3) grouping over entry lists on the matrix cores, two
+// workgroups per CU.  One kernel serves both directions of the inter convolution when no anchor
+// permutation is in play (no pose, or every relative rotation of the cloud is the identity):
+//
+//   forward   X[b,c,k,p,a]  = sum_n  F[b,c,idx[b,p,n],a]  * w(p,a,k,n)      entries of row p = its neighbours
+//             (vgtk/vgtk/so3conv/functional.py:L1112-1261, einsum 'bcpna,bpakn->bckpa' at L1261)
+//   backward  Z[b,o,k,r,a]  = sum_{(p,n)->q_r} dY[b,o,p,a] * w(p,a,k,n)      entries of row r = the (p,n) pairs
+//             that reference support point q_r (inverse neighbour lists, csrc/so3_inter_inv.hip)
+//   w(p,a,k,n) = relu(1 - |g(p,n) - A_a kappa_k|^2 / sigma)
+//
+// Per (row, 32 channels, anchor group) this is a [32 x E] x [E x 24] product for every anchor,
+// mapped on v_mfma_f32_32x32x2_f32 (M = channels, N = kernel points padded to 32, K = entries):
+//   * A operand: the 16-byte pieces of the entries' feature rows go global -> LDS by DMA
+//     (global_load_lds_dwordx4), one wave-instruction after every second MFMA; no staging
+//     registers, no ds_write pass.  The LDS image of a chunk is [8 entries][32 channels][pieces];
+//     DMA cannot pad a row, so when the row length is a multiple of 8 dwords the pieces of channel
+//     row r are rotated by r (on the global-address side, for free) to keep the 32 channel lanes
+//     of an operand read on different banks.
+//   * B operand: never in memory.  Lane (k = l&31, e = l>>5) evaluates w = max(0, base_e + kc + g.k')
+//     in registers (k' = 2 A_a kappa_k / sigma, kc = -|kappa_k|^2 / sigma are per-lane constants).
+//   * The anchors of a row are split into two groups (32 + 28 at na = 60) handled by different
+//     workgroups: 4 anchors per wave = 64 accumulator VGPRs, under 128 VGPRs in total and 64 KB of
+//     LDS, so TWO workgroups share a CU.  A workgroup is alone for its chunk barrier, its DMA
+//     drain, its prologue and its epilogue (20-30 % of its life in the one-per-CU version:
+//     tools/microbench/glds.hip, profiles/r01_*); with a second one resident the matrix pipe has
+//     other MFMAs to run in those gaps.
+//   * Row end: accumulators straight to global (16-byte stores, no LDS transposition, no barrier);
+//     in the forward a workgroup streams through 8 consecutive rows without draining its pipeline.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CB = 32;        // channels per block (one MFMA M tile)
+constexpr int NBK = 8;        // entries per LDS stage (4 MFMA k-steps)
+constexpr int APW = 4;        // anchors per wave
+constexpr int NWV = 8;
+constexpr int TM = 64 * NWV;
+constexpr int NSTD = 4;       // DMA instructions per thread and chunk: NBK*CB*(pieces <= 8)/TM
+
+__device__ inline unsigned lds_addr(const void *ptr) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
+}
+// wave-wide 16-byte-per-lane global -> LDS DMA, invisible to hipcc's waitcnt bookkeeping on
+// purpose (see csrc/so3_inter_inv.hip); the kernel waits with dma_wait() before the chunk barrier
+__device__ inline void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void glds4(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LISTS = true : rows / off / cnt describe variable-length entry lists (backward);
+// LISTS = false: row r of cloud b owns entries [ (b*R + r)*nn, +nn ) (forward: its neighbours).
+template <bool LISTS>
+__global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
+    int C, int PF, int na, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, float inv_sigma,
+    const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
+    const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
+    const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- block -> (row, anchor group, channel slice, cloud); XCDs get whole (slice, cloud) pairs ----
+    const int nrun = (R + RPB - 1) / RPB;                 // runs of RPB consecutive rows (RPB = 1 with lists)
+    const int ny = gridDim.y, nsl = ny * gridDim.z, per_slice = nrun * AG;
+    int qd = blockIdx.x, sl = blockIdx.y + ny * blockIdx.z;
+    if ((nsl & 7) == 0) {
+        const unsigned lin = blockIdx.x + (unsigned)per_slice * (blockIdx.y + (unsigned)ny * blockIdx.z);
+        const unsigned j = lin >> 3;
+        sl = (int)((lin & 7u) + 8u * (j / (unsigned)per_slice));
+        qd = (int)(j % (unsigned)per_slice);
+    } else {
+        qd = xcd_point(blockIdx.x, per_slice);           // contiguous rows per XCD (whole output lines in one L2)
+    }
+    const int run = qd / AG, ag = qd - run * AG;
+    const int r_begin = run * RPB, rows_blk = min(RPB, R - r_begin);
+    const int cy = sl % ny, bi = sl / ny, c0 = cy * CB;
+    if (nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) != 0) return;   // permuted cloud: not ours
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lk = lane & 31, lh = lane >> 5;
+    const int a0 = ag * gsz, gcount = min(gsz, na - a0);      // anchors [a0, a0 + gcount) of this block
+    const int npg = gcount >> 2, pitch = gcount;               // 16-byte pieces per row, LDS row pitch (floats)
+    const bool rotate = (npg & 1) == 0;
+    const int al_beg = wave_u * APW;                           // first local anchor of this wave
+    const bool active = al_beg < gcount;                       // wave-uniform
+
+    float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][pitch]
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * pitch);   // [3][NBK] ring
+    int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] ring
+
+    // entries of the block: one list (backward), or the neighbours of rows_blk consecutive rows
+    // (forward; they are contiguous in idx / gx, and with nn a multiple of the chunk the flat chunk
+    // sequence never straddles two rows)
+    int n_ent, nchunk_row;
+    size_t e0;
+    if (LISTS) {
+        const int q = rows[(size_t)bi * R + r_begin];
+        n_ent = q >= 0 ? cnt[(size_t)bi * R + r_begin] : 0;
+        e0 = (size_t)bi * ent_stride + (q >= 0 ? off[(size_t)bi * R + r_begin] : 0);
+        nchunk_row = (n_ent + NBK - 1) / NBK;
+    } else {
+        n_ent = rows_blk * nn;
+        e0 = ((size_t)bi * R + r_begin) * nn;
+        nchunk_row = (nn + NBK - 1) / NBK;
+    }
+    const int nchunk = LISTS ? nchunk_row : rows_blk * nchunk_row;
+
+    // ---- per-lane weight constants of this wave's anchors (k = lane & 31) -------------------------
+    float kx[APW], ky[APW], kz[APW], kc[APW];
+#pragma unroll
+    for (int ai = 0; ai < APW; ++ai) {
+        const int a = a0 + min(al_beg + ai, gcount - 1);
+        const float *r3 = rk + ((size_t)a * ks + min(lk, ks - 1)) * 3;
+        const float x = r3[0], y = r3[1], z = r3[2];
+        kx[ai] = 2.f * inv_sigma * x; ky[ai] = 2.f * inv_sigma * y; kz[ai] = 2.f * inv_sigma * z;
+        kc[ai] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
+    }
+    // operand read offsets of the two anchor pairs (rotation by the channel row, see the header)
+    int roff[APW / 2];
+#pragma unroll
+    for (int j = 0; j < APW / 2; ++j) {
+        const int al = min(al_beg + 2 * j, gcount - 2);
+        const int piece = al >> 2, slot = rotate ? (piece + lk) % npg : piece;
+        roff[j] = lk * pitch + 4 * slot + (al & 3);
+    }
+
+    f32x16 acc[APW];
+#pragma unroll
+    for (int ai = 0; ai < APW; ++ai)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
+
+    // ---- DMA: thread -> NSTD fixed 16-byte pieces of a chunk's LDS image ---------------------------
+    const float *fb = F + (size_t)bi * C * PF * na;
+    const int total4 = NBK * CB * npg;                    // a multiple of 64: whole waves in or out
+    const unsigned lds_f = lds_addr(s_f);
+    const unsigned buf_bytes = (unsigned)(NBK * CB) * (unsigned)pitch * 4u;
+    unsigned dma_off[NSTD], nl_pack = 0;                  // nl_pack: the entry (0..7) of each of the thread's pieces, 3 bits each
+#pragma unroll
+    for (int u = 0; u < NSTD; ++u) {
+        const int f = min(u * TM + t, total4 - 1);
+        const int row = f / npg, slot = f - row * npg;
+        const int nl = row / CB, cl = row - nl * CB;
+        const int piece = rotate ? (slot + npg - cl % npg) % npg : slot;
+        dma_off[u] = (unsigned)min(c0 + cl, C - 1) * (unsigned)PF * (unsigned)na + (unsigned)(a0 + 4 * piece);
+        nl_pack |= (unsigned)nl << (3 * u);
+    }
+    // The ring of entry -> (feature row, offset vector) runs two chunks ahead of the MFMAs and is
+    // filled by DMA as well (8 lanes of wave 0).  Entries past the end of the list repeat the last
+    // one; they -- and the forward's shadow rows -- are given a dead offset vector (weight 0)
+    // when the weights are evaluated.
+    const unsigned lds_g = lds_addr(s_g), lds_p = lds_addr(s_p);
+    auto issue_idx = [&](int j0, int slot) {
+        if (wave_u == 0 && lane < NBK) {
+            const size_t e = e0 + min(j0 + lane, max(n_ent - 1, 0));
+            glds4(ent_p + e, __builtin_amdgcn_readfirstlane(lds_p + (unsigned)slot * NBK * 4u));
+            glds16(ent_gx + e, __builtin_amdgcn_readfirstlane(lds_g + (unsigned)slot * NBK * 16u));
+        }
+    };
+    unsigned src_off[NSTD];
+    auto prep_rows = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < NSTD; ++u) {
+            int pe = s_p[slot * NBK + ((nl_pack >> (3 * u)) & 7)];
+            if (!LISTS) pe = (unsigned)pe < (unsigned)PF ? pe : 0;     // shadow row: any valid row, weight 0
+            src_off[u] = dma_off[u] + __umul24((unsigned)pe, (unsigned)na);
+        }
+    };
+    auto issue = [&](int u, int buf) {
+        const int f0 = u * TM + wave_u * 64;              // wave-uniform
+        if (f0 < total4)
+            glds16(fb + src_off[u], __builtin_amdgcn_readfirstlane(lds_f + (unsigned)buf * buf_bytes + (unsigned)f0 * 16u));
+    };
+
+    if (nchunk > 0) {
+        issue_idx(0, 0);
+        issue_idx(NBK, 1);
+        dma_wait();
+        __syncthreads();
+        prep_rows(0);
+#pragma unroll
+        for (int u = 0; u < NSTD; ++u) issue(u, 0);
+        dma_wait();
+    }
+    __syncthreads();
+
+    // operands of one MFMA k-step (2 entries): the anchor pairs of this lane's channel row, the
+    // entry's offset vector and (forward) its support row for the shadow test
+    auto gather = [&](const float *fbuf, int gslot, int s, float (&fa)[APW], float4 &g, int &pe) {
+        const float *base = fbuf + (size_t)(2 * s + lh) * CB * pitch;
+#pragma unroll
+        for (int j = 0; j < APW / 2; ++j) {
+            const float2 v = *reinterpret_cast<const float2 *>(base + roff[j]);
+            fa[2 * j] = v.x; fa[2 * j + 1] = v.y;
+        }
+        g = s_g[gslot * NBK + 2 * s + lh];
+        if (!LISTS) pe = s_p[gslot * NBK + 2 * s + lh];
+    };
+    auto step = [&](int je, const float4 g, int pe, const float (&fa)[APW], auto mid) {
+        float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
+        if (je >= n_ent || (!LISTS && (unsigned)pe >= (unsigned)PF)) base = -1e30f;    // dead entry: weight 0
+        float wv[APW];
+#pragma unroll
+        for (int ai = 0; ai < APW; ++ai) {
+            float x = fmaf(g.x, kx[ai], kc[ai]);
+            x = fmaf(g.y, ky[ai], x);
+            x = fmaf(g.z, kz[ai], x);
+            wv[ai] = fmaxf(x + base, 0.0f);
+        }
+        // unguarded: a wave whose last anchors fall off the group repeats its last one into
+        // accumulators the epilogue never stores
+#pragma unroll
+        for (int ai = 0; ai < APW / 2; ++ai)
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+        mid();
+#pragma unroll
+        for (int ai = APW / 2; ai < APW; ++ai)
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+    };
+
+    // Row end: the accumulators go straight to global memory.  D[i = channel][j = kernel point]
+    // sits as col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); register r of this wave's four
+    // anchors is one 16-byte store into out[b, c0+i, k, row, a0 + al_beg ..].  64 partial lines per
+    // wave-instruction, completed in L2 by the other waves of the two anchor groups; no LDS
+    // transposition, no barrier, and nobody waits for the stores (they are issued right after
+    // the chunk's DMA drain, so the next drain finds them long retired).
+    // Addresses: wave-uniform 64-bit base per store + ONE 32-bit per-lane offset (the launcher
+    // bounds it), so the 16 stores cost no address registers inside the MFMA loop.
+    const size_t o_ks = (size_t)R * na, o_cs = (size_t)ks * R * na;
+    float *ob = out + (size_t)bi * C * o_cs + (size_t)c0 * o_cs + a0;
+    const unsigned lane_off = (unsigned)((size_t)(4 * lh) * o_cs + (size_t)min(lk, ks - 1) * o_ks) + (unsigned)al_beg;
+    const bool full_c = c0 + CB <= C;                       // block-uniform
+    auto store_row = [&](int row) {
+        if (active && lk < ks) {
+            float *rb = ob + (size_t)row * na;             // uniform
+            if (full_c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float4 *>(rb + (size_t)((r & 3) + 8 * (r >> 2)) * o_cs + lane_off) =
+                        make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (c0 + (r & 3) + 8 * (r >> 2) + 4 * lh < C)
+                        *reinterpret_cast<float4 *>(rb + (size_t)((r & 3) + 8 * (r >> 2)) * o_cs + lane_off) =
+                            make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            }
+        }
+#pragma unroll
+        for (int ai = 0; ai < APW; ++ai)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
+    };
+
+    int g0 = 0, g1 = 1, g2 = 2;                           // ring slots of chunks ch, ch+1, ch+2
+    int ch_row = 0, row = r_begin;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1, nb = buf ^ 1;
+        const float *fbuf = s_f + (size_t)buf * NBK * CB * pitch;
+        const int je = ch * NBK + lh;
+        // Operands run two k-steps ahead of the MFMAs; the next chunk's rows are requested one
+        // wave-instruction per step, from the middle of the step's MFMAs.  Past the end of the
+        // list the ring repeats the last entry (a harmless reload of the idle buffer).
+        if (active) {
+            float fa0[APW], fa1[APW];
+            float4 ga, gb;
+            int pa = 0, pb = 0;
+            gather(fbuf, g0, 0, fa0, ga, pa);
+            gather(fbuf, g0, 1, fa1, gb, pb);
+            prep_rows(g1);
+            issue_idx((ch + 2) * NBK, g2);
+            __builtin_amdgcn_sched_barrier(0);
+            step(je, ga, pa, fa0, [&] { issue(0, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            gather(fbuf, g0, 2, fa0, ga, pa);
+            __builtin_amdgcn_sched_barrier(0);
+            step(je + 2, gb, pb, fa1, [&] { issue(1, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            gather(fbuf, g0, 3, fa1, gb, pb);
+            __builtin_amdgcn_sched_barrier(0);
+            step(je + 4, ga, pa, fa0, [&] { issue(2, nb); });
+            __builtin_amdgcn_sched_barrier(0);
+            step(je + 6, gb, pb, fa1, [&] { issue(3, nb); });
+        } else {
+            prep_rows(g1);
+#pragma unroll
+            for (int u = 0; u < NSTD; ++u) issue(u, nb);
+        }
+        dma_wait();
+        if (++ch_row == nchunk_row) {                     // block-uniform
+            store_row(row);
+            ch_row = 0;
+            ++row;
+        }
+        __syncthreads();
+        const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
+    }
+    if (nchunk == 0) store_row(r_begin);                  // unreferenced row: zeros
+}
+
+struct Geometry { int AG, gsz; size_t shmem; };
+
+// anchor groups: one up to 32 anchors, two above (the first a multiple of 4: 32 + 28 at na = 60)
+bool geometry(int na, int ks, Geometry &g) {
+    if (na <= 0 || (na & 3) != 0 || na > 64 || ks <= 0 || ks > 32) return false;
+    g.AG = na > 32 ? 2 : 1;
+    g.gsz = g.AG == 1 ? na : ((na / 2 + 3) & ~3);
+    g.shmem = sizeof(float) * 2 * NBK * CB * g.gsz + 16 * 3 * NBK + 16 * NBK;     // the first group is the larger one
+    return g.shmem <= 80 * 1024;
+}
+
+template <bool LISTS>
+int launch(int b, int C, int PF, int na, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
+           const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
+           const float *rk, const int32_t *nonident, float *out, hipStream_t s, const char *what) {
+    Geometry g;
+    if (!geometry(na, ks, g)) return eap::bad_arg("so3_group_lists: unsupported anchor / kernel-point count");
+    if ((long long)C * PF * na >= (1ll << 31)) return eap::bad_arg("so3_group_lists: one cloud's features exceed 2^31 elements");
+    if (((long long)ks * R * na * 4 + 32ll * R * na + 64) * 4 >= (1ll << 31)) return eap::bad_arg("so3_group_lists: output rows too far apart for 32-bit store offsets");
+    auto kern = so3_group_lists_kernel<LISTS>;
+    int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.shmem), what);
+    if (e) return e;
+    // forward: a workgroup streams through a run of consecutive rows (the next row's entries and
+    // first chunk are in flight during the current row's last chunk)
+    const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
+    dim3 grid((R + RPB - 1) / RPB * g.AG, (C + CB - 1) / CB, b);
+    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, 1.0f / sigma, F,
+                       rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
+    return eap::check_launch(what);
+}
+
+}  // namespace
+
+namespace eap {
+
+bool group_lists_supported(int na, int ks) {
+    Geometry g;
+    return geometry(na, ks, g);
+}
+
+// forward over the clouds whose relative rotations are all the identity (nonident[b] == 0, or
+// nonident == nullptr for every cloud); other clouds are left untouched
+int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                    const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, float *out,
+                    hipStream_t s) {
+    return launch<false>(b, c, n, na, ks, p, nn, 0, sigma, feats, nullptr, nullptr, nullptr, idx, gx, rk, nonident, out, s,
+                         "so3_inter_group_fwd (lists)");
+}
+
+int group_lists_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
+                    const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
+                    const float *ent_gx, const float *rk, float *z, hipStream_t s) {
+    return launch<true>(b, o, p, na, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, nullptr, z, s,
+                        "so3_inter_group_inv (lists)");
+}
+
+}  // namespace eap

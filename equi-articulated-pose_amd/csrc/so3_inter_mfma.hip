@@ -40,8 +40,10 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     int c, int p, int n_sup, int nn, int na, int ks, float inv_sigma,
     const float *__restrict__ feats, const int32_t *__restrict__ idx, const float4 *__restrict__ gx,
     const float *__restrict__ rk, const uint8_t *__restrict__ mult, const int32_t *__restrict__ nonident,
-    float *__restrict__ out) {
+    int skip_plain, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // clouds without any non-identity relative rotation were served by csrc/so3_inter_lists.hip
+    if (skip_plain && __builtin_amdgcn_readfirstlane(nonident[blockIdx.z]) == 0) return;
     const int FP = na <= 60 ? 60 : FPMAX, FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
     float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP_);       // [nn_pad]
@@ -262,15 +264,14 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
 
 }  // namespace
 
-extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int nn, int na, int ks,
-                                                float sigma, const float *feats, const int32_t *idx,
-                                                const float *gx, const float *rk, const uint8_t *mult,
-                                                const int32_t *nonident, float *out, eap_stream_t stream) {
+int eap::group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                        const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,
+                        const int32_t *nonident, int skip_plain, float *out, hipStream_t s) {
     if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 32 kernel points");
     if ((long long)c * n * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_fwd_mfma: one cloud's features exceed 2^31 elements");
-    hipStream_t s = eap::S(stream);
+    if (!nonident) skip_plain = 0;
     const int FP_ = na <= 60 ? 60 : FPMAX;
     if (nn <= 0)
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, s), "so3_inter_group_fwd memset");
@@ -289,11 +290,18 @@ extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int 
                                               (int)shmem), "so3_inter_group_fwd_mfma shared memory");         \
         if (e) return e;                                                                                      \
         hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, c, p, n, nn, na, ks, inv_sigma, feats, idx, g4,    \
-                           rk, mult, nonident, out);                                                          \
+                           rk, mult, nonident, skip_plain, out);                                              \
     } while (0)
     if ((na & 3) == 0) { if (mult) EAP_MFMA_LAUNCH(8, true, true); else EAP_MFMA_LAUNCH(8, true, false); }
     else if (mult) EAP_MFMA_LAUNCH(8, false, true);
     else EAP_MFMA_LAUNCH(8, false, false);
 #undef EAP_MFMA_LAUNCH
     return eap::check_launch("so3_inter_group_fwd_mfma");
+}
+
+extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int nn, int na, int ks,
+                                                float sigma, const float *feats, const int32_t *idx,
+                                                const float *gx, const float *rk, const uint8_t *mult,
+                                                const int32_t *nonident, float *out, eap_stream_t stream) {
+    return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, out, eap::S(stream));
 }

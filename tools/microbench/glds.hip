@@ -199,6 +199,73 @@ void run_flat(const char *src, int pwin, float *sink, unsigned long long *cyc) {
     printf("flat: load u after MFMA %d*u+%d (+%d for waves 4..7) window %4d: %7.1f cyc/round\n", STRIDE, OFF, SKEW, pwin, avg / rounds);
 }
 
+// Two workgroups per CU: 4 accumulators per wave (<= 128 VGPRs), 64 KB of LDS, 16 MFMAs and 4 DMA
+// loads per wave and round (32-anchor rows: 8 pieces).  DMA: 0 = none, 1 = one after every 4th MFMA
+template <int DMA, int READS>
+__global__ __launch_bounds__(512, 4) void kocc2(const char *src, int rounds, int pwin, float *sink, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)smem;
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    unsigned goff[4]; int gent[4];
+    for (int u = 0; u < 4; ++u) {
+        const int f = u * 512 + t;
+        const int row = f >> 3, pc = f & 7;
+        goff[u] = (unsigned)(row & 31) * 983040u + ((pc + 8 - (row & 7)) & 7) * 16 + ((blockIdx.x * 13) & 63) * 240;
+        gent[u] = row >> 5;
+    }
+    int roff[2];
+    for (int j = 0; j < 2; ++j) { const int al = wave * 4 + 2 * j; roff[j] = (lane & 31) * 32 + 4 * (((al >> 2) + (lane & 31)) & 7) + (al & 3); }
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        const int buf = r & 1;
+        const float *fbuf = reinterpret_cast<const float *>(smem + buf * 32768);
+        float2 fall[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fall[s][j] = READS ? *reinterpret_cast<const float2 *>(fbuf + (2 * s + (lane >> 5)) * 1024 + roff[j]) : make_float2(1.f, 2.f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int s = m >> 2, j = (m >> 1) & 1;
+            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32((m & 1) ? fall[s][j].y : fall[s][j].x, 1.0f, acc[m & 3], 0, 0, 0);
+            if (DMA && (m & 3) == 1) {
+                const int u = m >> 2;
+                glds16(src + goff[u] + (size_t)(((r * 8 + gent[u]) * 7) & (pwin - 1)) * 240,
+                       __builtin_amdgcn_readfirstlane(lds0 + (buf ^ 1) * 32768 + (u * 512 + wave * 64) * 16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (t == 0) cyc[blockIdx.x] = t1 - t0;
+    float sum = 0; for (int i = 0; i < 4; ++i) sum += acc[i][0];
+    if (sum == 12345.f) sink[0] = sum;
+}
+
+template <int DMA, int READS>
+void run_occ2(const char *src, int pwin, int nblk, float *sink, unsigned long long *cyc) {
+    const int rounds = 2000;
+    auto kern = kocc2<DMA, READS>;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 512);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 65536 + 512, 0, src, 50, pwin, sink, cyc);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 65536 + 512, 0, src, rounds, pwin, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[512]; hipMemcpy(h, cyc, 8 * nblk, hipMemcpyDeviceToHost);
+    double avg = 0; for (int i = 0; i < nblk; ++i) avg += h[i]; avg /= nblk;
+    // per CU: nblk/256 blocks x 16 MFMAs x 8 waves / 4 SIMDs x 64 cycles
+    printf("occ2 dma %d reads %d window %4d, %d blocks: %7.1f cyc/round/block, MFMA-pipe busy %.1f%%, %.3f ms -> clock %.2f GHz\n", DMA, READS, pwin, nblk,
+           avg / rounds, 100.0 * (nblk / 256) * 2048.0 / (avg / rounds), ms, avg / (ms * 1e-3) / 1e9);
+}
+
 template <int MIX, int ORDER = 0, int SCHED = 0>
 void run_mix(const char *src, int pwin, float *sink, unsigned long long *cyc) {
     const int rounds = 2000, nblk = 256;
@@ -217,7 +284,7 @@ int main(int argc, char **argv) {
     const size_t bytes = (size_t)1 << 30;
     char *src; float *sink; unsigned long long *cyc;
     hipMalloc(&src, bytes); hipMemset(src, 0, bytes);
-    hipMalloc(&sink, 4); hipMalloc(&cyc, 8 * nblk);
+    hipMalloc(&sink, 4); hipMalloc(&cyc, 8 * 1024);
     struct { const char *name; int rowb; long cstride; int nrows; int pwin; } cfg[] = {
         {"240B rows, 32 ch x 983040B stride, window 4096", 240, 983040, 32, 4096},
         {"240B rows, 32 ch x 983040B stride, window 64", 240, 983040, 32, 64},
@@ -228,10 +295,9 @@ int main(int argc, char **argv) {
         {"7680B rows (whole entry contiguous), 1 ch, window 4096", 7680, 0, 1, 4096},
     };
     for (int pwin : {64, 4096}) {
-        run_mix<15, 1, 0>(src, pwin, sink, cyc);
-        run_flat<4, 3, 0>(src, pwin, sink, cyc); run_flat<4, 1, 2>(src, pwin, sink, cyc); run_flat<3, 1, 1>(src, pwin, sink, cyc);
-        run_flat<3, 0, 0>(src, pwin, sink, cyc); run_flat<2, 0, 1>(src, pwin, sink, cyc); run_flat<2, 0, 0>(src, pwin, sink, cyc);
-        run_flat<3, 0, 2>(src, pwin, sink, cyc);
+        run_occ2<0, 0>(src, pwin, 256, sink, cyc); run_occ2<0, 0>(src, pwin, 512, sink, cyc);
+        run_occ2<0, 1>(src, pwin, 512, sink, cyc); run_occ2<1, 0>(src, pwin, 512, sink, cyc);
+        run_occ2<1, 1>(src, pwin, 256, sink, cyc); run_occ2<1, 1>(src, pwin, 512, sink, cyc);
     }
     if (argc > 1)
     for (auto &c : cfg)
