@@ -245,13 +245,14 @@ def main():
         dom_name = max(kern, key=lambda k: kern[k]['ms'])
         dom = kern[dom_name]
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 and dom['flops'] > 0 else 0.0
-        # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes committed under
-        # profiles/ (only measured for the contraction GEMM so far; null otherwise)
+        # fabric-side bytes per launch of the dominant entry, from the rocprofv3 FETCH_SIZE /
+        # WRITE_SIZE passes committed under profiles/ (collected at the default workload only)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_b_gemm_pmc_hbm_traffic.json')
-        if dom_name == 'eap_gemm_f32' and os.path.exists(pmc) and args.points == 4096:
-            d = json.load(open(pmc))['derived']
-            traffic = (d['fwd_read_GB_corrected'] + d['fwd_write_GB']) / 2.0 * args.batch * 1e9
+        pmc = os.path.join(ROOT, 'profiles', 'r01_h_pmc_traffic.json')
+        if os.path.exists(pmc) and args.points == 4096 and args.batch == 8 and not args.fwd_only:
+            d = json.load(open(pmc))['per_launch_bytes'].get(dom_name)
+            if d:
+                traffic = d['fetch'] + d['write']
         clouds = args.batch * world * args.steps
         line = {
             'metric': 'point-clouds/sec (4096 pts, 60 anchors) ' + ('fwd' if args.fwd_only else 'fwd+bwd'),
