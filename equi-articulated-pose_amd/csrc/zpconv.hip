@@ -16,7 +16,9 @@
 //     streams its (point, k-pair) slab of idx/w into LDS with fully coalesced loads and the
 //     lanes then read their own anchor's row from LDS (row pitch odd => conflict-free).
 // HBM traffic per launch is the algorithmic minimum: idx + w read once, out written once,
-// feats served from L2/MALL.  The backward kernels keep scatter semantics (fp atomics on the
+// feats served from L2/MALL -- but every (a,k,n) tuple chases its own feature row through L2
+// (3-5 % of the HBM roofline).  The f32 forward with >= 8 channels therefore goes to
+// csrc/zpconv_rows.hip (30-34 %); this file serves f64, the backward and tiny channel counts.  The backward kernels keep scatter semantics (fp atomics on the
 // gradient of feats), lanes along `a` as well.
 #include "common.h"
 
@@ -170,7 +172,13 @@ int launch_intra(int b, int np, int na_in, int na_out, int ks, int ann, int c, c
                         const T *w, const T *src, T *dst, eap_stream_t stream) {                 \
         return launch_inter<T, BWD>(b, np, nq, na, ks, ann, c, idx, w, src, dst, eap::S(stream)); \
     }
-EAP_INTER(eap_inter_zpconv_fwd_f32, float, false)
+extern "C" int eap_inter_zpconv_fwd_f32(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx,
+                                        const float *w, const float *src, float *dst, eap_stream_t stream) {
+    // HBM-speed path when the sizes fit (csrc/zpconv_rows.hip; it checks the index pattern itself)
+    if (b > 0 && np > 0 && eap::inter_zpconv_rows_supported(np, nq, na, ks, ann, c))
+        return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, eap::S(stream));
+    return launch_inter<float, false>(b, np, nq, na, ks, ann, c, idx, w, src, dst, eap::S(stream));
+}
 EAP_INTER(eap_inter_zpconv_fwd_f64, double, false)
 EAP_INTER(eap_inter_zpconv_bwd_f32, float, true)
 EAP_INTER(eap_inter_zpconv_bwd_f64, double, true)

@@ -106,6 +106,32 @@ def test_inter_zpconv(dev, dtype, tol, shape):
     assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 10 * tol
 
 
+@pytest.mark.parametrize('case', ['shared', 'irregular', 'mixed'])
+@pytest.mark.parametrize('shape', [(2, 9, 50, 60, 24, 64, 40), (1, 5, 33, 28, 17, 32, 16), (1, 3, 20, 60, 24, 64, 130)])
+def test_inter_zpconv_row_kernel(dev, case, shape):
+    """>= 8 channels: csrc/zpconv_rows.hip.  'shared' = the index the Python
+    layer builds (one neighbour list per point broadcast over anchors and kernel points);
+    'irregular' = an arbitrary 5-D index (the workgroup falls back to the gather loop);
+    'mixed' = some points of each kind."""
+    import vgtk.cuda.zpconv as Z
+    b, p, q, a, k, ann, c = shape
+    rng = np.random.default_rng(7)
+    shared = np.broadcast_to(rng.integers(0, q, (b, p, 1, 1, ann)), (b, p, a, k, ann)).astype(np.int32)
+    random = rng.integers(0, q, (b, p, a, k, ann)).astype(np.int32)
+    if case == 'shared':
+        idx = shared.copy()
+    elif case == 'irregular':
+        idx = random
+    else:
+        idx = np.where((np.arange(p) % 2 == 0)[None, :, None, None, None], shared, random).astype(np.int32)
+        idx[0, 1, a - 1, k - 1, ann - 1] = (idx[0, 1, 0, 0, ann - 1] + 1) % q      # a single deviating entry in the last row
+    w = rng.random((b, p, a, k, ann)).astype(np.float32)
+    feats = rng.standard_normal((b, c, q, a)).astype(np.float32)
+    out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
+    ref = native.inter_zpconv_forward(idx, w, feats)
+    assert rel_err(out, ref) < 2e-6
+
+
 @pytest.mark.parametrize('dtype,tol', [(np.float32, 2e-6), (np.float64, 1e-13)])
 def test_intra_zpconv(dev, dtype, tol):
     import vgtk.cuda.zpconv as Z
