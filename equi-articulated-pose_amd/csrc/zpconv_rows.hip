@@ -31,7 +31,8 @@
 // re-read for each of its three kernel-point tiles (983 KB each at C = 64; served by L2 only when
 // the neighbour rows are hot).  Variants tried and kept under tools/experiments/: MFMA with 8/16
 // anchors per workgroup (32-byte row segments: TA-bound), 4-kernel-point tiles with two
-// workgroups per CU or with dedicated loader waves (row re-reads double: MALL-bound).
+// workgroups per CU or with dedicated loader waves (row re-reads double: MALL-bound), and
+// half-neighbour tiles with 4 loader + 8 compute waves persistent over 4 points (same speed).
 #include "common.h"
 
 namespace {
