@@ -42,7 +42,7 @@ NN, KS, NA, SLOTS = 64, 24, 60, 2
 
 
 class Backbone(nn.Module):
-    """3 x (InterSO3PoseConv -> BatchNorm2d -> leaky_relu): the `backbone` of
+    """3 x (InterSO3PoseConv -> BatchNorm2d -> leaky_relu; the last two fused): the `backbone` of
     SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L505-508 with build_model's
     hyper-parameters (L2089-2225)."""
 
@@ -54,7 +54,7 @@ class Backbone(nn.Module):
         self.norms = nn.ModuleList()
         for (c, o, r, s) in synth_clouds.backbone_layers(input_num):
             self.convs.append(sptk.InterSO3PoseConv(c, o, 1, 1, r, s, NN, kanchor=NA, permute_modes=1))
-            self.norms.append(nn.BatchNorm2d(o))
+            self.norms.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))   # = nn.BatchNorm2d + F.leaky_relu, fused (csrc/bn_act.hip)
         # stand-in for the pose head's output layer: pooled features -> per-slot, per-anchor
         # (R as 9 numbers, T as 3) hypotheses -- only so the all-gather moves real data
         self.pose_head = nn.Linear(512, SLOTS * 12)
@@ -66,7 +66,7 @@ class Backbone(nn.Module):
         x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
         for conv, norm in zip(self.convs, self.norms):
             _, _, _, x = conv(x)
-            x = zptk.SphericalPointCloudPose(x.xyz, F.leaky_relu(norm(x.feats)), x.anchors, x.pose)
+            x = zptk.SphericalPointCloudPose(x.xyz, norm(x.feats), x.anchors, x.pose)
         return x.feats
 
     def hypotheses(self, feats):
@@ -144,8 +144,8 @@ def cpu_baseline(points, slab=64):
 KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
     'eap_gemm_f32': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
     'eap_gemm_f32_reduce': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K',
-    'eap_so3_inter_group_fwd_f32': 'so3_inter_group_fwd_mfma_kernel (v_mfma_f32_32x32x2_f32)',
-    'eap_so3_inter_group_inv_f32': 'so3_inter_group_inv_kernel (v_mfma_f32_32x32x2_f32)',
+    'eap_so3_inter_group_fwd_f32': 'so3_group_lists_kernel<false> (v_mfma_f32_32x32x2_f32)',
+    'eap_so3_inter_group_inv_f32': 'so3_group_lists_kernel<true> (v_mfma_f32_32x32x2_f32)',
 }
 
 

@@ -1,0 +1,193 @@
+// csrc/bn_act.hip -- block-layer epilogue: BatchNorm2d (training statistics) + leaky_relu in one
+// pass over the [B,C,P,A] feature tensor (SPConvNets/utils/base_so3poseconv.py:L214-221:
+// `feat = self.norm(x.feats); feat = self.relu(feat)`).
+//
+//   forward : y = leaky(x * scale[c] + shift[c]),  scale = gamma * invstd,  shift = beta - mean * scale
+//   backward: g  = gy * (pre > 0 ? 1 : slope),     pre = x * scale + shift
+//             gx = gamma * invstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  xhat = (x - mean) * invstd
+//             dgamma = sum_c(g * xhat),  dbeta = sum_c(g)
+//
+// torch runs this as four kernels that each stream the 4 GB tensor (MIOpen BN forward, leaky_relu,
+// leaky_relu backward, MIOpen BN backward: 15 ms per bench step); here the forward is a statistics
+// pass + one apply pass, the backward one reduction pass + one apply pass.  All of it is
+// HBM-bound streaming: 16-byte loads and stores, one (cloud, channel) row segment per block,
+// per-block partial sums written out and reduced in a fixed order by the caller (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int TB = 256;       // threads per block
+constexpr int VPT = 8;        // float4 per thread
+constexpr int SEG = TB * VPT * 4;   // floats per block (8192)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block -> (segment, channel, cloud); row = x + (b*C + c)*n
+__device__ __forceinline__ void block_reduce2(float a, float b, float *pa, float *pb) {
+    __shared__ float sa[TB / 64], sb[TB / 64];
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < TB / 64; ++i) { ta += sa[i]; tb += sb[i]; }
+        *pa = ta; *pb = tb;
+    }
+}
+
+// partial[(c*B + b)*nseg + seg] = (sum, sumsq) of the segment, relative to a per-channel pivot
+// (the first element of the channel's first row) so that E[x^2] - E[x]^2 does not cancel
+__global__ __launch_bounds__(TB) void bn_stats_kernel(int c, long n, int nseg, const float *__restrict__ x,
+                                                     float *__restrict__ psum, float *__restrict__ psq) {
+    const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
+    const float pivot = x[(size_t)ci * n];
+    const float *row = x + ((size_t)bi * c + ci) * n;
+    float s = 0.f, q = 0.f;
+    const long base = (long)seg * SEG;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const long i = base + ((long)v * TB + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + i);
+            const float d0 = a.x - pivot, d1 = a.y - pivot, d2 = a.z - pivot, d3 = a.w - pivot;
+            s += (d0 + d1) + (d2 + d3);
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        } else {
+            for (long j = i; j < n; ++j) { const float d = row[j] - pivot; s += d; q += d * d; }
+        }
+    }
+    const size_t o = ((size_t)ci * gridDim.z + bi) * nseg + seg;
+    block_reduce2(s, q, psum + o, psq + o);
+}
+
+__global__ __launch_bounds__(TB) void bn_act_fwd_kernel(int c, long n, float slope, const float *__restrict__ x,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       float *__restrict__ y) {
+    const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
+    const float sc = scale[ci], sh = shift[ci];
+    const size_t r0 = ((size_t)bi * c + ci) * n;
+    const long base = (long)seg * SEG;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const long i = base + ((long)v * TB + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            float4 a = *reinterpret_cast<const float4 *>(x + r0 + i);
+            a.x = fmaf(a.x, sc, sh); a.y = fmaf(a.y, sc, sh); a.z = fmaf(a.z, sc, sh); a.w = fmaf(a.w, sc, sh);
+            a.x = a.x > 0.f ? a.x : a.x * slope; a.y = a.y > 0.f ? a.y : a.y * slope;
+            a.z = a.z > 0.f ? a.z : a.z * slope; a.w = a.w > 0.f ? a.w : a.w * slope;
+            *reinterpret_cast<float4 *>(y + r0 + i) = a;
+        } else {
+            for (long j = i; j < n; ++j) { const float p = fmaf(x[r0 + j], sc, sh); y[r0 + j] = p > 0.f ? p : p * slope; }
+        }
+    }
+}
+
+// partials of sum(g) and sum(g * xhat)
+__global__ __launch_bounds__(TB) void bn_act_bwd_reduce_kernel(int c, long n, int nseg, float slope,
+                                                              const float *__restrict__ gy, const float *__restrict__ x,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              float *__restrict__ pg, float *__restrict__ pgx) {
+    const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
+    const float sc = scale[ci], sh = shift[ci], mu = mean[ci], is = invstd[ci];
+    const size_t r0 = ((size_t)bi * c + ci) * n;
+    const long base = (long)seg * SEG;
+    float s = 0.f, q = 0.f;
+    auto one = [&](float g, float xv) {
+        const float pre = fmaf(xv, sc, sh);
+        const float gg = pre > 0.f ? g : g * slope;
+        s += gg;
+        q += gg * ((xv - mu) * is);
+    };
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const long i = base + ((long)v * TB + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            const float4 g = *reinterpret_cast<const float4 *>(gy + r0 + i);
+            const float4 a = *reinterpret_cast<const float4 *>(x + r0 + i);
+            one(g.x, a.x); one(g.y, a.y); one(g.z, a.z); one(g.w, a.w);
+        } else {
+            for (long j = i; j < n; ++j) one(gy[r0 + j], x[r0 + j]);
+        }
+    }
+    const size_t o = ((size_t)ci * gridDim.z + bi) * nseg + seg;
+    block_reduce2(s, q, pg + o, pgx + o);
+}
+
+// gx = k1[c] * g - k2[c] - xhat * k3[c]   with k1 = gamma*invstd, k2 = k1*mean(g), k3 = k1*mean(g*xhat)
+__global__ __launch_bounds__(TB) void bn_act_bwd_apply_kernel(int c, long n, float slope, const float *__restrict__ gy,
+                                                             const float *__restrict__ x, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ k2,
+                                                             const float *__restrict__ k3, float *__restrict__ gx) {
+    const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
+    const float sc = scale[ci], sh = shift[ci], mu = mean[ci], is = invstd[ci], c2 = k2[ci], c3 = k3[ci];
+    const size_t r0 = ((size_t)bi * c + ci) * n;
+    const long base = (long)seg * SEG;
+    auto one = [&](float g, float xv) {
+        const float pre = fmaf(xv, sc, sh);
+        const float gg = pre > 0.f ? g : g * slope;
+        return fmaf(gg, sc, -c2) - ((xv - mu) * is) * c3;      // scale = gamma * invstd = k1
+    };
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const long i = base + ((long)v * TB + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            const float4 g = *reinterpret_cast<const float4 *>(gy + r0 + i);
+            const float4 a = *reinterpret_cast<const float4 *>(x + r0 + i);
+            *reinterpret_cast<float4 *>(gx + r0 + i) = make_float4(one(g.x, a.x), one(g.y, a.y), one(g.z, a.z), one(g.w, a.w));
+        } else {
+            for (long j = i; j < n; ++j) gx[r0 + j] = one(gy[r0 + j], x[r0 + j]);
+        }
+    }
+}
+
+inline int nseg_of(long n) { return (int)((n + SEG - 1) / SEG); }
+inline bool ok_dims(int b, int c, long n) { return b > 0 && c > 0 && n > 0 && c <= 65535 && b <= 65535; }
+
+}  // namespace
+
+extern "C" int eap_bn_act_segments(int64_t n) { return nseg_of((long)n); }
+
+extern "C" int eap_bn_stats_f32(int b, int c, int64_t n, const float *x, float *psum, float *psq, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_stats: row length must be a multiple of 4; at most 65535 channels / clouds");
+    const int nseg = nseg_of(n);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, x, psum, psq);
+    return eap::check_launch("bn_stats");
+}
+
+extern "C" int eap_bn_act_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale,
+                                  const float *shift, float *y, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_fwd: row length must be a multiple of 4; at most 65535 channels / clouds");
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift, y);
+    return eap::check_launch("bn_act_fwd");
+}
+
+extern "C" int eap_bn_act_bwd_reduce_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x,
+                                         const float *scale, const float *shift, const float *mean,
+                                         const float *invstd, float *pg, float *pgx, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_bwd_reduce: row length must be a multiple of 4; at most 65535 channels / clouds");
+    const int nseg = nseg_of(n);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, slope, gy, x,
+                       scale, shift, mean, invstd, pg, pgx);
+    return eap::check_launch("bn_act_bwd_reduce");
+}
+
+extern "C" int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x,
+                                        const float *scale, const float *shift, const float *mean,
+                                        const float *invstd, const float *k2, const float *k3, float *gx,
+                                        eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_bwd_apply: row length must be a multiple of 4; at most 65535 channels / clouds");
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, gy, x,
+                       scale, shift, mean, invstd, k2, k3, gx);
+    return eap::check_launch("bn_act_bwd_apply");
+}

@@ -27,6 +27,7 @@ lib = ctypes.CDLL(LIB_PATH)
 lib.eap_last_error.restype = ctypes.c_char_p
 lib.eap_gemm_f32_reduce_workspace.restype = ctypes.c_int64
 lib.eap_so3_inter_group_bwd_workspace.restype = ctypes.c_int64
+lib.eap_bn_act_segments.restype = ctypes.c_int
 
 _I64 = ctypes.c_int64
 _F32 = ctypes.c_float
@@ -179,3 +180,38 @@ def so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, sigma, n
          _ptr(cnt), _ptr(ent_p), _ptr(ent_gx), _ptr(rk), _ptr(multinv), int(identity_anchor), _ptr(z),
          tag={'flops': 2.0 * b * o * ks * p * nn * na, 'shape': ('group_inv', b, o, p, nn, na, ks, rcap)})
     return z
+
+
+# ---- block-layer epilogue (csrc/bn_act.hip) -------------------------------------------------------
+
+def _partials(x, b, c, n):
+    nseg = int(lib.eap_bn_act_segments(_I64(n)))
+    return (torch.empty(c, b * nseg, dtype=torch.float32, device=x.device),
+            torch.empty(c, b * nseg, dtype=torch.float32, device=x.device))
+
+
+def bn_stats(x, b, c, n):
+    """-> (sum, sumsq) of x - pivot per channel, float64 [c] (pivot = x[0, c, 0])."""
+    ps, pq = _partials(x, b, c, n)
+    call('eap_bn_stats_f32', x, b, c, _I64(n), _ptr(x), _ptr(ps), _ptr(pq))
+    return ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64)
+
+
+def bn_act_fwd(x, b, c, n, scale, shift, slope):
+    y = torch.empty_like(x)
+    call('eap_bn_act_fwd_f32', x, b, c, _I64(n), _F32(slope), _ptr(x), _ptr(scale), _ptr(shift), _ptr(y))
+    return y
+
+
+def bn_act_bwd_reduce(gy, x, b, c, n, scale, shift, mean, invstd, slope):
+    pg, pgx = _partials(x, b, c, n)
+    call('eap_bn_act_bwd_reduce_f32', x, b, c, _I64(n), _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
+         _ptr(mean), _ptr(invstd), _ptr(pg), _ptr(pgx))
+    return pg.sum(1, dtype=torch.float64), pgx.sum(1, dtype=torch.float64)
+
+
+def bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, slope):
+    gx = torch.empty_like(x)
+    call('eap_bn_act_bwd_apply_f32', x, b, c, _I64(n), _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
+         _ptr(mean), _ptr(invstd), _ptr(k2), _ptr(k3), _ptr(gx))
+    return gx

@@ -227,6 +227,27 @@ int eap_chamfer_bwd_f32(int b, int n, int m, const float *xyz1, const float *xyz
                         const int32_t *idx1, const int32_t *idx2, const float *g1, const float *g2,
                         float *gxyz1, float *gxyz2, eap_stream_t stream);
 
+/* ---- block-layer epilogue: BatchNorm2d (batch statistics) + leaky_relu ------------------------- */
+/* SPConvNets/utils/base_so3poseconv.py:L214-221 (`feat = self.norm(x.feats); feat = self.relu(feat)`),
+ * SURVEY.md 8(f) row 1.  x, y, gy, gx: [b, c, n] (n = P*A, a multiple of 4), contiguous.
+ * Reductions are returned as per-block partials [c][b][eap_bn_act_segments(n)] for the caller to
+ * sum in a fixed order (deterministic). */
+int eap_bn_act_segments(int64_t n);
+/* partial sums of (x - pivot_c) and (x - pivot_c)^2, pivot_c = x[0, c, 0] */
+int eap_bn_stats_f32(int b, int c, int64_t n, const float *x, float *psum, float *psq, eap_stream_t stream);
+/* y = leaky_relu(x * scale[c] + shift[c], slope) */
+int eap_bn_act_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale,
+                       const float *shift, float *y, eap_stream_t stream);
+/* partial sums of g and g * xhat,  g = gy * (x*scale+shift > 0 ? 1 : slope),  xhat = (x - mean) * invstd */
+int eap_bn_act_bwd_reduce_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x,
+                              const float *scale, const float *shift, const float *mean,
+                              const float *invstd, float *pg, float *pgx, eap_stream_t stream);
+/* gx = scale[c] * g - k2[c] - xhat * k3[c] */
+int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x,
+                             const float *scale, const float *shift, const float *mean,
+                             const float *invstd, const float *k2, const float *k3, float *gx,
+                             eap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

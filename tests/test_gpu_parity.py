@@ -517,3 +517,37 @@ def test_full_size_ball_query_properties(dev):
         assert (idx[:, :, -1][outside[:, :, -1]] == 0).all()
         first = idx[:, :, 0]
         assert (first <= torch.arange(4096, device=dev)).all()      # index order: first hit <= self
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 5, 7, 12), (2, 64, 33, 60), (1, 3, 2051, 4)])
+@pytest.mark.parametrize('training', [True, False])
+def test_batchnorm_leaky_relu_block_epilogue(dev, vg, shape, training):
+    """csrc/bn_act.hip against torch's BatchNorm2d + leaky_relu (fp32 torch reference of the same
+    op on the same device; base_so3poseconv.py:L214-221): outputs, input / affine gradients and
+    running statistics."""
+    import vgtk.so3conv as sptk
+    torch.manual_seed(3)
+    b, c, p, a = shape
+    x = (torch.randn(b, c, p, a, device=dev) * 2.0 + 3.0)
+    g = torch.randn(b, c, p, a, device=dev)
+    ref = torch.nn.BatchNorm2d(c).to(dev)
+    fused = sptk.BatchNormLeakyReLU(c, negative_slope=0.01).to(dev)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-1, 1)
+        ref.running_mean.uniform_(2.5, 3.5); ref.running_var.uniform_(3.0, 5.0)
+    fused.load_state_dict(ref.state_dict())
+    ref.train(training); fused.train(training)
+    xr = x.clone().requires_grad_(True); xf = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(ref(xr), 0.01)
+    yf = fused(xf)
+    yr.backward(g); yf.backward(g)
+    def close(u, v, tol):
+        assert float((u - v).detach().abs().max()) <= tol * float(v.detach().abs().max() + 1e-12)
+    close(yf, yr, 2e-6)
+    close(xf.grad, xr.grad, 2e-5)
+    close(fused.weight.grad, ref.weight.grad, 2e-5)
+    close(fused.bias.grad, ref.bias.grad, 2e-5)
+    close(fused.running_mean, ref.running_mean, 1e-6)
+    close(fused.running_var, ref.running_var, 1e-5)
+    assert int(fused.num_batches_tracked) == int(ref.num_batches_tracked)
