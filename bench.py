@@ -75,6 +75,47 @@ class Backbone(nn.Module):
         return h[..., :9].reshape(feats.shape[0], SLOTS, NA, 3, 3).contiguous(), h[..., 9:].contiguous()
 
 
+class SeparableBackbone(nn.Module):
+    """The frozen stage-0 `glb_backbone`: 3 x SeparableSO3PoseConvBlock = inter conv block -> intra
+    conv block -> + relu(norm(1x1 skip conv)) (SPConvNets/utils/base_so3poseconv.py:L270-328,
+    ...pn_38_multi_stage.py:L369-374).  The reference only ever runs it forward, under no_grad
+    (trainer_unsup_arti_align.py:L594-597); `bench.py --separable` reports it separately
+    (SURVEY.md 8(d)).  The 1x1 skip conv is a plain channel matmul (torch / rocBLAS plumbing)."""
+
+    def __init__(self, input_num):
+        super().__init__()
+        import synth_clouds
+        import vgtk.so3conv as sptk
+        self.inter, self.inter_norm = nn.ModuleList(), nn.ModuleList()
+        self.intra, self.intra_norm = nn.ModuleList(), nn.ModuleList()
+        self.skip, self.skip_norm = nn.ModuleList(), nn.ModuleList()
+        for (c, o, r, s) in synth_clouds.backbone_layers(input_num):
+            self.inter.append(sptk.InterSO3PoseConv(c, o, 1, 1, r, s, NN, kanchor=NA, permute_modes=1))
+            self.inter_norm.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))
+            self.intra.append(sptk.IntraSO3Conv(o, o))
+            self.intra_norm.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))
+            self.skip.append(nn.Conv2d(c, o, 1))
+            self.skip_norm.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))
+        self.pose_head = nn.Linear(512, SLOTS * 12)
+
+    def forward(self, xyz, pose):
+        import vgtk.so3conv as sptk
+        import vgtk.spconv as zptk
+        feats = sptk.get_occupancy_features(xyz.transpose(1, 2), NA, False)
+        x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
+        for i in range(len(self.inter)):
+            skip = x.feats
+            _, _, _, y = self.inter[i](x)
+            y = zptk.SphericalPointCloud(y.xyz, self.inter_norm[i](y.feats), y.anchors)
+            y = self.intra[i](y)
+            f = self.intra_norm[i](y.feats)
+            f = f + self.skip_norm[i](self.skip[i](skip))
+            x = zptk.SphericalPointCloudPose(x.xyz, f, y.anchors, x.pose)
+        return x.feats
+
+    hypotheses = Backbone.hypotheses
+
+
 class StandInLoss(torch.autograd.Function):
     """loss = mean(feats^2) + mean(h^2), h = pose_head(mean over points of feats): what the bench
     back-propagates into the backbone (the reference's heads and losses are out of scope).  Written
@@ -181,6 +222,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='clouds per GPU per step')
     ap.add_argument('--points', type=int, default=4096)
     ap.add_argument('--fwd-only', action='store_true', help='BASELINE config 2 (forward only)')
+    ap.add_argument('--separable', action='store_true', help='the separable (inter + intra + skip) glb_backbone instead of the inter backbone; implies --fwd-only as in the reference')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -196,7 +238,9 @@ def main():
     from vgtk import _hip, sharding
 
     torch.manual_seed(2913)
-    model = Backbone(args.points).to(dev)
+    if args.separable:
+        args.fwd_only = True
+    model = (SeparableBackbone if args.separable else Backbone)(args.points).to(dev)
     conv_params = [p for p in model.parameters()]
     opt = torch.optim.Adam(conv_params, lr=1e-4)
     xyz_np, _, pose_np = synth_clouds.laptop_batch(rank * args.batch, args.batch, args.points)
@@ -259,8 +303,9 @@ def main():
             'value': clouds / dt, 'unit': 'point-clouds/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.batch} x {args.points}-pt synthetic laptop clouds per GPU, 3-block inter '
-                                   f'backbone 1->64->128->512 (NN=64,K=24,A=60), '
+            'config': {'workload': f'{args.batch} x {args.points}-pt synthetic laptop clouds per GPU, 3-block '
+                                   + ('separable (inter+intra+skip) glb_backbone' if args.separable else 'inter backbone')
+                                   + f' 1->64->128->512 (NN=64,K=24,A=60), '
                                    + ('forward' if args.fwd_only else 'forward+backward+Adam'),
                        'clouds_per_gpu': args.batch, 'points': args.points, 'anchors': NA,
                        'sharding': f'clouds x{world}, pose all-gather + 1 gradient all-reduce' if world > 1 else 'single GPU'},
