@@ -551,3 +551,50 @@ def test_batchnorm_leaky_relu_block_epilogue(dev, vg, shape, training):
     close(fused.running_mean, ref.running_mean, 1e-6)
     close(fused.running_var, ref.running_var, 1e-5)
     assert int(fused.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [
+    # b, c, p, n_sup, nn, na, ks
+    (2, 40, 37, 50, 20, 12, 24),      # one anchor group of 12, channel tail, nn not a multiple of the chunk
+    (1, 33, 19, 19, 64, 28, 17),      # 28 anchors: one group, odd piece count, 17 kernel points
+    (1, 64, 21, 30, 8, 64, 32),       # 64 anchors: two groups of 32, rotated LDS image, 32 kernel points
+    (2, 17, 70, 70, 24, 60, 24),      # 60 anchors: groups 32 + 28; 3 chunks per row, rows streamed 8 at a time
+    (1, 96, 9, 40, 16, 60, 24),       # fewer rows than a run
+])
+def test_entry_list_grouping_kernel_shapes(dev, vg, shape):
+    """csrc/so3_inter_lists.hip (forward dispatcher for >= 16 channels, and the backward's Z) against
+    the VALU kernel / a dense torch evaluation with materialised weights, on anchor counts, kernel
+    sizes and list lengths the golden layers do not cover; shadow rows (idx == n_sup) included."""
+    from vgtk import _hip
+    b, c, p, n, nn, na, ks = shape
+    torch.manual_seed(5)
+    feats = torch.randn(b, c, n, na, device=dev)
+    idx = torch.randint(0, n + 1, (b, p, nn), device=dev, dtype=torch.int32)      # n = shadow row
+    gx = torch.zeros(b, p, nn, 4, device=dev)
+    gx[..., :3] = torch.randn(b, p, nn, 3, device=dev) * 0.05
+    rk = torch.randn(na, ks, 3, device=dev) * 0.05
+    sigma = 0.01
+    got = _hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma)
+    ref = torch.empty_like(got)
+    _hip.call('eap_so3_inter_group_fwd_valu_f32', ref, b, c, p, n, nn, na, ks, _hip._F32(sigma), _hip._ptr(feats),
+              _hip._ptr(idx), _hip._ptr(gx), _hip._ptr(rk), _hip._ptr(None), _hip._ptr(ref))
+    assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+
+    # backward: Z over inverse lists vs dense scatter of dY * w
+    import vgtk.so3conv.functional as L
+    o = c
+    gy = torch.randn(b, o, p, na, device=dev)
+    idx_v = idx.clamp(max=n - 1)                                                   # lists never hold shadow rows
+    rows, off, cnt, ent_p, ent_gx, rcap, all_ident = L._inverse_lists(idx_v, gx, n, 0, None)
+    z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, None, sigma, nn)
+    w = _hip.so3_inter_weights(gx, rk, sigma)                                      # [b,p,na,ks,nn]
+    dense = torch.zeros(b, o, ks, n, na, device=dev, dtype=torch.float64)
+    contrib = torch.einsum('bopa,bpakn->bokpna', gy.double(), w.double())          # [b,o,ks,p,nn,na]
+    flat_q = idx_v.long().reshape(b, 1, 1, p * nn, 1).expand(b, o, ks, p * nn, na)
+    dense.scatter_add_(3, flat_q, contrib.reshape(b, o, ks, p * nn, na))
+    for bi in range(b):
+        for ri in range(rcap):
+            q = int(rows[bi, ri])
+            want = dense[bi, :, :, q] if q >= 0 else torch.zeros_like(dense[bi, :, :, 0])
+            assert rel_err(z[bi, :, :, ri].double().cpu().numpy(), want.cpu().numpy() + 0.0) < 1e-5 or float(want.abs().max()) == 0.0
