@@ -241,6 +241,9 @@ def main():
     if args.separable:
         args.fwd_only = True
     model = (SeparableBackbone if args.separable else Backbone)(args.points).to(dev)
+    for m in model.modules():           # the reference converts its BatchNorms to SyncBatchNorm for multi-GPU runs
+        if hasattr(m, 'sync') and hasattr(m, 'negative_slope'):
+            m.sync = world > 1
     conv_params = [p for p in model.parameters()]
     opt = torch.optim.Adam(conv_params, lr=1e-4)
     xyz_np, _, pose_np = synth_clouds.laptop_batch(rank * args.batch, args.batch, args.points)

@@ -10,15 +10,53 @@ entries load into it; its forward equals `F.leaky_relu(bn(x), negative_slope)`.
 The arithmetic runs in csrc/bn_act.hip (no CPU / eager fallback).
 """
 import torch
+import torch.distributed as dist
 from torch import nn
 
-from .. import _hip
+
+def _syncing(sync):
+    return bool(sync) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def batch_moments(s1, s2, pivot, count, sync=False):
+    """Per-channel mean and biased variance from pivoted sums  s1 = sum(x - pivot), s2 = sum((x - pivot)^2)
+    over `count` elements (float64 tensors [C]).  With `sync` (the reference wraps its models in
+    nn.SyncBatchNorm for multi-GPU training, trainer_unsup_arti_align.py:L430) the raw moments of
+    all ranks are summed by ONE all-reduce of 2C+1 doubles, so every rank normalises with the
+    statistics of the whole batch.  Returns (mean, var, total_count)."""
+    if not _syncing(sync):
+        m = s1 / count
+        return pivot + m, (s2 / count - m * m).clamp_(min=0.0), count
+    raw = torch.cat([s1 + count * pivot, s2 + 2.0 * pivot * s1 + count * pivot * pivot,
+                     torch.full((1,), float(count), dtype=torch.float64, device=s1.device)])
+    dist.all_reduce(raw)
+    c = s1.numel()
+    total = raw[2 * c]
+    mean = raw[:c] / total
+    var = (raw[c:2 * c] / total - mean * mean).clamp_(min=0.0)
+    return mean, var, total
+
+
+def all_reduce_sums(*tensors, sync=False):
+    """Sum float64 per-channel reductions over the ranks (one all-reduce); identity without sync."""
+    if not _syncing(sync):
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat)
+    out, o = [], 0
+    for t in tensors:
+        out.append(flat[o:o + t.numel()].view_as(t))
+        o += t.numel()
+    return tuple(out)
+
+
+from .. import _hip  # noqa: E402  (after the pure-torch helpers: they are unit-tested without the HIP library)
 
 
 class _BNAct(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, sync):
         x = x.contiguous()
         b, c = x.shape[0], x.shape[1]
         n = x.numel() // (b * c)
@@ -26,13 +64,11 @@ class _BNAct(torch.autograd.Function):
         if training:
             pivot = x.reshape(b, c, n)[0, :, 0].double()
             s1, s2 = _hip.bn_stats(x, b, c, n)
-            m = s1 / count
-            mean = pivot + m
-            var = (s2 / count - m * m).clamp_(min=0.0)                     # biased, as BatchNorm normalises with
+            mean, var, count = batch_moments(s1, s2, pivot, count, sync)    # biased variance, as BatchNorm normalises with
             if running_mean is not None:
                 with torch.no_grad():
                     running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                    running_var.mul_(1.0 - momentum).add_((var * (count / max(count - 1, 1))).to(running_var.dtype), alpha=momentum)
+                    running_var.mul_(1.0 - momentum).add_((var * (count / (count - 1))).to(running_var.dtype), alpha=momentum)
         else:
             mean, var = running_mean.double(), running_var.double()
         invstd = torch.rsqrt(var + eps)
@@ -41,7 +77,7 @@ class _BNAct(torch.autograd.Function):
         shift = (bias.double() - mean * scale64).float()
         y = _hip.bn_act_fwd(x, b, c, n, scale, shift, slope)
         ctx.save_for_backward(x, scale, shift, mean.float(), invstd.float())
-        ctx.training, ctx.slope, ctx.dims = training, slope, (b, c, n)
+        ctx.training, ctx.slope, ctx.dims, ctx.sync, ctx.count = training, slope, (b, c, n), sync, count
         return y
 
     @staticmethod
@@ -53,22 +89,24 @@ class _BNAct(torch.autograd.Function):
         g_x = None
         if ctx.needs_input_grad[0]:
             if ctx.training:
-                k2 = (scale.double() * sg / (b * n)).float()
-                k3 = (scale.double() * sgx / (b * n)).float()
+                tg, tgx = all_reduce_sums(sg, sgx, sync=ctx.sync)          # whole-batch means (SyncBatchNorm backward)
+                k2 = (scale.double() * tg / ctx.count).float()
+                k3 = (scale.double() * tgx / ctx.count).float()
             else:
                 k2 = torch.zeros_like(scale)
                 k3 = torch.zeros_like(scale)
             g_x = _hip.bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, ctx.slope)
-        return g_x, sgx.float(), sg.float(), None, None, None, None, None, None
+        return g_x, sgx.float(), sg.float(), None, None, None, None, None, None, None
 
 
 class BatchNormLeakyReLU(nn.BatchNorm2d):
     """nn.BatchNorm2d followed by leaky_relu, fused.  Input [B, C, P, A] (any trailing shape whose
     product is a multiple of 4)."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1, negative_slope=0.01):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, negative_slope=0.01, sync=False):
         super().__init__(num_features, eps=eps, momentum=momentum, affine=True, track_running_stats=True)
         self.negative_slope = negative_slope
+        self.sync = sync          # batch statistics over all ranks (what nn.SyncBatchNorm does for the reference)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -76,4 +114,4 @@ class BatchNormLeakyReLU(nn.BatchNorm2d):
         if self.training:
             self.num_batches_tracked.add_(1)
         return _BNAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                            self.momentum, self.eps, self.negative_slope)
+                            self.momentum, self.eps, self.negative_slope, self.sync)

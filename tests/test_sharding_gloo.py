@@ -70,3 +70,36 @@ def test_single_process_is_identity():
     assert a is R and b is Tt
     assert sharding.shard_range(10) == (0, 10)
     assert sharding.shard_range(10, rank=1, world=4) == (3, 6)
+
+
+def _bn_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, os.path.join(root, 'equi-articulated-pose_amd'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vgtk.so3conv.blocks import batch_moments, all_reduce_sums
+    gen = torch.Generator().manual_seed(7)
+    x = (torch.randn(5, 6, 40, generator=gen, dtype=torch.float64) * 3 + 100.0)   # global batch [B, C, N], large mean
+    mine = x[:3] if rank == 0 else x[3:]                                            # uneven shards
+    pivot = mine[0, :, 0]
+    d = mine - pivot[None, :, None]
+    mean, var, total = batch_moments(d.sum((0, 2)), (d * d).sum((0, 2)), pivot, mine.shape[0] * mine.shape[2], sync=True)
+    g = torch.arange(6, dtype=torch.float64) * (rank + 1)
+    sg, = all_reduce_sums(g, sync=True)
+    np.savez(os.path.join(out_dir, f'bn{rank}.npz'), mean=mean.numpy(), var=var.numpy(), total=float(total), sg=sg.numpy(),
+             ref_mean=x.mean((0, 2)).numpy(), ref_var=x.var((0, 2), unbiased=False).numpy())
+    dist.destroy_process_group()
+
+
+def test_batchnorm_statistics_exchange_world_size_2(tmp_path):
+    """The block epilogue's SyncBatchNorm-style exchange (vgtk/so3conv/blocks.py): every rank ends
+    with the statistics of the whole batch from one all-reduce of raw moments."""
+    world = 2
+    mp.spawn(_bn_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for i in range(world):
+        r = dict(np.load(tmp_path / f'bn{i}.npz'))
+        np.testing.assert_allclose(r['mean'], r['ref_mean'], rtol=1e-13)
+        np.testing.assert_allclose(r['var'], r['ref_var'], rtol=1e-9)
+        assert r['total'] == 5 * 40
+        np.testing.assert_allclose(r['sg'], np.arange(6) * 3.0)
