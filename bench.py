@@ -93,7 +93,7 @@ class SeparableBackbone(nn.Module):
             self.inter.append(sptk.InterSO3PoseConv(c, o, 1, 1, r, s, NN, kanchor=NA, permute_modes=1))
             self.inter_norm.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))
             self.intra.append(sptk.IntraSO3Conv(o, o))
-            self.intra_norm.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))
+            self.intra_norm.append(sptk.InstanceNormLeakyReLU(o, negative_slope=0.01))   # base_so3poseconv.py:L88
             self.skip.append(nn.Conv2d(c, o, 1))
             self.skip_norm.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))
         self.pose_head = nn.Linear(512, SLOTS * 12)

@@ -1,4 +1,4 @@
 from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose  # noqa: F401
 from .functional import *  # noqa: F401,F403
 from .modules import *  # noqa: F401,F403
-from .blocks import BatchNormLeakyReLU  # noqa: F401
+from .blocks import BatchNormLeakyReLU, InstanceNormLeakyReLU  # noqa: F401

@@ -115,3 +115,22 @@ class BatchNormLeakyReLU(nn.BatchNorm2d):
             self.num_batches_tracked.add_(1)
         return _BNAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                             self.momentum, self.eps, self.negative_slope, self.sync)
+
+
+class InstanceNormLeakyReLU(nn.Module):
+    """nn.InstanceNorm2d(affine=False) followed by leaky_relu, fused: the norm of the intra blocks
+    (`self.norm = nn.InstanceNorm2d(dim_out, affine=False)`, base_so3poseconv.py:L88).  Instance
+    statistics are batch statistics of a [1, B*C, P, A] view, so the same kernels serve it."""
+
+    def __init__(self, num_features, eps=1e-5, negative_slope=0.01):
+        super().__init__()
+        self.num_features, self.eps, self.negative_slope = num_features, eps, negative_slope
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('InstanceNormLeakyReLU: tensor must be a CUDA(HIP) tensor (no CPU fallback)')
+        b, c = x.shape[0], x.shape[1]
+        ones = torch.ones(b * c, dtype=torch.float32, device=x.device)
+        y = _BNAct.apply(x.contiguous().view(1, b * c, *x.shape[2:]), ones, torch.zeros_like(ones), None, None, True,
+                         0.0, self.eps, self.negative_slope, False)
+        return y.view_as(x)

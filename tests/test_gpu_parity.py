@@ -598,3 +598,19 @@ def test_entry_list_grouping_kernel_shapes(dev, vg, shape):
             q = int(rows[bi, ri])
             want = dense[bi, :, :, q] if q >= 0 else torch.zeros_like(dense[bi, :, :, 0])
             assert rel_err(z[bi, :, :, ri].double().cpu().numpy(), want.cpu().numpy() + 0.0) < 1e-5 or float(want.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_instancenorm_leaky_relu_block_epilogue(dev, vg):
+    """The intra blocks' InstanceNorm2d(affine=False) + leaky_relu (base_so3poseconv.py:L88) through
+    the same kernels, against torch."""
+    import vgtk.so3conv as sptk
+    torch.manual_seed(4)
+    x = torch.randn(3, 7, 21, 60, device=dev) * 1.5 - 2.0
+    g = torch.randn_like(x)
+    xr = x.clone().requires_grad_(True); xf = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(torch.nn.InstanceNorm2d(7, affine=False)(xr), 0.01)
+    yf = sptk.InstanceNormLeakyReLU(7)(xf)
+    yr.backward(g); yf.backward(g)
+    assert float((yf - yr).detach().abs().max()) <= 2e-6 * float(yr.detach().abs().max())
+    assert float((xf.grad - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
