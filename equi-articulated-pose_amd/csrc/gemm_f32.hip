@@ -38,6 +38,9 @@ struct GemmArgs {
     int splits;      // k-splits per batch item (1 for the plain GEMM)
     int kchunk;      // K elements per split (multiple of BK)
     int tiles_m, tiles_n;
+    // implicit intra conv (GATHER kernels): B row k = (channel c = k / gnt, tap t = k % gnt), column
+    // n = (point p = n / gna, anchor a = n % gna)  ->  B[c*ldb + p*gna + gidx[a*gnt + t]]
+    const int32_t *gidx; int gna, gnt;
 };
 
 // Load 4 consecutive elements along the contiguous dimension `x` of a row-major [rows][cols]
@@ -61,10 +64,11 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ base, long lon
 }
 
 // NWM x NWN waves per block, every wave owns a WTM x 64 tile (WTM = 64, or 32 for the small-M variant)
-template <int NWM, int NWN, int WTM, bool TA, bool TB, bool VEC>
+template <int NWM, int NWN, int WTM, bool TA, bool TB, bool VEC, bool GATHER = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WTM * NWM, BN = 64 * NWN, NT = 64 * NWM * NWN;
     __shared__ Smem<BM, BN> sm;
+    __shared__ int s_gi[GATHER ? 64 * 16 : 1];              // the [anchor][tap] index table of the implicit intra conv
     constexpr int MT = WTM / 32;          // 32x32 MFMA tiles per wave along M
     constexpr int A_V4 = BM * BK / 4 / NT;  // float4 loads per thread for the A tile
     constexpr int B_V4 = BN * BK / 4 / NT;
@@ -97,6 +101,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g)
 
     float4 ra[A_V4], rb[B_V4];
 
+    // implicit intra conv: this thread's 4 B columns are 4 consecutive anchors of one point
+    int g_pcol = 0, g_a0 = 0;
+    if (GATHER) {
+        for (int i = t; i < g.gna * g.gnt; i += NT) s_gi[i] = g.gidx[i];
+        const int n = n0 + (t % (BN / 4)) * 4;
+        g_pcol = n / g.gna * g.gna;
+        g_a0 = n - g_pcol;
+        __syncthreads();
+    }
+
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < A_V4; ++u) {
@@ -110,7 +124,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g)
         }
 #pragma unroll
         for (int u = 0; u < B_V4; ++u) {
-            if (!TB) {   // B [K,N]: n contiguous
+            if (GATHER) {   // rows (channel, tap) of the never-materialised [C*T, P*A] operand
+                const int k = k0 + (t / (BN / 4)) + u * (NT / (BN / 4)), n = g_pcol + g_a0;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend && n < g.N) {                  // N = P*A is a multiple of 4: all four columns valid
+                    const int ci = k / g.gnt, tt = k - ci * g.gnt;
+                    const float *row = B + (long long)ci * g.ldb + g_pcol;
+                    v.x = row[s_gi[(g_a0 + 0) * g.gnt + tt]]; v.y = row[s_gi[(g_a0 + 1) * g.gnt + tt]];
+                    v.z = row[s_gi[(g_a0 + 2) * g.gnt + tt]]; v.w = row[s_gi[(g_a0 + 3) * g.gnt + tt]];
+                }
+                rb[u] = v;
+            } else if (!TB) {   // B [K,N]: n contiguous
                 const int k = (t / (BN / 4)) + u * (NT / (BN / 4)), jq = (t % (BN / 4)) * 4;
                 rb[u] = load4<VEC>(B, g.ldb, k0 + k, n0 + jq, kend, g.N);
             } else {     // B stored [N,K]: k contiguous
@@ -218,7 +242,10 @@ int launch(bool ta, bool tb, const GemmArgs &g, int zcount, hipStream_t s) {
         if (vec) hipLaunchKernelGGL((gemm_f32_kernel<NWM, NWN, WTM, TA, TB, true>), grid, block, 0, s, g);   \
         else hipLaunchKernelGGL((gemm_f32_kernel<NWM, NWN, WTM, TA, TB, false>), grid, block, 0, s, g);      \
     } while (0)
-    if (!ta && !tb) EAP_GEMM_LAUNCH(false, false);
+    if (g.gidx) {   // implicit intra conv: A = W [M,K] row-major, B gathered
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<NWM, NWN, WTM, false, false, true, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<NWM, NWN, WTM, false, false, false, true>), grid, block, 0, s, g);
+    } else if (!ta && !tb) EAP_GEMM_LAUNCH(false, false);
     else if (ta && !tb) EAP_GEMM_LAUNCH(true, false);
     else if (!ta && tb) EAP_GEMM_LAUNCH(false, true);
     else EAP_GEMM_LAUNCH(true, true);
@@ -265,9 +292,22 @@ extern "C" int eap_gemm_f32(int transA, int transB, int M, int N, int K, const f
                             int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
                             int64_t ldc, int64_t strideC, int batch, eap_stream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, 1, (K + BK - 1) / BK * BK, 0, 0};
+    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, 1, (K + BK - 1) / BK * BK, 0, 0, nullptr, 0, 0};
     if (g.kchunk == 0) g.kchunk = BK;
     return run(transA != 0, transB != 0, g, batch, eap::S(stream));
+}
+
+// Intra SO(3) conv as an implicit GEMM: out[b,o,p,a] = sum_{c,t} W[o, c*T + t] * feats[b, c, p, intra_idx[a,t]]
+// (so3conv/functional.py:L2553-2602 + modules.py:L48-55) without the [B,C,T,P,A] gathered tensor.
+extern "C" int eap_so3_intra_conv_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
+                                      const int32_t *intra_idx, float *out, eap_stream_t stream) {
+    if (b <= 0 || o <= 0 || p <= 0 || na <= 0) return 0;
+    if (na > 64 || nt > 16 || (na & 3) != 0) return eap::bad_arg("so3_intra_conv: at most 64 anchors (a multiple of 4) and 16 taps");
+    const int K = c * nt, N = p * na;
+    GemmArgs g{o, N, K, W, K, 0, feats, (long long)N, (long long)c * N, out, (long long)N, (long long)o * N, 1,
+               (K + BK - 1) / BK * BK, 0, 0, intra_idx, na, nt};
+    if (g.kchunk == 0) g.kchunk = BK;
+    return run(false, false, g, b, eap::S(stream));
 }
 
 extern "C" int64_t eap_gemm_f32_reduce_workspace(int M, int N, int K, int batch) {
@@ -289,7 +329,7 @@ extern "C" int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, 
     }
     const int splits = pick_splits(M, N, K, batch);
     int kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, workspace, N, (long long)M * N, splits, kchunk, 0, 0};
+    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, workspace, N, (long long)M * N, splits, kchunk, 0, 0, nullptr, 0, 0};
     int e = run(transA != 0, transB != 0, g, batch * splits, s);
     if (e) return e;
     const long long mn = (long long)M * N;

@@ -215,3 +215,13 @@ def bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, slope):
     call('eap_bn_act_bwd_apply_f32', x, b, c, _I64(n), _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
          _ptr(mean), _ptr(invstd), _ptr(k2), _ptr(k3), _ptr(gx))
     return gx
+
+
+def so3_intra_conv(feats, W, intra_idx32):
+    """Implicit-GEMM intra conv forward: feats [b,c,p,na], W [o, c*nt], intra_idx int32 [na,nt] -> [b,o,p,na]."""
+    b, c, p, na = feats.shape
+    o, nt = W.shape[0], intra_idx32.shape[1]
+    out = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
+    call('eap_so3_intra_conv_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats), _ptr(intra_idx32), _ptr(out),
+         tag={'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)})
+    return out

@@ -3,6 +3,7 @@ vgtk/vgtk/so3conv/modules.py).  Parameter / buffer names and shapes match the re
 (`basic_conv.W` [O, C*K], `anchors`, `kernels`, `intra_idx`) so its checkpoints load."""
 import numpy as np
 import torch
+from .. import _hip
 import torch.nn as nn
 
 from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose
@@ -128,8 +129,15 @@ class IntraSO3Conv(nn.Module):
         self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
 
     def forward(self, x):
-        feats = L.intra_so3conv_grouping(self.intra_idx, x.feats)
-        feats = self.basic_conv(feats)
+        W = self.basic_conv.W
+        if x.feats.is_cuda and x.feats.dtype == torch.float32 and x.feats.shape[3] % 4 == 0 and \
+                not (torch.is_grad_enabled() and (x.feats.requires_grad or W.requires_grad)):
+            # no gradient wanted (the frozen glb_backbone, inference): the 12-tap gather is folded into
+            # the contraction's operand load instead of materialising [B,C,12,P,A] (eap_so3_intra_conv_f32)
+            feats = _hip.so3_intra_conv(x.feats.contiguous(), W.contiguous(), self.intra_idx.to(torch.int32).contiguous())
+        else:
+            feats = L.intra_so3conv_grouping(self.intra_idx, x.feats)
+            feats = self.basic_conv(feats)
         return SphericalPointCloud(x.xyz, feats, self.anchors)
 
 

@@ -215,6 +215,13 @@ int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, const float
                         int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
                         int64_t ldc, int batch, float *workspace, eap_stream_t stream);
 
+/* Intra SO(3) conv, forward, as an implicit GEMM (no [b,c,t,p,na] gathered tensor):
+ * out[b,o,p,a] = sum_{c,t} W[o, c*nt + t] * feats[b, c, p, intra_idx[a*nt + t]]
+ * (so3conv/functional.py:L2553-2602 intra_so3conv_grouping + so3conv/modules.py:L48-55 BasicSO3Conv).
+ * W [o, c*nt], feats [b,c,p,na], intra_idx int32 [na,nt] (na a multiple of 4, <= 64; nt <= 16), out [b,o,p,na]. */
+int eap_so3_intra_conv_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
+                           const int32_t *intra_idx, float *out, eap_stream_t stream);
+
 /* ---- chamfer distance (extensions/chamfer_dist) ------------------------------------------- */
 
 /* chamfer.forward: chamfer_cuda.cpp:L22-25, chamfer.cu:L15-171.

@@ -614,3 +614,21 @@ def test_instancenorm_leaky_relu_block_epilogue(dev, vg):
     yr.backward(g); yf.backward(g)
     assert float((yf - yr).detach().abs().max()) <= 2e-6 * float(yr.detach().abs().max())
     assert float((xf.grad - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 24, 40, 37), (1, 130, 8, 300), (1, 64, 512, 64)])
+def test_intra_conv_implicit_gemm(dev, vg, shape):
+    """eap_so3_intra_conv_f32 (gather folded into the GEMM operand load) against the materialised
+    intra_so3conv_grouping + BasicSO3Conv path (so3conv/functional.py:L2553-2602, modules.py:L48-55)."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    b, c, o, p = shape
+    torch.manual_seed(11)
+    conv = sptk.IntraSO3Conv(c, o).to(dev)
+    feats = torch.randn(b, c, p, 60, device=dev)
+    x = zptk.SphericalPointCloud(torch.zeros(b, 3, p, device=dev), feats, conv.anchors)
+    with torch.no_grad():
+        fast = conv(x).feats                                   # implicit path
+    slow = conv(zptk.SphericalPointCloud(x.xyz, feats.clone().requires_grad_(True), conv.anchors)).feats   # materialised path
+    assert rel_err(fast.cpu().numpy(), slow.detach().cpu().numpy()) < 1e-5
