@@ -204,7 +204,8 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         g = s_g[gslot * NBK + 2 * s + lh];
         if (!LISTS) pe = s_p[gslot * NBK + 2 * s + lh];
     };
-    auto step = [&](int je, const float4 g, int pe, const float (&fa)[APW], auto mid) {
+    auto nothing = [] {};
+    auto step = [&](int je, const float4 g, int pe, const float (&fa)[APW], auto mid, auto end) {
         float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
         if (je >= n_ent || (!LISTS && (unsigned)pe >= (unsigned)PF)) base = -1e30f;    // dead entry: weight 0
         float wv[APW];
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
 #pragma unroll
         for (int ai = APW / 2; ai < APW; ++ai)
             acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+        end();
     };
 
     // Row end: the accumulators go straight to global memory.  D[i = channel][j = kernel point]
@@ -278,17 +280,17 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
             prep_rows(g1);
             issue_idx((ch + 2) * NBK, g2);
             __builtin_amdgcn_sched_barrier(0);
-            step(je, ga, pa, fa0, [&] { issue(0, nb); });
+            step(je, ga, pa, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); });
             __builtin_amdgcn_sched_barrier(0);
             gather(fbuf, g0, 2, fa0, ga, pa);
             __builtin_amdgcn_sched_barrier(0);
-            step(je + 2, gb, pb, fa1, [&] { issue(1, nb); });
+            step(je + 2, gb, pb, fa1, [&] { issue(2, nb); }, [&] { issue(3, nb); });
             __builtin_amdgcn_sched_barrier(0);
             gather(fbuf, g0, 3, fa1, gb, pb);
             __builtin_amdgcn_sched_barrier(0);
-            step(je + 4, ga, pa, fa0, [&] { issue(2, nb); });
+            step(je + 4, ga, pa, fa0, nothing, nothing);
             __builtin_amdgcn_sched_barrier(0);
-            step(je + 6, gb, pb, fa1, [&] { issue(3, nb); });
+            step(je + 6, gb, pb, fa1, nothing, nothing);
         } else {
             prep_rows(g1);
 #pragma unroll
