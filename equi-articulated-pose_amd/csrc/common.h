@@ -55,7 +55,7 @@ __device__ __forceinline__ int xcd_point(int bx, int p) {
 namespace eap {
 bool group_lists_supported(int na, int ks);
 int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
-                    const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, float *out,
+                    const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int blocked, float *out,
                     hipStream_t s);
 int group_lists_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
@@ -67,6 +67,6 @@ int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, 
 // csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped
 int group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                    const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,
-                   const int32_t *nonident, int skip_plain, float *out, hipStream_t s);
+                   const int32_t *nonident, int skip_plain, int blocked, float *out, hipStream_t s);
 }
 #endif

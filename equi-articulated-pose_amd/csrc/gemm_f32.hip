@@ -41,6 +41,10 @@ struct GemmArgs {
     // implicit intra conv (GATHER kernels): B row k = (channel c = k / gnt, tap t = k % gnt), column
     // n = (point p = n / gna, anchor a = n % gna)  ->  B[c*ldb + p*gna + gidx[a*gnt + t]]
     const int32_t *gidx; int gna, gnt;
+    // B operand stored blocked by 4 along its contiguous logical dimension: element (row r of the `bblk`
+    // (channel, kernel point) rows, position x along P*A) at  (x >> 2) * bblk * 4 + r * 4 + (x & 3)
+    // -- the layout the grouping kernels can write with coalesced stores (csrc/so3_inter_lists.hip)
+    long long bblk;
 };
 
 // Load 4 consecutive elements along the contiguous dimension `x` of a row-major [rows][cols]
@@ -136,10 +140,22 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g)
                 rb[u] = v;
             } else if (!TB) {   // B [K,N]: n contiguous
                 const int k = (t / (BN / 4)) + u * (NT / (BN / 4)), jq = (t % (BN / 4)) * 4;
-                rb[u] = load4<VEC>(B, g.ldb, k0 + k, n0 + jq, kend, g.N);
+                if (g.bblk) {   // rows = K (channel, kernel point), blocked along N
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 + k < kend && n0 + jq + 3 < g.N)
+                        v = *reinterpret_cast<const float4 *>(B + (long long)((n0 + jq) >> 2) * g.bblk * 4 + (long long)(k0 + k) * 4);
+                    rb[u] = v;
+                } else
+                    rb[u] = load4<VEC>(B, g.ldb, k0 + k, n0 + jq, kend, g.N);
             } else {     // B stored [N,K]: k contiguous
                 const int r = (t >> 2) + u * (NT / 4), kq = (t & 3) * 4;
-                rb[u] = load4<VEC>(B, g.ldb, n0 + r, k0 + kq, g.N, kend);
+                if (g.bblk) {   // rows = N (channel, kernel point), blocked along K
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n0 + r < g.N && k0 + kq + 3 < kend)
+                        v = *reinterpret_cast<const float4 *>(B + (long long)((k0 + kq) >> 2) * g.bblk * 4 + (long long)(n0 + r) * 4);
+                    rb[u] = v;
+                } else
+                    rb[u] = load4<VEC>(B, g.ldb, n0 + r, k0 + kq, g.N, kend);
             }
         }
     };
@@ -292,7 +308,7 @@ extern "C" int eap_gemm_f32(int transA, int transB, int M, int N, int K, const f
                             int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
                             int64_t ldc, int64_t strideC, int batch, eap_stream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, 1, (K + BK - 1) / BK * BK, 0, 0, nullptr, 0, 0};
+    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, 1, (K + BK - 1) / BK * BK, 0, 0, nullptr, 0, 0, 0};
     if (g.kchunk == 0) g.kchunk = BK;
     return run(transA != 0, transB != 0, g, batch, eap::S(stream));
 }
@@ -305,9 +321,42 @@ extern "C" int eap_so3_intra_conv_f32(int b, int o, int c, int p, int na, int nt
     if (na > 64 || nt > 16 || (na & 3) != 0) return eap::bad_arg("so3_intra_conv: at most 64 anchors (a multiple of 4) and 16 taps");
     const int K = c * nt, N = p * na;
     GemmArgs g{o, N, K, W, K, 0, feats, (long long)N, (long long)c * N, out, (long long)N, (long long)o * N, 1,
-               (K + BK - 1) / BK * BK, 0, 0, intra_idx, na, nt};
+               (K + BK - 1) / BK * BK, 0, 0, intra_idx, na, nt, 0};
     if (g.kchunk == 0) g.kchunk = BK;
     return run(false, false, g, b, eap::S(stream));
+}
+
+// eap_gemm_f32 with B stored blocked by 4 (see GemmArgs::bblk); b_block_rows = number of B's (channel,
+// kernel point) rows = K without transB, N with it; the blocked dimension must be a multiple of 4
+extern "C" int eap_gemm_f32_xb(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                               int64_t strideA, const float *B, int64_t b_block_rows, int64_t strideB, float *C,
+                               int64_t ldc, int64_t strideC, int batch, eap_stream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (((transB ? K : N) & 3) != 0 || b_block_rows != (transB ? N : K))
+        return eap::bad_arg("gemm_f32_xb: blocked dimension must be a multiple of 4 and b_block_rows the other one");
+    GemmArgs g{M, N, K, A, lda, strideA, B, 4, strideB, C, ldc, strideC, 1, (K + BK - 1) / BK * BK, 0, 0, nullptr, 0, 0, b_block_rows};
+    if (g.kchunk == 0) g.kchunk = BK;
+    return run(transA != 0, transB != 0, g, batch, eap::S(stream));
+}
+
+extern "C" int eap_gemm_f32_reduce_xb(int transA, int transB, int M, int N, int K, const float *A,
+                                      int64_t lda, int64_t strideA, const float *B, int64_t b_block_rows,
+                                      int64_t strideB, float *C, int64_t ldc, int batch, float *workspace,
+                                      eap_stream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (batch <= 0 || K <= 0) return eap_gemm_f32_reduce(transA, transB, M, N, K, A, lda, strideA, B, 4, strideB, C, ldc, batch, workspace, stream);
+    if (((transB ? K : N) & 3) != 0 || b_block_rows != (transB ? N : K))
+        return eap::bad_arg("gemm_f32_reduce_xb: blocked dimension must be a multiple of 4 and b_block_rows the other one");
+    hipStream_t s = eap::S(stream);
+    const int splits = pick_splits(M, N, K, batch);
+    int kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    GemmArgs g{M, N, K, A, lda, strideA, B, 4, strideB, workspace, N, (long long)M * N, splits, kchunk, 0, 0, nullptr, 0, 0, b_block_rows};
+    int e = run(transA != 0, transB != 0, g, batch * splits, s);
+    if (e) return e;
+    const long long mn = (long long)M * N;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(eap::cdiv(mn, 256)), dim3(256), 0, s, mn, N,
+                       batch * splits, workspace, C, (long long)ldc);
+    return eap::check_launch("gemm_f32_reduce");
 }
 
 extern "C" int64_t eap_gemm_f32_reduce_workspace(int M, int N, int K, int batch) {
@@ -329,7 +378,7 @@ extern "C" int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, 
     }
     const int splits = pick_splits(M, N, K, batch);
     int kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, workspace, N, (long long)M * N, splits, kchunk, 0, 0, nullptr, 0, 0};
+    GemmArgs g{M, N, K, A, lda, strideA, B, ldb, strideB, workspace, N, (long long)M * N, splits, kchunk, 0, 0, nullptr, 0, 0, 0};
     int e = run(transA != 0, transB != 0, g, batch * splits, s);
     if (e) return e;
     const long long mn = (long long)M * N;

@@ -323,17 +323,27 @@ int launch_group_fwd(int b, int c, int p, int n, int nn, int na, int ks, float s
 }
 }  // namespace
 
-extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, int na, int ks,
-                                           float sigma, const float *feats, const int32_t *idx,
-                                           const float *gx, const float *rk, const uint8_t *mult,
-                                           const int32_t *nonident, float *out, eap_stream_t stream) {
+// can the forward write the blocked layout for these sizes?  (>= 16 channels, the entry-list kernel's
+// anchor / kernel-point limits, a multiple of 4 anchors, and either no permutation table or the
+// per-cloud flag array)
+extern "C" int eap_so3_inter_group_fwd_can_block(int c, int n, int na, int ks, int has_mult, int has_flag) {
+    return c >= 16 && (na & 3) == 0 && eap::group_lists_supported(na, ks) && (long long)c * n * na < (1ll << 31) &&
+           (!has_mult || has_flag);
+}
+
+static int group_fwd_dispatch(int blocked, int b, int c, int p, int n, int nn, int na, int ks,
+                              float sigma, const float *feats, const int32_t *idx,
+                              const float *gx, const float *rk, const uint8_t *mult,
+                              const int32_t *nonident, float *out, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd: at most 32 kernel points (use the zpconv op)");
+    if (blocked && !eap_so3_inter_group_fwd_can_block(c, n, na, ks, mult != nullptr, nonident != nullptr))
+        return eap::bad_arg("so3_inter_group_fwd_xb: blocked output not available for these sizes (ask eap_so3_inter_group_fwd_can_block)");
     if (nn <= 0)
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, eap::S(stream)), "so3_inter_group_fwd memset");
-    // >= 16 channels: matrix-core formulation (csrc/so3_inter_mfma.hip); fewer: the VALU kernel
-    // below (a 32-channel MFMA tile would be mostly padding)
+    // >= 16 channels: matrix-core formulation; fewer: the VALU kernel below (a 32-channel MFMA tile
+    // would be mostly padding)
     if (c >= 16) {
         // no permutation (no pose, or a cloud whose relative rotations are all the identity -- the
         // flag eap_so3_prep_f32 leaves in nonident): the two-workgroups-per-CU kernel
@@ -341,14 +351,29 @@ extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, i
         // both kernels are launched and each skips the other's clouds -- no host round trip.
         const bool lists = eap::group_lists_supported(na, ks) && (long long)c * n * na < (1ll << 31);
         if (lists && (!mult || nonident)) {
-            int e = eap::group_lists_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, out, eap::S(stream));
+            int e = eap::group_lists_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream));
             if (e || !mult) return e;
-            return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 1, out, eap::S(stream));
+            return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 1, blocked, out, eap::S(stream));
         }
-        return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, out, eap::S(stream));
+        return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, 0, out, eap::S(stream));
     }
     if (ks <= 24) return launch_group_fwd<6>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
     return launch_group_fwd<8>(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, out, eap::S(stream));
+}
+
+extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, int na, int ks,
+                                           float sigma, const float *feats, const int32_t *idx,
+                                           const float *gx, const float *rk, const uint8_t *mult,
+                                           const int32_t *nonident, float *out, eap_stream_t stream) {
+    return group_fwd_dispatch(0, b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, out, stream);
+}
+
+// same, output blocked by anchor quads: out[b][p][a/4][c][k][4] (read by eap_gemm_f32_xb)
+extern "C" int eap_so3_inter_group_fwd_xb_f32(int b, int c, int p, int n, int nn, int na, int ks,
+                                              float sigma, const float *feats, const int32_t *idx,
+                                              const float *gx, const float *rk, const uint8_t *mult,
+                                              const int32_t *nonident, float *out, eap_stream_t stream) {
+    return group_fwd_dispatch(1, b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, out, stream);
 }
 
 extern "C" int eap_so3_inter_group_fwd_valu_f32(int b, int c, int p, int n, int nn, int na, int ks,

@@ -60,7 +60,7 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // LISTS = false: row r of cloud b owns entries [ (b*R + r)*nn, +nn ) (forward: its neighbours).
 template <bool LISTS>
 __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
-    int C, int PF, int na, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, float inv_sigma,
+    int C, int PF, int na, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, int blocked, float inv_sigma,
     const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
     const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
     const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
@@ -240,8 +240,22 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     float *ob = out + (size_t)bi * C * o_cs + (size_t)c0 * o_cs + a0;
     const unsigned lane_off = (unsigned)((size_t)(4 * lh) * o_cs + (size_t)min(lk, ks - 1) * o_ks) + (unsigned)al_beg;
     const bool full_c = c0 + CB <= C;                       // block-uniform
+    // blocked output (the forward's X when the contraction GEMM reads it with eap_gemm_f32_xb):
+    // out[b][row][anchor quad][c][k][4] -- for one register r the 24 kernel-point lanes of a
+    // channel write 384 contiguous bytes, 6 cache lines per wave-instruction instead of 64
+    const int npq = na >> 2, aq0 = (a0 + al_beg) >> 2;
+    float *obb = out + (size_t)bi * C * o_cs;
+    const unsigned lane_off_b = (unsigned)((4 * lh) * ks + min(lk, ks - 1)) * 4u;
     auto store_row = [&](int row) {
         if (active && lk < ks) {
+            if (blocked) {
+                float *rb = obb + (((size_t)row * npq + aq0) * C + c0) * ks * 4;     // uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (full_c || c0 + (r & 3) + 8 * (r >> 2) + 4 * lh < C)
+                        *reinterpret_cast<float4 *>(rb + (size_t)((r & 3) + 8 * (r >> 2)) * ks * 4 + lane_off_b) =
+                            make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            } else {
             float *rb = ob + (size_t)row * na;             // uniform
             if (full_c) {
 #pragma unroll
@@ -254,6 +268,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
                     if (c0 + (r & 3) + 8 * (r >> 2) + 4 * lh < C)
                         *reinterpret_cast<float4 *>(rb + (size_t)((r & 3) + 8 * (r >> 2)) * o_cs + lane_off) =
                             make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            }
             }
         }
 #pragma unroll
@@ -320,7 +335,7 @@ bool geometry(int na, int ks, Geometry &g) {
 }
 
 template <bool LISTS>
-int launch(int b, int C, int PF, int na, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
+int launch(int blocked, int b, int C, int PF, int na, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
            const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
            const float *rk, const int32_t *nonident, float *out, hipStream_t s, const char *what) {
     Geometry g;
@@ -334,7 +349,7 @@ int launch(int b, int C, int PF, int na, int ks, int R, int nn, int ent_stride, 
     // first chunk are in flight during the current row's last chunk)
     const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
     dim3 grid((R + RPB - 1) / RPB * g.AG, (C + CB - 1) / CB, b);
-    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, 1.0f / sigma, F,
+    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, blocked, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
     return eap::check_launch(what);
 }
@@ -351,16 +366,16 @@ bool group_lists_supported(int na, int ks) {
 // forward over the clouds whose relative rotations are all the identity (nonident[b] == 0, or
 // nonident == nullptr for every cloud); other clouds are left untouched
 int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
-                    const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, float *out,
+                    const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int blocked, float *out,
                     hipStream_t s) {
-    return launch<false>(b, c, n, na, ks, p, nn, 0, sigma, feats, nullptr, nullptr, nullptr, idx, gx, rk, nonident, out, s,
+    return launch<false>(blocked, b, c, n, na, ks, p, nn, 0, sigma, feats, nullptr, nullptr, nullptr, idx, gx, rk, nonident, out, s,
                          "so3_inter_group_fwd (lists)");
 }
 
 int group_lists_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
                     const float *ent_gx, const float *rk, float *z, hipStream_t s) {
-    return launch<true>(b, o, p, na, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, nullptr, z, s,
+    return launch<true>(0, b, o, p, na, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, nullptr, z, s,
                         "so3_inter_group_inv (lists)");
 }
 

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     int c, int p, int n_sup, int nn, int na, int ks, float inv_sigma,
     const float *__restrict__ feats, const int32_t *__restrict__ idx, const float4 *__restrict__ gx,
     const float *__restrict__ rk, const uint8_t *__restrict__ mult, const int32_t *__restrict__ nonident,
-    int skip_plain, float *__restrict__ out) {
+    int skip_plain, int blocked, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // clouds without any non-identity relative rotation were served by csrc/so3_inter_lists.hip
     if (skip_plain && __builtin_amdgcn_readfirstlane(nonident[blockIdx.z]) == 0) return;
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
                 if (ci < c && piece < npiece) {
                     const float *src = s_o + (size_t)row * na + 4 * pc;
                     float *dst = ob + (size_t)ci * o_cs + (size_t)k * o_ks + 4 * pc;
+                    // blocked output [b][point][anchor quad][c][k][4] (see csrc/so3_inter_lists.hip)
+                    if (blocked) dst = out + (size_t)bi * c * o_cs + ((((size_t)pi * npiece + pc) * c + ci) * ks + k) * 4;
                     if (vec_ok) {
                         *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
                     } else {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
 
 int eap::group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                         const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,
-                        const int32_t *nonident, int skip_plain, float *out, hipStream_t s) {
+                        const int32_t *nonident, int skip_plain, int blocked, float *out, hipStream_t s) {
     if (b <= 0 || c <= 0 || p <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 64 anchors");
     if (ks > 32) return eap::bad_arg("so3_inter_group_fwd_mfma: at most 32 kernel points");
@@ -290,7 +292,7 @@ int eap::group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, floa
                                               (int)shmem), "so3_inter_group_fwd_mfma shared memory");         \
         if (e) return e;                                                                                      \
         hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, c, p, n, nn, na, ks, inv_sigma, feats, idx, g4,    \
-                           rk, mult, nonident, skip_plain, out);                                              \
+                           rk, mult, nonident, skip_plain, blocked, out);                                     \
     } while (0)
     if ((na & 3) == 0) { if (mult) EAP_MFMA_LAUNCH(8, true, true); else EAP_MFMA_LAUNCH(8, true, false); }
     else if (mult) EAP_MFMA_LAUNCH(8, false, true);
@@ -303,5 +305,5 @@ extern "C" int eap_so3_inter_group_fwd_mfma_f32(int b, int c, int p, int n, int 
                                                 float sigma, const float *feats, const int32_t *idx,
                                                 const float *gx, const float *rk, const uint8_t *mult,
                                                 const int32_t *nonident, float *out, eap_stream_t stream) {
-    return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, out, eap::S(stream));
+    return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, 0, out, eap::S(stream));
 }

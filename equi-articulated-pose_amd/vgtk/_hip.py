@@ -85,17 +85,18 @@ def suffix(t):
 
 # ---- raw launchers used by the operator layer ---------------------------------------------------
 
-def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch):
-    call('eap_gemm_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
-         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch,
+def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, b_blocked=False):
+    """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored."""
+    call('eap_gemm_f32_xb' if b_blocked else 'eap_gemm_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
+         _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch,
          tag={'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)})
 
 
-def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch):
+def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch, b_blocked=False):
     n_ws = lib.eap_gemm_f32_reduce_workspace(M, N, K, batch)
     ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=C.device)
-    call('eap_gemm_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
-         _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws),
+    call('eap_gemm_f32_reduce_xb' if b_blocked else 'eap_gemm_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
+         _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws),
          tag={'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)})
 
 
@@ -126,12 +127,18 @@ def so3_anchor_perm(gx, mult):
     return perm
 
 
-def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None):
+def so3_inter_group_fwd_can_block(c, n, na, ks, has_mult, has_flag):
+    return bool(lib.eap_so3_inter_group_fwd_can_block(c, n, na, ks, int(has_mult), int(has_flag)))
+
+
+def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=False):
+    """-> X [b,c,ks,p,na]; with `blocked` the same numbers as [b,p,na/4,c,ks,4] (returned with the
+    nominal shape: only eap_gemm_f32_xb may read it)."""
     b, c, n, na = feats.shape
     p, nn = idx.shape[1], idx.shape[2]
     ks = rk.shape[1]
     out = torch.empty(b, c, ks, p, na, dtype=torch.float32, device=feats.device)
-    call('eap_so3_inter_group_fwd_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
+    call('eap_so3_inter_group_fwd_xb_f32' if blocked else 'eap_so3_inter_group_fwd_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
          _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out),
          tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd', b, c, p, nn, na, ks)})
     return out

@@ -260,6 +260,9 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
             cnt_c.to(torch.int32).contiguous(), ent_p, ent_gx, rcap, all_ident)
 
 
+BLOCKED_X = True     # dev knob: keep the fused conv's intermediate in the blocked layout when possible
+
+
 class _InterConv(torch.autograd.Function):
     """Fused inter conv  y = W . group(feats)  (functional.py:L1221-1261 + modules.py:L48-55)
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
@@ -268,11 +271,17 @@ class _InterConv(torch.autograd.Function):
     def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident, nonident=None):
         feats = feats.contiguous()
         W = W.contiguous()
-        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident)      # [b,c,k,p,a]
+        # X is internal to this Function: where the kernels allow it, it is kept blocked by anchor
+        # quads ([b,p,a/4,c,k,4]) -- coalesced row-end stores in the grouping kernel -- and the GEMMs
+        # read it as a blocked B operand (include/eap_hip.h, "blocked intermediate")
+        blocked = BLOCKED_X and _hip.so3_inter_group_fwd_can_block(feats.shape[1], feats.shape[2], feats.shape[3], rk.shape[1],
+                                                                   mult is not None, nonident is not None)
+        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=blocked)   # [b,c,k,p,a] (nominal)
         b, c, ks, p, na = x.shape
         o = W.shape[0]
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=x.device)
-        _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b)
+        _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=blocked)
+        ctx.blocked = blocked
         ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0),
                               nonident if nonident is not None else torch.empty(0))
         ctx.has_mult = mult is not None
@@ -329,7 +338,7 @@ class _InterConv(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[1]:
                 gW = torch.empty_like(W)          # sum_b gy_b x_b^T
-                _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)
+                _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b, b_blocked=ctx.blocked)
             if ctx.needs_input_grad[0]:
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)

@@ -215,6 +215,25 @@ int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, const float
                         int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
                         int64_t ldc, int batch, float *workspace, eap_stream_t stream);
 
+/* ---- blocked intermediate: the forward's grouped tensor X with coalesced row-end stores --------
+ * X_blocked[b][p][a/4][c][k][4] holds the same numbers as X[b][c][k][p][a].  The grouping kernels
+ * write 384 contiguous bytes per (channel, anchor quad) instead of 16-byte pieces 983 KB apart, and
+ * the contraction GEMMs read it as a B operand "blocked by 4" along P*A.  Internal to the fused
+ * conv (vgtk.so3conv.functional._InterConv); the reference-layout entries above stay as they are. */
+int eap_so3_inter_group_fwd_can_block(int c, int n, int na, int ks, int has_mult, int has_flag);
+int eap_so3_inter_group_fwd_xb_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                   const float *feats, const int32_t *idx, const float *gx,
+                                   const float *rk, const uint8_t *mult, const int32_t *nonident,
+                                   float *out, eap_stream_t stream);
+/* eap_gemm_f32 / eap_gemm_f32_reduce with B blocked by 4: element (row r of b_block_rows, position x)
+ * at (x >> 2) * b_block_rows * 4 + r * 4 + (x & 3); b_block_rows = K (transB = 0) or N (transB = 1). */
+int eap_gemm_f32_xb(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                    int64_t strideA, const float *B, int64_t b_block_rows, int64_t strideB, float *C,
+                    int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+int eap_gemm_f32_reduce_xb(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                           int64_t strideA, const float *B, int64_t b_block_rows, int64_t strideB,
+                           float *C, int64_t ldc, int batch, float *workspace, eap_stream_t stream);
+
 /* Intra SO(3) conv, forward, as an implicit GEMM (no [b,c,t,p,na] gathered tensor):
  * out[b,o,p,a] = sum_{c,t} W[o, c*nt + t] * feats[b, c, p, intra_idx[a*nt + t]]
  * (so3conv/functional.py:L2553-2602 intra_so3conv_grouping + so3conv/modules.py:L48-55 BasicSO3Conv).

@@ -234,13 +234,16 @@ def _run_layer(vg, dev, g):
     return conv, feats, conv(x)
 
 
+@pytest.mark.parametrize('blocked', [True, False])
 @pytest.mark.parametrize('mode', ['dx', 'inverse'])
 @pytest.mark.parametrize('name', INTER_CASES)
-def test_inter_pose_layer_golden(dev, vg, golden, name, mode, monkeypatch):
+def test_inter_pose_layer_golden(dev, vg, golden, name, mode, blocked, monkeypatch):
     """Forward + both feature-gradient strategies (dX + transposed grouping / re-associated
-    inverse-list grouping of dY) against the reference's autograd."""
+    inverse-list grouping of dY) against the reference's autograd; with the fused conv's
+    intermediate in the blocked layout and in the reference layout."""
     _, _, _, L = vg
     monkeypatch.setattr(L, 'BACKWARD_MODE', mode)
+    monkeypatch.setattr(L, 'BLOCKED_X', blocked)
     g = golden(name + '.npz')
     conv, feats, (inter_idx, inter_w, sample_idx, y) = _run_layer(vg, dev, g)
     assert inter_idx is None and sample_idx is None            # reference stride-1 return values
