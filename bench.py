@@ -299,7 +299,7 @@ def main():
         # fabric-side bytes per launch of the dominant entry, from the rocprofv3 FETCH_SIZE /
         # WRITE_SIZE passes committed under profiles/ (collected at the default workload only)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_h_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_l_pmc_traffic.json')
         if os.path.exists(pmc) and args.points == 4096 and args.batch == 8 and not args.fwd_only:
             d = json.load(open(pmc))['per_launch_bytes'].get(dom_name)
             if d:
