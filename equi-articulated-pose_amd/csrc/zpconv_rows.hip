@@ -77,31 +77,43 @@ __global__ __launch_bounds__(TM, 2) void inter_zpconv_rows_kernel(
     const bool ref_fixed = (TM % qpr) == 0;
     const int4 ref_mine = ref4[t % qpr];
     int mismatch = 0;
-    for (int f0 = t; f0 < nquad; f0 += 4 * TM) {                  // 8-12 loads in flight per thread
-        int4 iv[4], ir[4];
-        float4 wv[4];
+    // software-pipelined: the loads of batch i+1 (4 pieces = 8 x 16 bytes per thread) are in flight
+    // while batch i is compared and scattered into LDS, so the HBM stream never pauses
+    auto load_batch = [&](int f0, int4 (&iv)[4], float4 (&wv)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = min(f0 + j * TM, nquad - 1);
             const int a = f / per_a, rem = f - a * per_a;        // rem = kl*qpr + q4: contiguous in memory
             const size_t g = (((pbase + a) * ks + k0) * nn >> 2) + rem;
             iv[j] = reinterpret_cast<const int4 *>(idx)[g];
-            ir[j] = ref_mine;
-            if (!ref_fixed) ir[j] = ref4[rem % qpr];
             wv[j] = reinterpret_cast<const float4 *>(w)[g];
         }
+    };
+    auto store_batch = [&](int f0, const int4 (&iv)[4], const float4 (&wv)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = f0 + j * TM;
             if (f < nquad) {
                 const int a = f / per_a, rem = f - a * per_a;
-                mismatch |= (iv[j].x ^ ir[j].x) | (iv[j].y ^ ir[j].y) | (iv[j].z ^ ir[j].z) | (iv[j].w ^ ir[j].w);
+                const int4 ir = ref_fixed ? ref_mine : ref4[rem % qpr];
+                mismatch |= (iv[j].x ^ ir.x) | (iv[j].y ^ ir.y) | (iv[j].z ^ ir.z) | (iv[j].w ^ ir.w);
                 // row(kl, n) = (n & 3) * KT*qpr + kl*qpr + (n >> 2): consecutive lanes (consecutive rem)
                 // write consecutive rows
                 float *dst = s_w + (size_t)rem * PW + a;
                 const size_t js = (size_t)KT * qpr * PW;
                 dst[0] = wv[j].x; dst[js] = wv[j].y; dst[2 * js] = wv[j].z; dst[3 * js] = wv[j].w;
             }
+        }
+    };
+    {
+        int4 iva[4], ivb[4];
+        float4 wva[4], wvb[4];
+        load_batch(t, iva, wva);
+        for (int f0 = t; f0 < nquad; f0 += 8 * TM) {
+            load_batch(f0 + 4 * TM, ivb, wvb);                   // clamped past the end (harmless reload)
+            store_batch(f0, iva, wva);
+            load_batch(f0 + 8 * TM, iva, wva);
+            store_batch(f0 + 4 * TM, ivb, wvb);
         }
     }
     for (int n = t; n < nn; n += TM) s_q[n] = idx[(pbase * ks + k0) * nn + n];
