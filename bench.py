@@ -182,6 +182,37 @@ def cpu_baseline(points, slab=64):
             'value_perm_search_short_circuited': out['short_circuit']}
 
 
+def zpconv_roofline(dev, points, clouds=2, channels=64):
+    """The standalone native zpconv forward (vgtk.cuda.zpconv.inter_zpconv_forward, the op the north
+    star puts an HBM-roofline target on): algorithmic bytes = idx + w read once,
+    feats, out written once; time = HIP events around 3 launches after a warm-up.  Separate from
+    the timed steps (the shipped models never call this op: they use the fused grouping)."""
+    import synth_clouds
+    import vgtk.cuda.zpconv as Z
+    import vgtk.cuda.grouping as G
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(0, clouds, points)[0]).to(dev)
+    radius = synth_clouds.backbone_layers(points)[1][2]
+    ball = G.ball_query(xyz, xyz, radius, NN)
+    idx = ball[:, :, None, None, :].expand(clouds, points, NA, KS, NN).contiguous()
+    w = torch.rand(clouds, points, NA, KS, NN, device=dev)
+    feats = torch.randn(clouds, channels, points, NA, device=dev)
+    byts = 4.0 * clouds * (2.0 * points * NA * KS * NN + channels * points * NA + channels * KS * points * NA)
+    Z.inter_zpconv_forward(idx, w, feats)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        Z.inter_zpconv_forward(idx, w, feats)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    gbs = byts / ms / 1e6
+    return {'bound': 'hbm', 'kernel': 'inter_zpconv_rows_kernel', 'entry': 'eap_inter_zpconv_fwd_f32', 'achieved': gbs,
+            'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'ms': ms, 'bytes': byts,
+            'workload': f'{clouds} x {points} points, C={channels}, A={NA}, K={KS}, NN={NN}, one neighbour list per point '
+                        f'broadcast over (a,k) as the Python layer builds it, radius {radius}'}
+
+
 KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
     'eap_gemm_f32': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
     'eap_gemm_f32_reduce': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K',
@@ -329,6 +360,8 @@ def main():
             'dominant_kernel': dom_name,
             'launch_shapes': shapes[:8],
         }
+        if world == 1 and not args.fwd_only:
+            line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.points)
             line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
