@@ -36,3 +36,39 @@ class ChamferDistance(torch.nn.Module):
         if return_raw:
             return dist1, dist2
         return torch.mean(dist1) + torch.mean(dist2)
+
+
+MASKED_DISTANCE = 99999.0     # the constant the reference writes into masked entries of the distance tensor
+
+
+def orbit_reconstruction_distances(transformed_pts, ori_pts, hard_one_hot_labels):
+    """The slot/orbit reconstruction distances of the reference's orbit selection
+    (SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L1341-1361) WITHOUT its
+    `dist_recon_ori [B, S, A, M, N]` tensor (4 GB at B=8, S=2, A=60, M=256, N=4096): a 60-way batched
+    chamfer on the chamfer kernels (csrc/chamfer.hip), SURVEY.md 8(f) row 2.
+
+    transformed_pts [B,S,A,M,3]  per-slot, per-anchor reconstructions
+    ori_pts         [B,3,N]      the input cloud
+    hard_one_hot_labels [B,N,S]  0/1 point-to-slot assignment
+    ->  (minn_dist_ori_to_recon_all_pts [B,S,A,N],  min over M of the unmasked distances
+         minn_dist_recon_to_ori_all_pts [B,S,A],    mean over M of the min over N, unmasked
+         minn_dist_recon_to_ori         [B,S,A],    the same with points outside the slot masked
+         minn_dist_ori_to_recon         [B,S,A,N])  min over M with masked points set to 99999
+    Gradients flow to transformed_pts exactly as through the reference's min / mean."""
+    b, s, a, m, _ = transformed_pts.shape
+    n = ori_pts.shape[2]
+    recon = transformed_pts.reshape(b * s * a, m, 3)
+    ori = ori_pts.transpose(1, 2)                                                   # [B,N,3]
+    ori_all = ori[:, None, None].expand(b, s, a, n, 3).reshape(b * s * a, n, 3)
+    r2o_all, o2r_all = ChamferFunction.apply(recon, ori_all)                         # [B',M], [B',N]
+    in_slot = hard_one_hot_labels.transpose(1, 2) >= 0.5                             # [B,S,N]
+    # masked: points outside the slot are moved out of reach; the reference's 99999 entries are what
+    # an empty slot's minimum sees, hence the clamp
+    far = torch.full_like(ori, 1e4)
+    ori_masked = torch.where(in_slot[..., None], ori[:, None].expand(b, s, n, 3), far[:, None].expand(b, s, n, 3))
+    ori_masked = ori_masked[:, :, None].expand(b, s, a, n, 3).reshape(b * s * a, n, 3)
+    r2o_masked, _ = ChamferFunction.apply(recon, ori_masked)
+    r2o_masked = r2o_masked.clamp(max=MASKED_DISTANCE)
+    o2r_all = o2r_all.view(b, s, a, n)
+    o2r_masked = torch.where(in_slot[:, :, None].expand(b, s, a, n), o2r_all, o2r_all.new_full((), MASKED_DISTANCE))
+    return (o2r_all, r2o_all.view(b, s, a, m).mean(-1), r2o_masked.view(b, s, a, m).mean(-1), o2r_masked)

@@ -635,3 +635,32 @@ def test_intra_conv_implicit_gemm(dev, vg, shape):
         fast = conv(x).feats                                   # implicit path
     slow = conv(zptk.SphericalPointCloud(x.xyz, feats.clone().requires_grad_(True), conv.anchors)).feats   # materialised path
     assert rel_err(fast.cpu().numpy(), slow.detach().cpu().numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 3, 5, 7, 33), (1, 2, 60, 64, 300)])
+def test_orbit_reconstruction_distances(dev, vg, shape):
+    """the orbit-selection distances (…pn_38_multi_stage.py:L1341-1361) as a
+    60-way batched chamfer on the chamfer kernels, against the reference's materialised
+    [B,S,A,M,N] formulation (oracle/orbit_ref.py): values and the gradient reaching the
+    reconstructions.  One slot is left empty (its masked minima are the 99999 constant)."""
+    from extensions.chamfer_dist import orbit_reconstruction_distances
+    from oracle import orbit_ref
+    b, s, a, m, n = shape
+    torch.manual_seed(9)
+    recon = torch.randn(b, s, a, m, 3) * 0.3
+    ori = torch.randn(b, 3, n) * 0.3
+    slot = torch.randint(0, s - 1 if s > 2 else s, (b, n))          # for s > 2 the last slot stays empty
+    labels = torch.nn.functional.one_hot(slot, s).float()           # [B,N,S]
+    rc = recon.clone().requires_grad_(True)
+    want = orbit_ref.orbit_reconstruction_distances(rc, ori, labels)
+    rg = recon.clone().to(dev).requires_grad_(True)
+    got = orbit_reconstruction_distances(rg, ori.to(dev), labels.to(dev))
+    for u, v in zip(got, want):
+        assert u.shape == v.shape
+        np.testing.assert_allclose(u.detach().cpu().numpy(), v.detach().numpy(), rtol=1e-6, atol=1e-7)
+    wts = [torch.randn_like(v) for v in want]
+    finite = [torch.where(v.detach() < 9e4, w, torch.zeros_like(w)) for v, w in zip(want, wts)]   # constants carry no gradient
+    sum((v * w).sum() for v, w in zip(want, finite)).backward()
+    sum((u * w.to(dev)).sum() for u, w in zip(got, finite)).backward()
+    np.testing.assert_allclose(rg.grad.cpu().numpy(), rc.grad.numpy(), rtol=1e-5, atol=1e-6)
