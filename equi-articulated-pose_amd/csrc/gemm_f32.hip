@@ -69,7 +69,7 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ base, long lon
 
 // NWM x NWN waves per block, every wave owns a WTM x 64 tile (WTM = 64, or 32 for the small-M variant)
 template <int NWM, int NWN, int WTM, bool TA, bool TB, bool VEC, bool GATHER = false>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 16 ? 4 : 2)) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WTM * NWM, BN = 64 * NWN, NT = 64 * NWM * NWN;
     __shared__ Smem<BM, BN> sm;
     __shared__ int s_gi[GATHER ? 64 * 16 : 1];              // the [anchor][tap] index table of the implicit intra conv
@@ -204,11 +204,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g)
         if (it + 1 < ntile) fetch(kbeg + (it + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
+            // the MT row tiles (2 column tiles) of a wave are interleaved: tile i owns rows MT*li + i,
+            // so all operands of a k-step are one aligned 8-byte (or 4-byte) LDS read per side
             float af[MT], bf[2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = sm.a[buf][kk + lk][wm * WTM + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = sm.b[buf][kk + lk][wn * 64 + j * 32 + li];
+            if (MT == 2) {
+                const float2 a2 = *reinterpret_cast<const float2 *>(&sm.a[buf][kk + lk][wm * WTM + 2 * li]);
+                af[0] = a2.x; af[MT - 1] = a2.y;
+            } else {
+                af[0] = sm.a[buf][kk + lk][wm * WTM + li];
+            }
+            const float2 b2 = *reinterpret_cast<const float2 *>(&sm.b[buf][kk + lk][wn * 64 + 2 * li]);
+            bf[0] = b2.x; bf[1] = b2.y;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -219,21 +225,26 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_f32_kernel(GemmArgs g)
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5);
+    // with the interleaving above, tile (i, j) element (row, col) is C[MT*row + i][2*col + j]: the two
+    // column tiles of a lane are adjacent -> one 8-byte store
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        const int col = n0 + wn * 64 + 2 * li;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + li;
-            const int rbase = m0 + wm * WTM + i * 32 + 4 * lk;
-            if (col < g.N) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < g.M) C[(long long)row * g.ldc + col] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WTM + MT * ((r & 3) + 8 * (r >> 2) + 4 * lk) + i;
+            if (row < g.M) {
+                float *dst = C + (long long)row * g.ldc + col;
+                if (col + 1 < g.N && (g.ldc & 1) == 0 && ((reinterpret_cast<uintptr_t>(C) & 7) == 0))
+                    *reinterpret_cast<float2 *>(dst) = make_float2(acc[i][0][r], acc[i][1][r]);
+                else {
+                    if (col < g.N) dst[0] = acc[i][0][r];
+                    if (col + 1 < g.N) dst[1] = acc[i][1][r];
                 }
             }
         }
+    }
 }
 
 // sum `slabs` partial [M,N] slabs (contiguous, pitch M*N) into C (leading dimension ldc)
@@ -282,10 +293,12 @@ int run(bool ta, bool tb, GemmArgs g, int zcount, hipStream_t s) {
     if (g.M <= 64) { bm = 64; bn = 128; }
     else if (cfg == 1 && g.M >= 256) { bm = 256; bn = 128; }
     else if (cfg == 2 && g.N >= 256) { bm = 128; bn = 256; }
+    else if (cfg == 3 && g.M >= 256 && g.N >= 256) { bm = 256; bn = 256; }
     else { bm = 128; bn = 128; }
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
     if (bm == 64) return launch<2, 2, 32>(ta, tb, g, zcount, s);
+    if (bm == 256 && bn == 256) return launch<4, 4, 64>(ta, tb, g, zcount, s);
     if (bm == 256) return launch<4, 2, 64>(ta, tb, g, zcount, s);
     if (bn == 256) return launch<2, 4, 64>(ta, tb, g, zcount, s);
     return launch<2, 2, 64>(ta, tb, g, zcount, s);
