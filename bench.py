@@ -176,7 +176,16 @@ def cpu_baseline(points, slab=64):
             y.square().mean().backward()
             total += time.perf_counter() - t0
         out[label] = 1.0 / (total * points / slab)
+    model = 'unknown'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {'value': out['faithful'], 'unit': 'point-clouds/sec', 'cores': threads, 'kind': 'port',
+            'host_logical_cpus': os.cpu_count(), 'host_cpu_model': model,
             'sample': f'oracle fwd+bwd of the 3 backbone layers on {slab} of {points} query points of 1 cloud, '
                       f'scaled x{points // slab}; includes the reference\'s 60x60 anchor-permutation search',
             'value_perm_search_short_circuited': out['short_circuit']}
