@@ -320,18 +320,19 @@ class _InterConv(torch.autograd.Function):
             z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
                                          ctx.ident)                                  # [b,o,ks,rcap,na]
             ra = rcap * na
-            dest = torch.where(rows >= 0, rows, torch.full_like(rows, n)).long()   # unused slots -> dummy row n
+            dest = rows.clamp(min=0).long()                                           # unused slots (rows < 0) carry zeros in Z
+            dest4 = dest[:, None, :, None].expand(b, c, rcap, na)
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
                 _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
-                gF = torch.zeros(b, c, n + 1, na, dtype=torch.float32, device=gy.device)
-                gF.scatter_(2, dest[:, None, :, None].expand(b, c, rcap, na), gFc.view(b, c, rcap, na))
-                gF = gF[:, :, :n].contiguous()
+                # rows of unused slots are exactly zero (Z is), so adding them to row 0 is harmless
+                gF = torch.zeros(b, c, n, na, dtype=torch.float32, device=gy.device)
+                gF.scatter_add_(2, dest4, gFc.view(b, c, rcap, na))
             if ctx.needs_input_grad[1]:
                 feats = ctx.feats_ref
-                fpad = torch.cat([feats, feats.new_zeros(b, c, 1, na)], 2)          # dummy row n = zeros
-                fc = torch.gather(fpad, 2, dest[:, None, :, None].expand(b, c, rcap, na)).reshape(b, c, ra).contiguous()
+                fc = torch.gather(feats, 2, dest4)                                   # [b,c,rcap,na]; unused slots meet zero rows of Z
+                fc = fc.reshape(b, c, ra)
                 d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
                 _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
                 gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
