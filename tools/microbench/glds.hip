@@ -266,6 +266,67 @@ void run_occ2(const char *src, int pwin, int nblk, float *sink, unsigned long lo
            avg / rounds, 100.0 * (nblk / 256) * 2048.0 / (avg / rounds), ms, avg / (ms * 1e-3) / 1e9);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products (blocks <-> anchors, rows <-> 4 channels,
+// columns <-> 4 kernel points, K = 1 entry): no 24 -> 32 kernel-point padding.  Per wave and entry:
+// NCT channel tiles x 6 kernel-point tiles MFMAs, NCT operand reads from LDS, 6 weights (5 VALU each).
+template <int NCT, int VALU, int READS>
+__global__ __launch_bounds__(512, 4) void k4x4(int rounds, float *sink, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    f32x4 acc[NCT][6];
+    for (int i = 0; i < NCT; ++i) for (int j = 0; j < 6; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    float kx[6], ky[6], kz[6], kc[6];
+    for (int j = 0; j < 6; ++j) { kx[j] = 1e-3f * (t + j); ky[j] = 2e-3f * j; kz[j] = 3e-3f; kc[j] = 0.5f; }
+    const float *fbuf = reinterpret_cast<const float *>(smem);
+    float g = 0.25f;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a[NCT], w[6];
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) a[i] = READS ? fbuf[(e * 32 + i * 4 + (lane & 3)) * 60 + (lane >> 2) + (t >> 6)] : 1.0f + i;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (VALU) { float x = fmaf(g, kx[j], kc[j]); x = fmaf(g, ky[j], x); x = fmaf(g, kz[j], x); w[j] = fmaxf(x + g, 0.f); }
+                else w[j] = 0.5f;
+            }
+#pragma unroll
+            for (int i = 0; i < NCT; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[i], w[j], acc[i][j], 0, 0, 0);
+            g += 1e-6f;
+        }
+        __syncthreads();
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (t == 0) cyc[blockIdx.x] = t1 - t0;
+    float sum = 0; for (int i = 0; i < NCT; ++i) for (int j = 0; j < 6; ++j) sum += acc[i][j][0];
+    if (sum == 12345.f) sink[0] = sum;
+}
+
+template <int NCT, int VALU, int READS>
+void run_4x4(int nblk, float *sink, unsigned long long *cyc) {
+    const int rounds = 2000;
+    auto kern = k4x4<NCT, VALU, READS>;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 65536, 0, 50, sink, cyc);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 65536, 0, rounds, sink, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("   wall %.3f ms -> %.1f TFLOP/s (512 flop per MFMA)\n", ms, (double)nblk * rounds * 8 * 8 * NCT * 6 * 512 / (ms * 1e-3) / 1e12);
+    unsigned long long h[512]; hipMemcpy(h, cyc, 8 * nblk, hipMemcpyDeviceToHost);
+    double avg = 0; for (int i = 0; i < nblk; ++i) avg += h[i]; avg /= nblk;
+    // MFMA-pipe minimum per round and block: 8 entries x NCT*6 MFMAs x 8 cycles x 2 waves per SIMD
+    const double floor_ = 8.0 * NCT * 6 * 8 * 2 * (nblk / 256);
+    printf("4x4x1 mfma: %d channel tiles, valu %d, reads %d, %d blocks: %7.1f cyc/round/block (pipe minimum %.0f) -> %.1f%% busy (err %d)\n",
+           NCT, VALU, READS, nblk, avg / rounds, floor_, 100.0 * floor_ / (avg / rounds), (int)hipGetLastError());
+}
+
 template <int MIX, int ORDER = 0, int SCHED = 0>
 void run_mix(const char *src, int pwin, float *sink, unsigned long long *cyc) {
     const int rounds = 2000, nblk = 256;
@@ -294,11 +355,8 @@ int main(int argc, char **argv) {
         {"1024B rows, 8 ch x 4195328B stride, window 1024", 1024, 4195328, 8, 1024},
         {"7680B rows (whole entry contiguous), 1 ch, window 4096", 7680, 0, 1, 4096},
     };
-    for (int pwin : {64, 4096}) {
-        run_occ2<0, 0>(src, pwin, 256, sink, cyc); run_occ2<0, 0>(src, pwin, 512, sink, cyc);
-        run_occ2<0, 1>(src, pwin, 512, sink, cyc); run_occ2<1, 0>(src, pwin, 512, sink, cyc);
-        run_occ2<1, 1>(src, pwin, 256, sink, cyc); run_occ2<1, 1>(src, pwin, 512, sink, cyc);
-    }
+    run_4x4<4, 0, 0>(256, sink, cyc); run_4x4<4, 0, 0>(512, sink, cyc); run_4x4<4, 1, 0>(512, sink, cyc);
+    run_4x4<4, 1, 1>(512, sink, cyc); run_4x4<4, 1, 1>(256, sink, cyc);
     if (argc > 1)
     for (auto &c : cfg)
         for (int mode = 0; mode < 3; ++mode) {
