@@ -229,6 +229,8 @@ KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
     'eap_so3_inter_group_fwd_xb_f32': 'so3_group_lists_kernel<false> (v_mfma_f32_32x32x2_f32), blocked output',
     'eap_gemm_f32_xb': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), blocked B operand',
     'eap_gemm_f32_reduce_xb': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K, blocked B operand',
+    'library_gemm_f32': 'hipBLASLt fp32 GEMM through torch.matmul (plain [P*A, C*K] operand)',
+    'eap_so3_inter_group_fwd_t_f32': 'so3_group_lists_kernel<false, 2> (v_mfma_f32_32x32x2_f32), transposed output',
     'eap_so3_intra_conv_f32': 'gemm_f32_kernel<GATHER> (v_mfma_f32_32x32x2_f32), implicit intra conv',
     'eap_so3_inter_group_inv_f32': 'so3_group_lists_kernel<true> (v_mfma_f32_32x32x2_f32)',
 }

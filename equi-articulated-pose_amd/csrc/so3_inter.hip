@@ -368,6 +368,14 @@ extern "C" int eap_so3_inter_group_fwd_f32(int b, int c, int p, int n, int nn, i
     return group_fwd_dispatch(0, b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, out, stream);
 }
 
+// same, output transposed: out[b][p*na + a][c*ks + k] -- the plain [P*A, C*K] matrix (B^T of the contraction)
+extern "C" int eap_so3_inter_group_fwd_t_f32(int b, int c, int p, int n, int nn, int na, int ks,
+                                             float sigma, const float *feats, const int32_t *idx,
+                                             const float *gx, const float *rk, const uint8_t *mult,
+                                             const int32_t *nonident, float *out, eap_stream_t stream) {
+    return group_fwd_dispatch(2, b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, out, stream);
+}
+
 // same, output blocked by anchor quads: out[b][p][a/4][c][k][4] (read by eap_gemm_f32_xb)
 extern "C" int eap_so3_inter_group_fwd_xb_f32(int b, int c, int p, int n, int nn, int na, int ks,
                                               float sigma, const float *feats, const int32_t *idx,

@@ -58,9 +58,10 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 
 // LISTS = true : rows / off / cnt describe variable-length entry lists (backward);
 // LISTS = false: row r of cloud b owns entries [ (b*R + r)*nn, +nn ) (forward: its neighbours).
-template <bool LISTS>
+// LAYOUT of the output: 0 = [b,c,k,row,a] (reference), 1 = blocked by anchor quads, 2 = transposed [row*na+a][c*ks+k]
+template <bool LISTS, int LAYOUT>
 __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
-    int C, int PF, int na, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, int blocked, float inv_sigma,
+    int C, int PF, int na, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, float inv_sigma,
     const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
     const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
     const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
@@ -248,7 +249,21 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     const unsigned lane_off_b = (unsigned)((4 * lh) * ks + min(lk, ks - 1)) * 4u;
     auto store_row = [&](int row) {
         if (active && lk < ks) {
-            if (blocked) {
+            if (LAYOUT == 2) {
+                // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix a library
+                // GEMM reads as B^T): for one register r and one anchor the 24 kernel-point lanes of a
+                // channel write 96 contiguous bytes, consecutive channels follow -- dword stores
+                const size_t CK = (size_t)C * ks;
+                float *rb = obb + ((size_t)row * na + a0 + al_beg) * CK + (size_t)c0 * ks;      // uniform
+                const unsigned lo = (unsigned)((4 * lh) * ks + lk);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (full_c || c0 + (r & 3) + 8 * (r >> 2) + 4 * lh < C) {
+#pragma unroll
+                        for (int ai = 0; ai < APW; ++ai)
+                            rb[(size_t)ai * CK + (size_t)((r & 3) + 8 * (r >> 2)) * ks + lo] = acc[ai][r];
+                    }
+            } else if (LAYOUT == 1) {
                 float *rb = obb + (((size_t)row * npq + aq0) * C + c0) * ks * 4;     // uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -342,14 +357,15 @@ int launch(int blocked, int b, int C, int PF, int na, int ks, int R, int nn, int
     if (!geometry(na, ks, g)) return eap::bad_arg("so3_group_lists: unsupported anchor / kernel-point count");
     if ((long long)C * PF * na >= (1ll << 31)) return eap::bad_arg("so3_group_lists: one cloud's features exceed 2^31 elements");
     if (((long long)ks * R * na * 4 + 32ll * R * na + 64) * 4 >= (1ll << 31)) return eap::bad_arg("so3_group_lists: output rows too far apart for 32-bit store offsets");
-    auto kern = so3_group_lists_kernel<LISTS>;
+    auto kern = blocked == 2 ? so3_group_lists_kernel<LISTS, LISTS ? 0 : 2> : blocked == 1 ? so3_group_lists_kernel<LISTS, LISTS ? 0 : 1>
+                                                                                          : so3_group_lists_kernel<LISTS, 0>;
     int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.shmem), what);
     if (e) return e;
     // forward: a workgroup streams through a run of consecutive rows (the next row's entries and
     // first chunk are in flight during the current row's last chunk)
     const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
     dim3 grid((R + RPB - 1) / RPB * g.AG, (C + CB - 1) / CB, b);
-    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, blocked, 1.0f / sigma, F,
+    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
     return eap::check_launch(what);
 }

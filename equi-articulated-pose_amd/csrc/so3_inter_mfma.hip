@@ -249,8 +249,11 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
                     const float *src = s_o + (size_t)row * na + 4 * pc;
                     float *dst = ob + (size_t)ci * o_cs + (size_t)k * o_ks + 4 * pc;
                     // blocked output [b][point][anchor quad][c][k][4] (see csrc/so3_inter_lists.hip)
-                    if (blocked) dst = out + (size_t)bi * c * o_cs + ((((size_t)pi * npiece + pc) * c + ci) * ks + k) * 4;
-                    if (vec_ok) {
+                    if (blocked == 1) dst = out + (size_t)bi * c * o_cs + ((((size_t)pi * npiece + pc) * c + ci) * ks + k) * 4;
+                    if (blocked == 2) {   // transposed output [point*na + a][c*ks + k]
+                        float *dt = out + (size_t)bi * c * o_cs + ((size_t)pi * na + 4 * pc) * ((size_t)c * ks) + (size_t)ci * ks + k;
+                        for (int j = 0; j < 4 && 4 * pc + j < na; ++j) dt[(size_t)j * c * ks] = src[j];
+                    } else if (vec_ok) {
                         *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
                     } else {
                         for (int j = 0; j < 4 && 4 * pc + j < na; ++j) dst[j] = src[j];

@@ -138,7 +138,7 @@ def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=
     p, nn = idx.shape[1], idx.shape[2]
     ks = rk.shape[1]
     out = torch.empty(b, c, ks, p, na, dtype=torch.float32, device=feats.device)
-    call('eap_so3_inter_group_fwd_xb_f32' if blocked else 'eap_so3_inter_group_fwd_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
+    call({0: 'eap_so3_inter_group_fwd_f32', 1: 'eap_so3_inter_group_fwd_xb_f32', 2: 'eap_so3_inter_group_fwd_t_f32'}[int(blocked)], out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
          _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out),
          tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd', b, c, p, nn, na, ks)})
     return out
@@ -232,3 +232,23 @@ def so3_intra_conv(feats, W, intra_idx32):
     call('eap_so3_intra_conv_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats), _ptr(intra_idx32), _ptr(out),
          tag={'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)})
     return out
+
+
+def library_contract(W, xt, y):
+    """y[b] = W @ xt[b]^T  with W [o, ck], xt [b, pa, ck] (the transposed intermediate), y [b, o, pa]:
+    the PLAIN fp32 GEMM of the contraction handed to the vendor library through torch.matmul
+    (hipBLASLt / rocBLAS), exactly what the reference's BasicSO3Conv.forward does
+    (so3conv/modules.py:L48-55).  Timed like the C-ABI launches when bench.py asks for it."""
+    b, pa, ck = xt.shape
+    o = W.shape[0]
+    if KERNEL_TIMES is not None:
+        stream = torch.cuda.current_stream(xt.device)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        torch.matmul(W, xt.transpose(1, 2), out=y)
+        e1.record(stream)
+        KERNEL_TIMES.append(('library_gemm_f32', {'flops': 2.0 * o * pa * ck * b, 'shape': ('gemm_nt', o, pa, ck, b)}, e0, e1))
+    else:
+        torch.matmul(W, xt.transpose(1, 2), out=y)
+    return y

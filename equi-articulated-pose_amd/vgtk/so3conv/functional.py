@@ -260,7 +260,14 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
             cnt_c.to(torch.int32).contiguous(), ent_p, ent_gx, rcap, all_ident)
 
 
-BLOCKED_X = True     # dev knob: keep the fused conv's intermediate in the blocked layout when possible
+# Layout of the fused conv's intermediate X and who contracts it (where the kernels allow it, else the
+# reference layout + own GEMM):
+#   'transposed'  X as the plain [P*A, C*K] matrix, contraction = library GEMM (hipBLASLt via torch.matmul:
+#                 149 TFLOP/s on the deepest layer against 127 for csrc/gemm_f32.hip)
+#   'blocked'     X blocked by anchor quads, contraction = csrc/gemm_f32.hip (eap_gemm_f32_xb)
+#   'reference'   X [C*K, P*A] as the reference's einsum writes it, contraction = csrc/gemm_f32.hip
+X_LAYOUT = 'transposed'
+BLOCKED_X = True     # test knob: False forces the reference layout
 
 
 class _InterConv(torch.autograd.Function):
@@ -274,14 +281,18 @@ class _InterConv(torch.autograd.Function):
         # X is internal to this Function: where the kernels allow it, it is kept blocked by anchor
         # quads ([b,p,a/4,c,k,4]) -- coalesced row-end stores in the grouping kernel -- and the GEMMs
         # read it as a blocked B operand (include/eap_hip.h, "blocked intermediate")
-        blocked = BLOCKED_X and _hip.so3_inter_group_fwd_can_block(feats.shape[1], feats.shape[2], feats.shape[3], rk.shape[1],
-                                                                   mult is not None, nonident is not None)
-        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=blocked)   # [b,c,k,p,a] (nominal)
+        can = BLOCKED_X and X_LAYOUT != 'reference' and _hip.so3_inter_group_fwd_can_block(
+            feats.shape[1], feats.shape[2], feats.shape[3], rk.shape[1], mult is not None, nonident is not None)
+        layout = 0 if not can else (2 if X_LAYOUT == 'transposed' else 1)
+        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=layout)   # [b,c,k,p,a] (nominal shape)
         b, c, ks, p, na = x.shape
         o = W.shape[0]
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=x.device)
-        _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=blocked)
-        ctx.blocked = blocked
+        if layout == 2:
+            _hip.library_contract(W, x.view(b, p * na, c * ks), y.view(b, o, p * na))
+        else:
+            _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
+        ctx.layout = layout
         ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0),
                               nonident if nonident is not None else torch.empty(0))
         ctx.has_mult = mult is not None
@@ -339,7 +350,10 @@ class _InterConv(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[1]:
                 gW = torch.empty_like(W)          # sum_b gy_b x_b^T
-                _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b, b_blocked=ctx.blocked)
+                if ctx.layout == 2:     # X^T [pa, ck]: dW = dY X^T is a plain row-major product
+                    _hip.gemm_reduce(0, 0, o, ck, pa, gy, pa, o * pa, x, ck, ck * pa, gW, ck, b)
+                else:
+                    _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b, b_blocked=ctx.layout == 1)
             if ctx.needs_input_grad[0]:
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)

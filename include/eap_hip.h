@@ -225,6 +225,11 @@ int eap_so3_inter_group_fwd_xb_f32(int b, int c, int p, int n, int nn, int na, i
                                    const float *feats, const int32_t *idx, const float *gx,
                                    const float *rk, const uint8_t *mult, const int32_t *nonident,
                                    float *out, eap_stream_t stream);
+/* same, output transposed: out[b][p*na + a][c*ks + k] (a plain row-major [P*A, C*K] matrix) */
+int eap_so3_inter_group_fwd_t_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma,
+                                  const float *feats, const int32_t *idx, const float *gx,
+                                  const float *rk, const uint8_t *mult, const int32_t *nonident,
+                                  float *out, eap_stream_t stream);
 /* eap_gemm_f32 / eap_gemm_f32_reduce with B blocked by 4: element (row r of b_block_rows, position x)
  * at (x >> 2) * b_block_rows * 4 + r * 4 + (x & 3); b_block_rows = K (transB = 0) or N (transB = 1). */
 int eap_gemm_f32_xb(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,

@@ -234,7 +234,7 @@ def _run_layer(vg, dev, g):
     return conv, feats, conv(x)
 
 
-@pytest.mark.parametrize('blocked', [True, False])
+@pytest.mark.parametrize('blocked', ['transposed', 'blocked', 'reference'])
 @pytest.mark.parametrize('mode', ['dx', 'inverse'])
 @pytest.mark.parametrize('name', INTER_CASES)
 def test_inter_pose_layer_golden(dev, vg, golden, name, mode, blocked, monkeypatch):
@@ -243,7 +243,7 @@ def test_inter_pose_layer_golden(dev, vg, golden, name, mode, blocked, monkeypat
     intermediate in the blocked layout and in the reference layout."""
     _, _, _, L = vg
     monkeypatch.setattr(L, 'BACKWARD_MODE', mode)
-    monkeypatch.setattr(L, 'BLOCKED_X', blocked)
+    monkeypatch.setattr(L, 'X_LAYOUT', blocked)
     g = golden(name + '.npz')
     conv, feats, (inter_idx, inter_w, sample_idx, y) = _run_layer(vg, dev, g)
     assert inter_idx is None and sample_idx is None            # reference stride-1 return values
