@@ -252,3 +252,18 @@ def library_contract(W, xt, y):
     else:
         torch.matmul(W, xt.transpose(1, 2), out=y)
     return y
+
+
+def library_matmul(a, bmat, out):
+    """torch.matmul(a, bmat, out=out) with the bench's timing hook (plain GEMMs only)."""
+    if KERNEL_TIMES is not None:
+        stream = torch.cuda.current_stream(bmat.device)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r = torch.matmul(a, bmat, out=out) if out is not None else torch.matmul(a, bmat)
+        e1.record(stream)
+        fl = 2.0 * r.numel() * a.shape[-1]
+        KERNEL_TIMES.append(('library_gemm_f32', {'flops': fl, 'shape': ('matmul',) + tuple(a.shape) + tuple(bmat.shape)}, e0, e1))
+        return r
+    return torch.matmul(a, bmat, out=out) if out is not None else torch.matmul(a, bmat)

@@ -267,6 +267,7 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
 #   'blocked'     X blocked by anchor quads, contraction = csrc/gemm_f32.hip (eap_gemm_f32_xb)
 #   'reference'   X [C*K, P*A] as the reference's einsum writes it, contraction = csrc/gemm_f32.hip
 X_LAYOUT = 'transposed'
+LIBRARY_SMALL_GEMMS = True    # the two Z-based gradient GEMMs (plain row-major operands) through the library as well; False: csrc/gemm_f32.hip
 BLOCKED_X = True     # test knob: False forces the reference layout
 
 
@@ -336,7 +337,10 @@ class _InterConv(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
-                _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
+                if LIBRARY_SMALL_GEMMS:
+                    _hip.library_matmul(W2, z.view(b, o * ks, ra), gFc)
+                else:
+                    _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
                 # rows of unused slots are exactly zero (Z is), so adding them to row 0 is harmless
                 gF = torch.zeros(b, c, n, na, dtype=torch.float32, device=gy.device)
                 gF.scatter_add_(2, dest4, gFc.view(b, c, rcap, na))
@@ -344,8 +348,11 @@ class _InterConv(torch.autograd.Function):
                 feats = ctx.feats_ref
                 fc = torch.gather(feats, 2, dest4)                                   # [b,c,rcap,na]; unused slots meet zero rows of Z
                 fc = fc.reshape(b, c, ra)
-                d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
-                _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
+                if LIBRARY_SMALL_GEMMS:
+                    d = _hip.library_matmul(z.view(b, o * ks, ra), fc.transpose(1, 2), None).sum(0)
+                else:
+                    d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
+                    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
                 gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
         else:
             if ctx.needs_input_grad[1]:
