@@ -225,14 +225,14 @@ def zpconv_roofline(dev, points, clouds=2, channels=64):
 KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
     'eap_gemm_f32': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
     'eap_gemm_f32_reduce': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K',
-    'eap_so3_inter_group_fwd_f32': 'so3_group_lists_kernel<false> (v_mfma_f32_32x32x2_f32)',
-    'eap_so3_inter_group_fwd_xb_f32': 'so3_group_lists_kernel<false> (v_mfma_f32_32x32x2_f32), blocked output',
+    'eap_so3_inter_group_fwd_f32': 'so3_group_lists_kernel<false, 0> (v_mfma_f32_32x32x2_f32)',
+    'eap_so3_inter_group_fwd_xb_f32': 'so3_group_lists_kernel<false, 1> (v_mfma_f32_32x32x2_f32), blocked output',
     'eap_gemm_f32_xb': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), blocked B operand',
     'eap_gemm_f32_reduce_xb': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K, blocked B operand',
     'library_gemm_f32': 'hipBLASLt fp32 GEMM through torch.matmul (plain [P*A, C*K] operand)',
     'eap_so3_inter_group_fwd_t_f32': 'so3_group_lists_kernel<false, 2> (v_mfma_f32_32x32x2_f32), transposed output',
     'eap_so3_intra_conv_f32': 'gemm_f32_kernel<GATHER> (v_mfma_f32_32x32x2_f32), implicit intra conv',
-    'eap_so3_inter_group_inv_f32': 'so3_group_lists_kernel<true> (v_mfma_f32_32x32x2_f32)',
+    'eap_so3_inter_group_inv_f32': 'so3_group_lists_kernel<true, 0> (v_mfma_f32_32x32x2_f32)',
 }
 
 
@@ -341,7 +341,7 @@ def main():
         # fabric-side bytes per launch of the dominant entry, from the rocprofv3 FETCH_SIZE /
         # WRITE_SIZE passes committed under profiles/ (collected at the default workload only)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_l_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_p_pmc_traffic.json')
         if os.path.exists(pmc) and args.points == 4096 and args.batch == 8 and not args.fwd_only:
             d = json.load(open(pmc))['per_launch_bytes'].get(dom_name)
             if d:
