@@ -292,6 +292,9 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
             for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
     };
 
+    // the hardware favours the older waves of a SIMD; the younger half would otherwise reach every chunk
+    // barrier last
+    if (wave_u >= NWV / 2) __builtin_amdgcn_s_setprio(2);
     int g0 = 0, g1 = 1, g2 = 2;                           // ring slots of chunks ch, ch+1, ch+2
     int ch_row = 0, row = r_begin;
     for (int ch = 0; ch < nchunk; ++ch) {
