@@ -219,6 +219,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         }
         // unguarded: a wave whose last anchors fall off the group repeats its last one into
         // accumulators the epilogue never stores
+        __builtin_amdgcn_s_setprio(3);                      // a wave with MFMAs ready goes first (-2.5 % on one box, A/B)
 #pragma unroll
         for (int ai = 0; ai < APW / 2; ++ai)
             acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
 #pragma unroll
         for (int ai = APW / 2; ai < APW; ++ai)
             acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+        if (wave_u >= NWV / 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
         end();
     };
 
