@@ -664,3 +664,55 @@ def test_orbit_reconstruction_distances(dev, vg, shape):
     sum((v * w).sum() for v, w in zip(want, finite)).backward()
     sum((u * w.to(dev)).sum() for u, w in zip(got, finite)).backward()
     np.testing.assert_allclose(rg.grad.cpu().numpy(), rc.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_three_block_backbone_end_to_end_vs_oracle(dev, vg):
+    """The whole hot path composed as bench.py runs it -- 3 x (InterSO3PoseConv -> BatchNorm2d ->
+    leaky_relu) with the fused grouping, the transposed intermediate, the library contraction and the
+    fused block epilogue -- against the torch-CPU oracle layer by layer (256-point clouds, channel
+    plan 1 -> 16 -> 32 -> 24): the feature maps the pose head would read, within 1e-4 of their
+    magnitude, and the gradients of the first two layers' weights."""
+    import synth_clouds
+    _, sptk, zptk, L = vg
+    P = 256
+    xyz, _, pose = synth_clouds.laptop_batch(11, 2, P)
+    plan = [(1, 16), (16, 32), (32, 24)]
+    params = synth_clouds.backbone_layers(512)
+    torch.manual_seed(5)
+    convs = [sptk.InterSO3PoseConv(c, o, 1, 1, params[i][2], params[i][3], 64, kanchor=60, permute_modes=1) for i, (c, o) in enumerate(plan)]
+    bns = [torch.nn.BatchNorm2d(o) for _, o in plan]
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.2, 0.2)
+    # oracle: CPU, reference formulation
+    Ws = [cv.basic_conv.W.detach().clone().requires_grad_(True) for cv in convs]
+    f = torch.ones(2, 1, P, 60)
+    outs_ref = []
+    for i, cv in enumerate(convs):
+        y = so3_ref.inter_so3poseconv_layer(T(xyz), T(pose), f, Ws[i], cv.anchors, cv.kernels, params[i][2], params[i][3], 64,
+                                            permute_modes=1, chunk=64, skip_perm_search=True)
+        f = torch.nn.functional.leaky_relu(bns[i](y), 0.01)
+        outs_ref.append(f)
+    g_out = torch.randn_like(f)
+    gW_ref = torch.autograd.grad(f, Ws[:2], g_out)
+    # build under test
+    fused = []
+    for i, (_, o) in enumerate(plan):
+        m = sptk.BatchNormLeakyReLU(o, negative_slope=0.01)
+        bn_fresh = torch.nn.BatchNorm2d(o)
+        bn_fresh.load_state_dict({k: (v if 'running' not in k and 'num_batches' not in k else bn_fresh.state_dict()[k]) for k, v in bns[i].state_dict().items()})
+        m.load_state_dict(bn_fresh.state_dict())
+        fused.append(m.to(dev))
+    convs = [cv.to(dev) for cv in convs]
+    x = zptk.SphericalPointCloudPose(T(xyz).to(dev), torch.ones(2, 1, P, 60, device=dev), None, T(pose).to(dev))
+    outs = []
+    for cv, m in zip(convs, fused):
+        _, _, _, x = cv(x)
+        x = zptk.SphericalPointCloudPose(x.xyz, m(x.feats), x.anchors, x.pose)
+        outs.append(x.feats)
+    for got, want in zip(outs, outs_ref):
+        assert rel_err(got.detach().cpu().numpy(), want.detach().numpy()) < 1e-4
+    gW = torch.autograd.grad(outs[-1], [convs[0].basic_conv.W, convs[1].basic_conv.W], g_out.to(dev))
+    for got, want in zip(gW, gW_ref):
+        assert rel_err(got.cpu().numpy(), want.numpy()) < 2e-4
