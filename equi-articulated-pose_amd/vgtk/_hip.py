@@ -189,6 +189,43 @@ def so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, sigma, n
     return z
 
 
+def inv_lists_rows(idx, n):
+    """idx int32 [b,p,nn] -> rows, off, cnt [b,n] and n_rows [b] (csrc/inv_lists.hip); no host sync."""
+    b, p, nn = idx.shape
+    dev = idx.device
+    counts = torch.empty(b, n, dtype=torch.int32, device=dev)
+    rows, off, cnt = torch.empty_like(counts), torch.empty_like(counts), torch.empty_like(counts)
+    n_rows = torch.empty(b, dtype=torch.int32, device=dev)
+    call('eap_inv_lists_rows', idx, b, p, n, nn, _ptr(idx), _ptr(counts), _ptr(rows), _ptr(off), _ptr(cnt), _ptr(n_rows))
+    return rows, off, cnt, n_rows
+
+
+def inv_lists_fill(idx, gx, rows, off, rcap):
+    """-> ent_p int32 [b,p*nn], ent_gx [b,p*nn,4] for the first rcap rows of every cloud."""
+    b, p, nn = idx.shape
+    n = rows.shape[1]
+    ent_p = torch.empty(b, p * nn, dtype=torch.int32, device=idx.device)
+    ent_gx = torch.empty(b, p * nn, 4, dtype=torch.float32, device=idx.device)
+    call('eap_inv_lists_fill', idx, b, p, n, nn, int(rcap), _ptr(idx), _ptr(gx), _ptr(rows), _ptr(off), _ptr(ent_p), _ptr(ent_gx))
+    return ent_p, ent_gx
+
+
+def rows_gather(src, rows, rcap):
+    """src [b,c,n,na], rows int32 [b,>=rcap] -> [b,c,rcap,na] (zeros for rows < 0)."""
+    b, c, n, na = src.shape
+    dst = torch.empty(b, c, rcap, na, dtype=torch.float32, device=src.device)
+    call('eap_rows_gather_f32', src, b, c, n, na, int(rcap), rows.stride(0), _ptr(rows), _ptr(src), _ptr(dst))
+    return dst
+
+
+def rows_scatter(src, rows, n):
+    """src [b,c,rcap,na] -> [b,c,n,na], zero except the rows named by `rows`."""
+    b, c, rcap, na = src.shape
+    dst = torch.empty(b, c, n, na, dtype=torch.float32, device=src.device)
+    call('eap_rows_scatter_f32', src, b, c, n, na, int(rcap), rows.stride(0), _ptr(rows), _ptr(src), _ptr(dst))
+    return dst
+
+
 # ---- block-layer epilogue (csrc/bn_act.hip) -------------------------------------------------------
 
 def _partials(x, b, c, n):

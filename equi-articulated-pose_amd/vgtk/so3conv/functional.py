@@ -14,6 +14,7 @@ Differences a caller can observe (all documented in DESIGN.md):
   * float32 device tensors only -- there is no CPU path.
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -71,6 +72,75 @@ def get_sphereical_kernel_points_from_ply(radius, kernel_size):
     return pts * radius / r
 
 
+def get_2D_res_anchors():
+    """4 rotations about the y axis by multiples of 90 degrees (functional.py:L29-46) -> [4,3,3]."""
+    mats = []
+    for i in range(4):
+        th = i * (np.pi / 2.)
+        c, s_ = np.cos(th), np.sin(th)
+        mats.append(torch.from_numpy(np.array([[c, 0., s_], [0., 1., 0.], [-s_, 0., c]], dtype=np.float64)).float().unsqueeze(0))
+    return torch.cat(mats, dim=0)
+
+
+RES_ROT_2D = get_2D_res_anchors()
+
+
+def get_kernel_points_np(radius, aperature, kernel_size, multiplier=1):
+    """(x,y,z) kernel points from the conic parameterisation (functional.py:L73-89)."""
+    assert isinstance(kernel_size, int)
+    rrange = np.linspace(0, radius, kernel_size, dtype=np.float32)
+    kps = []
+    for ridx, ri in enumerate(rrange):
+        alpharange = zpconv.get_angular_kernel_points_np(aperature, ridx * multiplier + 1)
+        for aidx, alpha in enumerate(alpharange):
+            r_r = ri * np.tan(alpha)
+            thetarange = np.linspace(0, 2 * np.pi, aidx * 2 + 1, endpoint=False, dtype=np.float32)
+            kps.append(np.vstack([r_r * np.cos(thetarange), r_r * np.sin(thetarange), np.repeat(ri, aidx * 2 + 1)]).T)
+    return np.vstack(kps)
+
+
+def get_spherical_kernel_points_np(radius, kernel_size, multiplier=3):
+    """Kernel points on concentric spheres (functional.py:L91-109)."""
+    assert isinstance(kernel_size, int)
+    rrange = np.linspace(0, radius, kernel_size, dtype=np.float32)
+    kps = []
+    for ridx, r_i in enumerate(rrange):
+        asize = bsize = ridx * multiplier + 1
+        alpharange = np.linspace(0, 2 * np.pi, asize, endpoint=False, dtype=np.float32)
+        betarange = np.linspace(0, np.pi, bsize, endpoint=True, dtype=np.float32)
+        xs = r_i * np.cos(alpharange[:, None]) * np.sin(betarange[None])
+        ys = r_i * np.sin(alpharange[:, None]) * np.sin(betarange[None])
+        zs = r_i * np.cos(betarange)[None].repeat(asize, axis=0)
+        kps.append(np.vstack([xs.reshape(-1), ys.reshape(-1), zs.reshape(-1)]).T)
+    return np.vstack(kps)
+
+
+def initial_anchor_query(frag, centers, kernels, r, sigma):
+    """frag [m,3], centers [b,3,nc], kernels [ks,na,3] -> (w, cnt) [b,ks,nc,na] (functional.py:L129-130)."""
+    return cuda_nn.initial_anchor_query(centers, frag, kernels, r, sigma)
+
+
+def inter_so3conv_blurring(xyz, feats, n_neighbor, radius, stride, inter_idx=None, lazy_sample=True,
+                           radius_expansion=1.0):
+    """Low-pass blur / pool before a strided conv (functional.py:L133-141)."""
+    sample_idx = sample_xyz = None
+    if inter_idx is None:
+        _, inter_idx, sample_idx, sample_xyz = zpconv.inter_zpconv_grouping_ball(xyz, stride, radius * radius_expansion,
+                                                                               n_neighbor, lazy_sample)
+    if stride == 1:
+        return zpconv.inter_blurring_naive(inter_idx, feats), xyz
+    return zpconv.inter_pooling_naive(inter_idx, sample_idx, feats), sample_xyz
+
+
+def canonicalize_points(xyz, pose):
+    """R^T (x - t) per point (functional.py:L206-214): xyz [b,3,p], pose [b,p,4,4] -> [b,3,p]."""
+    rotations = pose[:, :, :3, :3]
+    translations = pose[:, :, :3, -1]
+    cana = torch.matmul(torch.transpose(rotations, 2, 3),
+                        (xyz.contiguous().transpose(1, 2).contiguous() - translations).unsqueeze(-1)).squeeze(-1)
+    return cana.contiguous().transpose(1, 2).contiguous()
+
+
 def get_occupancy_features(pc, n_anchor, use_center=False):
     """pc [nb,np,3] -> ones [nb,1,np,na] (functional.py:L50-69; normals are not supported --
     the reference branch for them is broken: `ns.anchors` at L61)."""
@@ -91,10 +161,12 @@ _TABLES = {}
 
 def _group_tables(anchors):
     """mult table (uint8 [na,na]) + identity index when `anchors` is a group, else (None, None)."""
-    key = (anchors.data_ptr(), anchors.device, anchors.shape[0])
+    # keyed on the tensor OBJECT and its version counter (a load_state_dict / copy_ into the buffer bumps
+    # the version; a recycled allocation is a different object), never on the data pointer
+    key = (id(anchors), anchors._version, str(anchors.device), anchors.shape[0])
     hit = _TABLES.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is anchors:
+        return hit[1]
     A = anchors.detach().double().cpu().numpy()
     na = A.shape[0]
     prod = np.einsum('gij,ajk->gaik', A, A)
@@ -107,8 +179,28 @@ def _group_tables(anchors):
         out = (torch.from_numpy(mult.astype(np.uint8)).to(anchors.device).contiguous(), ident)
     else:
         out = (None, None)
-    _TABLES[key] = out
+    if len(_TABLES) > 256:
+        _TABLES.clear()
+    _TABLES[key] = (weakref.ref(anchors), out)
     return out
+
+
+_MULTINV = {}
+
+
+def _group_tables_inverse(mult):
+    """multinv[r][a'] = a with mult[r][a] = a' (the inverse permutation of every row), cached per table."""
+    key = (id(mult), mult._version)
+    hit = _MULTINV.get(key)
+    if hit is not None and hit[0]() is mult:
+        return hit[1]
+    na = mult.shape[0]
+    multinv = torch.empty_like(mult)
+    multinv.scatter_(1, mult.long(), torch.arange(na, device=mult.device, dtype=torch.uint8).repeat(na, 1))
+    if len(_MULTINV) > 256:
+        _MULTINV.clear()
+    _MULTINV[key] = (weakref.ref(mult), multinv)
+    return multinv
 
 
 def rotated_kernels(anchors, kernels):
@@ -226,38 +318,49 @@ BACKWARD_MODE = 'auto'      # 'auto' | 'inverse' | 'dx'
 INV_ROW_FRACTION = 4
 
 
+INV_LISTS_MAX_ROWS = 16384      # csrc/inv_lists.hip sorts a cloud's support rows in LDS
+
+
+def _inv_lists_supported(idx, n_sup, na, ks):
+    return na % 4 == 0 and ks <= 32 and n_sup <= INV_LISTS_MAX_ROWS and (idx.shape[1] * idx.shape[2]) % 4 == 0
+
+
+class _ListHead:
+    """First half of the inverse neighbour lists of idx [b,p,nn] (csrc/inv_lists.hip): per cloud the
+    referenced support rows (longest list first), their counts and offsets -- all on the device -- plus an
+    ASYNCHRONOUS copy of the two numbers the backward's launch decisions need on the host (the largest
+    number of referenced rows of a cloud; whether any cloud carries non-identity relative rotations).
+    Built in the forward, read in the backward: by then the copy has long landed, so nothing stalls."""
+
+    def __init__(self, idx, n_sup, nonident):
+        self.rows, self.off, self.cnt, self.n_rows = _hip.inv_lists_rows(idx, n_sup)
+        flag = nonident.max() if nonident is not None else torch.ones((), dtype=torch.int32, device=idx.device)
+        stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32)])
+        self.host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        self.host.copy_(stats, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(idx.device))
+
+    def decide(self):
+        """-> (rcap, any_nonident) as Python values."""
+        self.event.synchronize()
+        rcap, flag = self.host.tolist()
+        return int(rcap), bool(flag)
+
+
 def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
-    """Inverse neighbour lists of idx [b,p,nn] (which (point, slot) pairs reference each support
-    row), with the referenced rows compacted.  Small torch plumbing on the device; ONE host sync
-    (the number of referenced rows sizes the workspace)."""
-    b, p, nn = idx.shape
-    keys = idx.reshape(b, p * nn).long()
-    skeys, order = torch.sort(keys, dim=1, stable=True)          # entries of a row stay in (p,n) order
-    counts = torch.zeros(b, n_sup + 1, dtype=torch.int64, device=idx.device)
-    counts.scatter_add_(1, keys.clamp(max=n_sup), torch.ones_like(keys))
-    counts = counts[:, :n_sup]
-    offs = torch.cumsum(counts, 1) - counts
-    nonempty = counts > 0
-    n_rows = nonempty.sum(1)
-    # one host sync for both facts the launch needs: workspace rows, and whether any relative
-    # rotation differs from the identity (if none does, the permutation table is skipped)
-    if nonident is not None:
-        all_ident = (nonident == 0).all()
-    else:
-        all_ident = (gx[..., 3].contiguous().view(torch.int32) == ident).all()
-    rcap, all_ident = torch.stack([n_rows.max(), all_ident.to(n_rows.dtype)]).tolist()
-    rcap, all_ident = int(rcap), bool(all_ident)
-    # referenced rows first, longest entry list first: neighbouring blocks then walk the query
-    # points at the same pace (shared L2 window, csrc/so3_inter_inv.hip) and the long lists start early
-    rows = torch.argsort(counts, dim=1, descending=True, stable=True)[:, :rcap]
-    valid = torch.arange(rcap, device=idx.device)[None, :] < n_rows[:, None]
-    off_c = torch.gather(offs, 1, rows)
-    cnt_c = torch.gather(counts, 1, rows) * valid
-    rows_c = torch.where(valid, rows, torch.full_like(rows, -1))
-    ent_p = torch.div(order, nn, rounding_mode='floor').to(torch.int32).contiguous()
-    ent_gx = torch.gather(gx.reshape(b, p * nn, 4), 1, order[..., None].expand(-1, -1, 4)).contiguous()
-    return (rows_c.to(torch.int32).contiguous(), off_c.to(torch.int32).contiguous(),
-            cnt_c.to(torch.int32).contiguous(), ent_p, ent_gx, rcap, all_ident)
+    """Inverse neighbour lists of idx [b,p,nn] (which (point, slot) pairs reference each support row), the
+    referenced rows compacted and ordered longest list first; entries of a row in (p, slot) order.
+    Convenience form for tests and tools (blocks on the host for the row count); the fused conv uses
+    _ListHead + _hip.inv_lists_fill without blocking.
+    -> rows, off, cnt int32 [b,rcap]; ent_p int32 [b,p*nn]; ent_gx [b,p*nn,4]; rcap; all_ident."""
+    if nonident is None:
+        nonident = (gx[..., 3].contiguous().view(torch.int32) != ident).flatten(1).any(1).to(torch.int32)
+    head = _ListHead(idx, n_sup, nonident)
+    rcap, any_nonident = head.decide()
+    ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
+    return (head.rows[:, :rcap].contiguous(), head.off[:, :rcap].contiguous(), head.cnt[:, :rcap].contiguous(),
+            ent_p, ent_gx, rcap, not any_nonident)
 
 
 # Layout of the fused conv's intermediate X and who contracts it (where the kernels allow it, else the
@@ -266,8 +369,8 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
 #                 149 TFLOP/s on the deepest layer against 127 for csrc/gemm_f32.hip)
 #   'blocked'     X blocked by anchor quads, contraction = csrc/gemm_f32.hip (eap_gemm_f32_xb)
 #   'reference'   X [C*K, P*A] as the reference's einsum writes it, contraction = csrc/gemm_f32.hip
-X_LAYOUT = 'transposed'
-LIBRARY_SMALL_GEMMS = True    # the two Z-based gradient GEMMs (plain row-major operands) through the library as well; False: csrc/gemm_f32.hip
+X_LAYOUT = os.environ.get('EAP_X_LAYOUT', 'transposed')
+LIBRARY_SMALL_GEMMS = os.environ.get('EAP_LIBRARY_GEMMS', '1') != '0'   # the two Z-based gradient GEMMs (plain row-major operands) through the library as well; False: csrc/gemm_f32.hip
 BLOCKED_X = True     # test knob: False forces the reference layout
 
 
@@ -294,17 +397,23 @@ class _InterConv(torch.autograd.Function):
         else:
             _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
         ctx.layout = layout
+        # feats: needed by the re-associated weight gradient (saved, not copied: autograd's version check
+        # then catches an in-place update of the previous block's output)
         ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0),
-                              nonident if nonident is not None else torch.empty(0))
+                              nonident if nonident is not None else torch.empty(0), feats)
         ctx.has_mult = mult is not None
         ctx.has_flag = nonident is not None
-        ctx.feats_ref = feats          # needed by the re-associated weight gradient (not a new copy)
         ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
+        # inverse neighbour lists, first half (device only; the host-side numbers arrive asynchronously)
+        ctx.head = None
+        if BACKWARD_MODE != 'dx' and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and \
+                _inv_lists_supported(idx, feats.shape[2], na, ks):
+            ctx.head = _ListHead(idx, feats.shape[2], nonident)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        W, x, idx, gx, rk, mult, nonident = ctx.saved_tensors
+        W, x, idx, gx, rk, mult, nonident, feats = ctx.saved_tensors
         mult = mult if ctx.has_mult else None
         nonident = nonident if ctx.has_flag else None
         gy = gy.contiguous()
@@ -318,22 +427,19 @@ class _InterConv(torch.autograd.Function):
         #     dF[c,q,a'] = sum_{o,k} W[o,(c,k)] Z[o,k,q,a']       dW[o,(c,k)] = sum_{q,a'} Z[o,k,q,a'] F[c,q,a']
         # two small GEMMs over the referenced rows only -- no dX = W^T dY, no scatter, and the
         # [O x P*A] x [P*A x C*K] weight-gradient GEMM shrinks by P / (referenced rows).
-        inv = None
-        if BACKWARD_MODE != 'dx' and na % 4 == 0 and ks <= 32 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            inv = _inverse_lists(idx, gx, n, ctx.ident, nonident)
-            if BACKWARD_MODE == 'auto' and inv[5] * INV_ROW_FRACTION > n:
-                inv = None
-        if inv is not None:
-            rows, off, cnt, ent_p, ent_gx, rcap, all_ident = inv
-            multinv = None
-            if mult is not None and not all_ident:   # multinv[r][a'] = a  with  mult[r][a] = a'
-                multinv = torch.empty_like(mult)
-                multinv.scatter_(1, mult.long(), torch.arange(na, device=mult.device, dtype=torch.uint8).repeat(na, 1))
+        head, rcap, any_nonident = ctx.head, 0, True
+        if head is not None:
+            rcap, any_nonident = head.decide()
+            if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
+                head = None
+        if head is not None:
+            rows = head.rows[:, :rcap].contiguous()
+            off, cnt = head.off[:, :rcap].contiguous(), head.cnt[:, :rcap].contiguous()
+            ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
+            multinv = _group_tables_inverse(mult) if (mult is not None and any_nonident) else None
             z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
                                          ctx.ident)                                  # [b,o,ks,rcap,na]
             ra = rcap * na
-            dest = rows.clamp(min=0).long()                                           # unused slots (rows < 0) carry zeros in Z
-            dest4 = dest[:, None, :, None].expand(b, c, rcap, na)
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
@@ -341,13 +447,9 @@ class _InterConv(torch.autograd.Function):
                     _hip.library_matmul(W2, z.view(b, o * ks, ra), gFc)
                 else:
                     _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
-                # rows of unused slots are exactly zero (Z is), so adding them to row 0 is harmless
-                gF = torch.zeros(b, c, n, na, dtype=torch.float32, device=gy.device)
-                gF.scatter_add_(2, dest4, gFc.view(b, c, rcap, na))
+                gF = _hip.rows_scatter(gFc.view(b, c, rcap, na), rows, n)           # unreferenced rows: zero gradient
             if ctx.needs_input_grad[1]:
-                feats = ctx.feats_ref
-                fc = torch.gather(feats, 2, dest4)                                   # [b,c,rcap,na]; unused slots meet zero rows of Z
-                fc = fc.reshape(b, c, ra)
+                fc = _hip.rows_gather(feats, rows, rcap).view(b, c, ra)              # [b,c,rcap*na]; unused slots: zeros
                 if LIBRARY_SMALL_GEMMS:
                     d = _hip.library_matmul(z.view(b, o * ks, ra), fc.transpose(1, 2), None).sum(0)
                 else:
@@ -477,6 +579,17 @@ def intra_so3conv_grouping(intra_idx, feature):
     if feature.dtype != torch.float32 or not feature.is_cuda:
         raise RuntimeError('intra_so3conv_grouping: float32 device tensors only')
     return _IntraGroup.apply(feature, intra_idx.to(torch.int32).contiguous())
+
+
+def intra_so3conv_grouping_2D(intra_idx, feature):
+    """The 2-D variant (functional.py:L2606-2628): the anchor axis is (na, 4); the 12-tap gather acts on na.
+    feature [nb,c,np,na*4] -> [nb,c,pnn,np,na*4].  Index plumbing only (a view + one gather)."""
+    nb, c_in, nq, tot_na = feature.shape
+    f = feature.contiguous().view(nb, c_in, nq, -1, 4)
+    na = f.size(-2)
+    _, pnn = intra_idx.shape
+    f1 = f.index_select(3, intra_idx.view(-1)).view(nb, c_in, nq, na, pnn, 4)
+    return f1.permute([0, 1, 4, 2, 3, 5]).contiguous().view(nb, c_in, pnn, nq, tot_na).contiguous()
 
 
 def anchor_permutation_index(xyz, pose, n_neighbor, anchors, radius):

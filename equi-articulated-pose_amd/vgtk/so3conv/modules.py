@@ -35,6 +35,35 @@ class BasicSO3Conv(nn.Module):
         return y.view(bs, self.dim_out, np_, na)
 
 
+class KernelPropagation(nn.Module):
+    """Initial features from a point fragment (modules.py:L57-119): kernel-weight query around `n_center`
+    centres (native initial_anchor_query, csrc/grouping.hip) -> BasicSO3Conv over the kernel axis."""
+
+    def __init__(self, dim_in, dim_out, n_center, kernel_size, radius, sigma, kanchor=60):
+        super(KernelPropagation, self).__init__()
+        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+        anchors = L.get_anchors(kanchor)
+        kernels = np.transpose(anchors @ kernels.T, (2, 0, 1))          # [ks, na, 3]
+        self.radius = radius
+        self.sigma = sigma
+        self.n_center = n_center
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        self.register_buffer('kernels', torch.from_numpy(np.ascontiguousarray(kernels)))
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, kernels.shape[0])
+
+    def _subsample(self, clouds):
+        idx, sample_xyz = pctk.furthest_sample(clouds, self.n_center, False)
+        return sample_xyz
+
+    def forward(self, frag, clouds):
+        """frag [m,3], clouds [b,3,n] -> SphericalPointCloud(centers [b,3,nc], feats [b,c_out,nc,na])."""
+        centers = clouds if clouds.shape[2] == self.n_center else self._subsample(clouds)
+        wts, nnctn = L.initial_anchor_query(frag, centers, self.kernels, self.radius, self.sigma)
+        wts = wts / (nnctn + 1.0)
+        feats = self.basic_conv(wts.unsqueeze(1))
+        return SphericalPointCloud(centers, feats, self.anchors)
+
+
 class InterSO3Conv(nn.Module):
     """Pose-free inter conv (modules.py:L125-174)."""
 
@@ -138,6 +167,26 @@ class IntraSO3Conv(nn.Module):
         else:
             feats = L.intra_so3conv_grouping(self.intra_idx, x.feats)
             feats = self.basic_conv(feats)
+        return SphericalPointCloud(x.xyz, feats, self.anchors)
+
+
+class IntraSO3Conv2D(nn.Module):
+    """IntraSO3Conv on an anchor axis of (60, 4) in-plane residual rotations (modules.py:L350-373)."""
+
+    def __init__(self, dim_in, dim_out):
+        super(IntraSO3Conv2D, self).__init__()
+        anchors = L.get_anchors()
+        intra_idx = L.get_intra_idx()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.kernel_size = intra_idx.shape[1]
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
+        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
+
+    def forward(self, x):
+        feats = L.intra_so3conv_grouping_2D(self.intra_idx, x.feats)
+        feats = self.basic_conv(feats)
         return SphericalPointCloud(x.xyz, feats, self.anchors)
 
 

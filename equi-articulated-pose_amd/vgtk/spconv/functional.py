@@ -83,7 +83,9 @@ def intra_zpconv_grouping(intra_idx, intra_w, feats):
     return IntraZPConvGrouping.apply(intra_idx, intra_w, feats)
 
 
-def inter_zpconv_grouping(inter_idx, inter_w, feats):
+def inter_zpconv_grouping_native(inter_idx, inter_w, feats):
+    """5-D index / weights [b,p,a,k,ann] + feats [b,c,q,a] -> [b,c,k,p,a] through the native op with autograd
+    (the commented-out `InterZPConvGrouping.apply` call of functional.py:L602)."""
     return InterZPConvGrouping.apply(inter_idx, inter_w, feats)
 
 
@@ -234,3 +236,104 @@ def compute_anchor_weights(anchor_in, anchor_out, k=3, sigma=1e-1, interpolation
 def anchor_prop(x, idx, w):
     """[b,c,p,a1] -> [b,c,p,a2] 3-NN interpolation over anchors."""
     return (x[:, :, :, idx] * w).sum(-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# S^2 anchors and kernels of the ZP convolution (functional.py:L20-66) -- host-side tables
+# ------------------------------------------------------------------------------------------------
+_SPHERES = None
+
+
+def get_anchors(anchor):
+    """int (12 / 42 / 92 / 162: vertices of the icosphere data file with norm > 0.5, normalised), a PLY path,
+    or a tensor -> [na, 3] CPU tensor (functional.py:L20-39)."""
+    global _SPHERES
+    if isinstance(anchor, torch.Tensor):
+        return anchor.detach().cpu()
+    if isinstance(anchor, int):
+        if _SPHERES is None:
+            import os
+            import vgtk
+            _SPHERES = np.load(os.path.join(vgtk.__path__[0], 'data', 'anchors', 'constants.npz'))
+        key = 'sphere%d_vertices' % anchor
+        if key not in _SPHERES.files:
+            raise ValueError('no S^2 anchor set with %d directions (12, 42, 92, 162)' % anchor)
+        pts = _SPHERES[key].astype('float32')
+    elif isinstance(anchor, str):
+        pts = pctk.load_ply(anchor).astype('float32')
+    else:
+        raise ValueError(f'Not recognized anchor type {type(anchor)}')
+    norms = np.sqrt(np.sum(pts ** 2, axis=1))
+    keep = np.where(norms > 0.5)
+    return torch.from_numpy(pts[keep] / np.expand_dims(norms[keep], 1))
+
+
+def get_kernel_rings_np(radius, aperature, kernel_size, multiplier=1):
+    """(radius, polar angle) kernel points of the inter ZP conv (functional.py:L42-61) -> [ks, 2]."""
+    if isinstance(kernel_size, int):
+        rrange = np.linspace(0, radius, kernel_size + 2, dtype=np.float32)[1:-1]
+        kps = []
+        for ri in range(kernel_size):
+            for wi in get_angular_kernel_points_np(aperature, multiplier * ri + 1):
+                kps.append([rrange[ri], wi])
+    else:
+        rrange = np.linspace(radius / kernel_size[0], radius, kernel_size[0], dtype=np.float32)
+        wrange = get_angular_kernel_points_np(aperature, kernel_size[1])
+        rr = np.tile(rrange[:, None, None], [1, wrange.shape[0], 1])
+        ww = np.tile(wrange[None, :, None], [rrange.shape[0], 1, 1])
+        kps = np.concatenate((rr, ww), axis=2).reshape(-1, 2)
+    return np.array(kps).astype('float32')
+
+
+# ------------------------------------------------------------------------------------------------
+# inter ZP conv: ball + anchor weights + grouping (functional.py:L468-607)
+# ------------------------------------------------------------------------------------------------
+def inter_zpposeconv_grouping_ball(xyz, pose, stride, radius, n_neighbor, lazy_sample=True):
+    """-> grouped_xyz [b,3,p2,nn], ball_idx (long) [b,p2,nn], idx [b,p2], sample_xyz, grouped_pose
+    [b,p2,nn,...], sampled_pose [b,p2,...]   (functional.py:L468-500)."""
+    n_sample = math.ceil(xyz.shape[2] / stride)
+    idx, sample_xyz = pctk.furthest_sample(xyz, n_sample, lazy_sample)
+    idx = idx.long()
+    sampled_pose = batched_index_select(pose, dim=1, index=idx)
+    ball_idx, grouped_xyz = ball_query(sample_xyz, xyz, radius, n_neighbor)
+    ball_idx = ball_idx.long()
+    grouped_pose = batched_index_select_other(pose, ball_idx, dim=1)
+    grouped_xyz = grouped_xyz - sample_xyz.unsqueeze(3)
+    return grouped_xyz, ball_idx, idx, sample_xyz, grouped_pose, sampled_pose
+
+
+def inter_zpconv_grouping_anchor(grouped_xyz, ball_idx, sample_idx, anchors, kernels, anchor_nn, n_support,
+                                 radius, aperture, sigma):
+    """S^2 kernel weights (functional.py:L503-573, the live "linear kernel" branch):
+    grouped_xyz [b,3,p,nn], anchors [a,3], kernels [ks,2] = (radius, polar angle)
+    -> inter_idx = ball_idx [b,p,nn], inter_w [b,p,a,ks,nn]."""
+    norm = grouped_xyz.pow(2).sum(1).sqrt() + 1e-6                                   # [b,p,nn]
+    cos_theta = (grouped_xyz.unsqueeze(3) * anchors.t()[:, None, :, None]).sum(1) / norm.unsqueeze(2)   # [b,p,a,nn]
+    theta = acos_safe(cos_theta).unsqueeze(3)                                        # [b,p,a,1,nn]
+    norm2 = norm[:, :, None, None, :]
+    knorm2 = kernels[:, :1]
+    theta2 = kernels[:, 1:]
+    ratio = 3.0
+    dist1 = (norm2 - knorm2).abs() + (norm2 * (theta - theta2)).abs() / ratio
+    inter_w = F.relu(1.0 - dist1 / sigma ** 0.5, inplace=True)
+    return ball_idx, inter_w
+
+
+def inter_zpconv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, anchor_nn, radius, aperture, sigma,
+                          inter_idx=None, inter_w=None, lazy_sample=True, radius_expansion=1.0):
+    """functional.py:L576-607 -> inter_idx, inter_w, new_xyz, new_feats [b,c,ks,p,a]; the contraction runs in
+    the HIP zpconv kernel (inter_zpconv_grouping_naive)."""
+    if inter_idx is None:
+        grouped_xyz, ball_idx, idx, new_xyz = inter_zpconv_grouping_ball(xyz, stride, radius * radius_expansion,
+                                                                         n_neighbor, lazy_sample)
+        inter_idx, inter_w = inter_zpconv_grouping_anchor(grouped_xyz, ball_idx, idx, anchors, kernels, anchor_nn,
+                                                          xyz.shape[2], radius, aperture, sigma)
+        inter_w = inter_w.contiguous().permute(0, 1, 3, 2, 4).contiguous()
+    else:
+        new_xyz = xyz
+    feats = add_shadow_feature(feats)
+    w = inter_w
+    if w.shape[2] == 1 and feats.shape[3] != 1:      # the reference's einsum broadcasts a singleton anchor axis
+        w = w.expand(-1, -1, feats.shape[3], -1, -1)
+    new_feats = inter_zpconv_grouping_naive(inter_idx, w, feats)
+    return inter_idx, inter_w, new_xyz, new_feats

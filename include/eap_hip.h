@@ -185,6 +185,28 @@ int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int
                                 const float *rk, const uint8_t *multinv, int identity_anchor,
                                 float *z, eap_stream_t stream);
 
+/* Inverse neighbour lists for so3_inter_group_inv, built on the device (the autograd transpose of the
+ * gather at so3conv/functional.py:L1221-1252 needs, per referenced support row, the (point, slot) pairs
+ * that reference it).  idx int32 [b,p,nn] with values in [0,n) (other values are ignored), n <= 16384.
+ * eap_inv_lists_rows: counts [b,n] (scratch) -> rows [b,n] (referenced support rows, longest list first,
+ *   ties by index; -1 past the end), cnt [b,n], off [b,n] (start of each row's entries in the per-cloud
+ *   entry list), n_rows [b].
+ * eap_inv_lists_fill: for the first `rcap` rows of every cloud (rows / off as written above, leading
+ *   dimension n): ent_p int32 [b,p*nn] (query point of each entry, entries of a row in (p,slot) order),
+ *   ent_gx float4 [b,p*nn] (its so3_prep word).  p*nn must be a multiple of 4. */
+int eap_inv_lists_rows(int b, int p, int n, int nn, const int32_t *idx, int32_t *counts, int32_t *rows,
+                       int32_t *off, int32_t *cnt, int32_t *n_rows, eap_stream_t stream);
+int eap_inv_lists_fill(int b, int p, int n, int nn, int rcap, const int32_t *idx, const float *gx,
+                       const int32_t *rows, const int32_t *off, int32_t *ent_p, float *ent_gx,
+                       eap_stream_t stream);
+/* Referenced rows of a feature tensor: dst [b,c,rcap,na] = src [b,c,n,na][:, :, rows[b,r], :] (zeros where
+ * rows < 0), and the transpose dst [b,c,n,na] = 0; dst[:, :, rows[b,r], :] = src [b,c,rcap,na].
+ * rows int32 with leading dimension rows_ld; na a multiple of 4. */
+int eap_rows_gather_f32(int b, int c, int n, int na, int rcap, int rows_ld, const int32_t *rows,
+                        const float *src, float *dst, eap_stream_t stream);
+int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, const int32_t *rows,
+                         const float *src, float *dst, eap_stream_t stream);
+
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 
 /* so3_intra_group_fwd: intra_so3conv_grouping, so3conv/functional.py:L2553-2602.

@@ -1,0 +1,177 @@
+"""GPU: the device-side inverse neighbour lists (csrc/inv_lists.hip) and the B1 modules added in round 2
+(KernelPropagation, IntraSO3Conv2D, vgtk.spconv.modules) against plain torch / the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import native, so3_ref  # noqa: E402  (checker only)
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _torch_inverse_lists(idx, gx, n):
+    """Round 1's construction (stable sort by support row, rows by descending count): the reference the
+    kernels must reproduce bit for bit."""
+    b, p, nn = idx.shape
+    keys = idx.reshape(b, p * nn).long()
+    skeys, order = torch.sort(keys, dim=1, stable=True)
+    counts = torch.zeros(b, n + 1, dtype=torch.int64)
+    counts.scatter_add_(1, keys.clamp(max=n), torch.ones_like(keys))
+    counts = counts[:, :n]
+    offs = torch.cumsum(counts, 1) - counts
+    n_rows = (counts > 0).sum(1)
+    rcap = int(n_rows.max())
+    rows = torch.argsort(counts, dim=1, descending=True, stable=True)[:, :rcap]
+    valid = torch.arange(rcap)[None, :] < n_rows[:, None]
+    cnt_c = torch.gather(counts, 1, rows) * valid
+    rows_c = torch.where(valid, rows, torch.full_like(rows, -1))
+    ent_p = torch.div(order, nn, rounding_mode='floor')
+    ent_gx = torch.gather(gx.reshape(b, p * nn, 4), 1, order[..., None].expand(-1, -1, 4))
+    return rows_c, torch.gather(offs, 1, rows), cnt_c, ent_p, ent_gx, rcap, skeys
+
+
+@pytest.mark.parametrize('case', ['hot_rows_4096', 'uniform', 'ragged_small', 'with_shadow'])
+def test_inverse_lists_on_device(dev, case):
+    import synth_clouds
+    import vgtk.cuda.grouping as G
+    import vgtk.so3conv.functional as L
+    gen = torch.Generator().manual_seed(17)
+    if case == 'hot_rows_4096':      # the benchmark regime: first-64-in-index-order lists of a big ball
+        xyz = T(synth_clouds.laptop_batch(5, 3, 4096)[0])
+        idx = G.ball_query(xyz.to(dev), xyz.to(dev), synth_clouds.backbone_layers(4096)[2][2], 64).cpu()
+        n = 4096
+    elif case == 'uniform':
+        n, idx = 500, torch.randint(0, 500, (2, 333, 16), generator=gen, dtype=torch.int32)
+    elif case == 'ragged_small':     # clouds with different numbers of referenced rows, some rows empty
+        n = 40
+        idx = torch.randint(0, 40, (3, 9, 8), generator=gen, dtype=torch.int32)
+        idx[1] = idx[1] % 5
+        idx[2] = 7
+    else:                            # shadow entries (== n) are ignored
+        n = 64
+        idx = torch.randint(0, 65, (2, 50, 12), generator=gen, dtype=torch.int32)
+    b, p, nn = idx.shape
+    gx = torch.randn(b, p, nn, 4, generator=gen)
+    rows, off, cnt, ent_p, ent_gx, rcap, all_ident = L._inverse_lists(idx.to(dev), gx.to(dev), n, 0, torch.zeros(b, dtype=torch.int32, device=dev))
+    r_rows, r_off, r_cnt, r_ent_p, r_ent_gx, r_rcap, skeys = _torch_inverse_lists(idx, gx, n)
+    assert rcap == r_rcap and all_ident
+    np.testing.assert_array_equal(rows.cpu().numpy(), r_rows.numpy())
+    np.testing.assert_array_equal(cnt.cpu().numpy(), r_cnt.numpy())
+    # entry lists: row r's entries are the same (p, gx) sequence; offsets may differ (here rows are stored
+    # in slot order, round 1 stored them in support-index order)
+    ent_p, ent_gx, off = ent_p.cpu(), ent_gx.cpu(), off.cpu()
+    for bi in range(b):
+        for r in range(rcap):
+            c = int(r_cnt[bi, r])
+            if c == 0:
+                continue
+            a0, b0 = int(off[bi, r]), int(r_off[bi, r])
+            np.testing.assert_array_equal(ent_p[bi, a0:a0 + c].numpy(), r_ent_p[bi, b0:b0 + c].numpy())
+            np.testing.assert_array_equal(ent_gx[bi, a0:a0 + c].numpy(), r_ent_gx[bi, b0:b0 + c].numpy())
+
+
+def test_rows_gather_scatter(dev):
+    from vgtk import _hip
+    gen = torch.Generator().manual_seed(3)
+    b, c, n, na, rcap = 2, 5, 37, 60, 9
+    src = torch.randn(b, c, n, na, generator=gen)
+    rows = torch.stack([torch.randperm(n, generator=gen)[:rcap], torch.randperm(n, generator=gen)[:rcap]]).int()
+    rows[1, 6:] = -1
+    rows_full = torch.full((b, n), -1, dtype=torch.int32)
+    rows_full[:, :rcap] = rows                                       # leading dimension n, as the list kernels write it
+    g = _hip.rows_gather(src.to(dev), rows_full.to(dev), rcap).cpu()
+    want = torch.zeros(b, c, rcap, na)
+    for bi in range(b):
+        for r in range(rcap):
+            if rows[bi, r] >= 0:
+                want[bi, :, r] = src[bi, :, rows[bi, r]]
+    assert torch.equal(g, want)
+    s = _hip.rows_scatter(want.to(dev), rows_full.to(dev), n).cpu()
+    back = torch.zeros(b, c, n, na)
+    for bi in range(b):
+        for r in range(rcap):
+            if rows[bi, r] >= 0:
+                back[bi, :, rows[bi, r]] = want[bi, :, r]
+    assert torch.equal(s, back)
+
+
+def test_kernel_propagation(dev):
+    """KernelPropagation.forward (so3conv/modules.py:L57-119) = initial_anchor_query / (cnt + 1) -> BasicSO3Conv."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    torch.manual_seed(1)
+    prop = sptk.KernelPropagation(1, 8, 32, 1, 0.2, 0.02, kanchor=60)
+    xyz = synth_clouds.laptop_batch(2, 2, 32)[0]
+    frag = np.ascontiguousarray(synth_clouds.laptop_batch(9, 1, 300)[0][0].T)
+    w, cnt = native.initial_anchor_query(xyz, frag, prop.kernels.numpy(), 0.2, 0.02)
+    ref = so3_ref.basic_so3conv(prop.basic_conv.W.detach(), T(w / (cnt + 1.0)).unsqueeze(1))
+    prop = prop.to(dev)
+    out = prop(T(frag).to(dev), T(xyz).to(dev))
+    assert out.feats.shape == (2, 8, 32, 60) and out.xyz.shape == (2, 3, 32)
+    assert rel_err(out.feats.detach().cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_intra_so3conv_2d(dev):
+    """IntraSO3Conv2D (so3conv/modules.py:L350-373) against the index_select formulation in plain torch."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    torch.manual_seed(2)
+    conv = sptk.IntraSO3Conv2D(5, 7)
+    f = torch.randn(2, 5, 11, 240)
+    fi = f.view(2, 5, 11, 60, 4).index_select(3, conv.intra_idx.view(-1)).view(2, 5, 11, 60, 12, 4)
+    grouped = fi.permute(0, 1, 4, 2, 3, 5).reshape(2, 5, 12, 11, 240)
+    ref = torch.matmul(conv.basic_conv.W.detach(), grouped.reshape(2, 60, 11 * 240)).view(2, 7, 11, 240)
+    conv = conv.to(dev)
+    out = conv(zptk.SphericalPointCloud(torch.zeros(2, 3, 11, device=dev), f.to(dev), None)).feats
+    assert rel_err(out.detach().cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_zpconv_modules(dev):
+    """vgtk.spconv.modules (spconv/modules.py:L17-146) on the HIP zpconv kernels vs the reference's einsum
+    formulation in plain torch on the CPU."""
+    import synth_clouds
+    import vgtk.spconv as zptk
+    torch.manual_seed(4)
+    xyz = T(synth_clouds.laptop_batch(4, 2, 128)[0])
+    # intra: [b,c,p,a_in] -> [b,c2,p,a_out]
+    intra = zptk.IntraZPConv(6, 9, 3, 1.2, 0.1, 4, 12)
+    f = torch.randn(2, 6, 128, 12)
+    g = so3_ref.intra_zpconv_grouping_naive(intra.intra_idx, intra.intra_w, f)
+    ref = torch.matmul(intra.basic_conv.W.detach(), g.reshape(2, 6 * 3, 128 * 12)) + intra.basic_conv.bias.detach()
+    out = intra.to(dev)(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None)).feats
+    assert rel_err(out.detach().cpu().numpy(), ref.view(2, 9, 128, 12).numpy()) < 1e-5
+    # anchor propagation 12 -> 42 directions
+    prop = zptk.AnchorProp(12, 42, 0.1)
+    want = (f[:, :, :, prop.idx] * prop.w).sum(-1)
+    got = prop.to(dev)(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None)).feats
+    assert got.shape == (2, 6, 128, 42) and rel_err(got.cpu().numpy(), want.numpy()) < 1e-6
+    # inter: ball query + S^2 kernel weights + grouping + dense layer sized by the anchor count
+    inter = zptk.InterZPConv(6, 5, 1, 1, 0.2, 1.2, 0.05, 12, 16, 4)     # kernel_size 1 -> ks = 1 (as the reference's example shapes)
+    idx = T(native.ball_query(xyz.numpy(), xyz.numpy(), 0.2, 16))
+    gxyz = so3_ref.group_nd(so3_ref.add_shadow_point(xyz), idx) - xyz.unsqueeze(3)
+    norm = gxyz.pow(2).sum(1).sqrt() + 1e-6
+    cos_t = (gxyz.unsqueeze(3) * inter.anchors.t()[:, None, :, None]).sum(1) / norm.unsqueeze(2)
+    sign = torch.sign(cos_t); eps = 1e-4; slope = np.arccos(1 - eps) / eps
+    theta = torch.where(cos_t.abs() <= 1 - eps, torch.acos(cos_t), torch.acos(sign * (1 - eps)) - slope * sign * (cos_t.abs() - 1 + eps)).unsqueeze(3)
+    dist1 = (norm[:, :, None, None, :] - inter.kernels[:, :1]).abs() + (norm[:, :, None, None, :] * (theta - inter.kernels[:, 1:])).abs() / 3.0
+    w = torch.relu(1.0 - dist1 / 0.05 ** 0.5).permute(0, 1, 3, 2, 4).contiguous()          # [b,p,ks=1,a,nn] read as [b,p,a'=1,k'=12,nn]
+    gf = so3_ref.inter_zpconv_grouping_naive(idx, w, so3_ref.add_shadow_feature(f))          # einsum broadcasts a' = 1 over the 12 anchors
+    ref = torch.matmul(inter.basic_conv.W.detach(), gf.reshape(2, 6 * 12, 128 * 12)) + inter.basic_conv.bias.detach()
+    inter = inter.to(dev)
+    i2, w2, y = inter(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None))
+    np.testing.assert_array_equal(i2.cpu().numpy(), idx.numpy())
+    assert rel_err(w2.cpu().numpy(), w.numpy()) < 1e-5
+    assert rel_err(y.feats.detach().cpu().numpy(), ref.view(2, 5, 128, 12).numpy()) < 1e-5

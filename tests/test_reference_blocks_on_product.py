@@ -1,0 +1,86 @@
+"""Boundary B1, checked with the reference's OWN block layer: SPConvNets/utils/base_so3poseconv.py (and
+base_so3conv.py where its imports resolve) is imported UNCHANGED on top of the product `vgtk`, and the three
+backbone block lists of build_model (...pn_38_multi_stage.py:L2146-2248: `glb_backbone` = separable blocks,
+`backbone` / `backbone_sec` = inter blocks with kanchor = kpconv_kanchor = 60) are constructed from the same
+parameter dictionaries.  Build-container only: skipped where /root/reference does not exist (GPU box).
+
+With a GPU (`-m gpu` half, skipped here) the reference blocks then RUN on the product operators."""
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'SPConvNets')), reason='needs /root/reference (build container only)')
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _params(input_num, block_type, kanchor, extra=None):
+    import synth_clouds
+    out = []
+    for (c, o, r, s) in synth_clouds.backbone_layers(input_num):
+        args = {'dim_in': c, 'dim_out': o, 'kernel_size': 1, 'stride': 1, 'radius': r, 'sigma': s, 'n_neighbor': 64,
+                'lazy_sample': True, 'dropout_rate': 0.0, 'multiplier': 2, 'activation': 'leaky_relu', 'pooling': 'none',
+                'kanchor': kanchor, 'norm': 'BatchNorm2d'}
+        args.update(extra or {})
+        out.append({'type': block_type, 'args': args})
+    return out
+
+
+@pytest.fixture(scope='module')
+def blocks():
+    import vgtk  # noqa: F401  (the PRODUCT package: tests/conftest.py puts it first on sys.path)
+    import vgtk.so3conv as sptk
+    assert 'equi-articulated-pose_amd' in vgtk.__file__
+    return _load('ref_base_so3poseconv', 'SPConvNets/utils/base_so3poseconv.py'), sptk
+
+
+def test_reference_block_layer_builds_the_three_backbones(blocks):
+    M, sptk = blocks
+    glb = M.BasicSO3PoseConvBlock(_params(4096, 'separable_block', 60))
+    bb = M.BasicSO3PoseConvBlock(_params(4096, 'inter_block', 60, {'permute_modes': 1, 'use_art_mode': False}))
+    bb_sec = M.BasicSO3PoseConvBlock(_params(4096, 'inter_block', 60, {'permute_modes': 1, 'use_art_mode': False}))
+    for net in (glb, bb, bb_sec):
+        assert len(net.blocks) == 3
+    # the product modules sit inside the reference's blocks, with the reference's parameter names
+    assert isinstance(bb.blocks[2].conv, sptk.InterSO3PoseConv)
+    assert isinstance(glb.blocks[0].intra_conv.conv, sptk.IntraSO3Conv)
+    names = set(glb.state_dict().keys())
+    for key in ('blocks.0.inter_conv.conv.basic_conv.W', 'blocks.0.inter_conv.conv.anchors', 'blocks.0.inter_conv.conv.kernels',
+                'blocks.0.intra_conv.conv.basic_conv.W', 'blocks.0.intra_conv.conv.intra_idx', 'blocks.2.skip_conv.weight',
+                'blocks.1.inter_conv.norm.running_mean'):
+        assert key in names, key
+    assert glb.blocks[2].inter_conv.conv.basic_conv.W.shape == (512, 128 * 24)
+    assert glb.blocks[2].intra_conv.conv.basic_conv.W.shape == (512, 512 * 12)
+    assert torch.equal(bb.get_anchor(), torch.from_numpy(sptk.get_anchors()))
+
+
+def test_reference_propagation_and_2d_blocks_build(blocks):
+    """The symbols the active block layer references beyond the shipped path: KernelPropagation
+    (base_so3poseconv.py:L149) and IntraSO3Conv2D (L121)."""
+    M, sptk = blocks
+    prop = M.PropagationBlock({'dim_in': 1, 'dim_out': 8, 'n_center': 32, 'kernel_size': 1, 'radius': 0.2, 'sigma': 0.02, 'kanchor': 60})
+    assert isinstance(prop.prop, sptk.KernelPropagation) and prop.prop.kernels.shape == (24, 60, 3)
+    blk = M.IntraSO3PoseConv2DBlock(8, 8, activation='leaky_relu')
+    assert isinstance(blk.conv, sptk.IntraSO3Conv2D)
+
+
+@pytest.mark.gpu
+def test_reference_blocks_run_on_the_product_operators(blocks):
+    """Only where both /root/reference and a GPU exist (never on the driver's boxes: documented, not relied on)."""
+    import synth_clouds
+    M, sptk = blocks
+    dev = torch.device('cuda:0')
+    net = M.BasicSO3PoseConvBlock(_params(512, 'separable_block', 60)).to(dev)
+    xyz, _, pose = synth_clouds.laptop_batch(0, 2, 256)
+    x = M.preprocess_input(torch.from_numpy(xyz).to(dev), 60, torch.from_numpy(pose).to(dev), False)
+    y = net(x)
+    assert y.feats.shape == (2, 512, 256, 60) and torch.isfinite(y.feats).all()

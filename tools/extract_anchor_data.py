@@ -31,7 +31,12 @@ np.savez(OUT,
          sphere12_faces=np.vstack(ico['face']['vertex_indices']).astype(np.int32),
          kpsphere24=verts('kpsphere24.ply'),
          kpsphere30=verts('kpsphere30.ply'),
-         kpsphere66=verts('kpsphere66.ply'))
+         kpsphere66=verts('kpsphere66.ply'),
+         # S^2 anchor sets of the ZP convolution (vgtk.spconv.functional.get_anchors(int): the vertices with
+         # norm > 0.5, normalised); sphere12_vertices doubles as the 12-anchor set
+         sphere42_vertices=verts('sphere42.ply'),
+         sphere92_vertices=verts('sphere92.ply'),
+         sphere162_vertices=verts('sphere162.ply'))
 d = np.load(OUT)
 for k in d.files:
     print(k, d[k].shape, d[k].dtype)
