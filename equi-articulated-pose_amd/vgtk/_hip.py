@@ -85,19 +85,40 @@ def suffix(t):
 
 # ---- raw launchers used by the operator layer ---------------------------------------------------
 
+# csrc/gemm_dma_f32.hip (DMA-fed three-stage ring) serves every GEMM whose operands it can take (K a multiple of 16,
+# 16-byte aligned rows); csrc/gemm_f32.hip the rest (first layer K = 24, blocked intermediates, odd shapes).
+# EAP_DMA_GEMM=0 forces the older kernel everywhere (A/B runs).
+USE_DMA_GEMM = os.environ.get('EAP_DMA_GEMM', '1') != '0'
+lib.eap_gemm_dma_f32_reduce_workspace.restype = ctypes.c_int64
+
+
+def _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
+    return USE_DMA_GEMM and bool(lib.eap_gemm_dma_f32_supported(int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
+                                                              _ptr(B), _I64(ldb), _I64(strideB)))
+
+
 def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, b_blocked=False):
     """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored."""
+    tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)}
+    if not b_blocked and _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
+        call('eap_gemm_dma_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb),
+             _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch, tag=tag)
+        return
     call('eap_gemm_f32_xb' if b_blocked else 'eap_gemm_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
-         _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch,
-         tag={'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)})
+         _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch, tag=tag)
 
 
 def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch, b_blocked=False):
+    tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)}
+    if not b_blocked and _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
+        ws = torch.empty(max(int(lib.eap_gemm_dma_f32_reduce_workspace(M, N, K, batch)), 1), dtype=torch.float32, device=C.device)
+        call('eap_gemm_dma_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb),
+             _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws), tag=tag)
+        return
     n_ws = lib.eap_gemm_f32_reduce_workspace(M, N, K, batch)
     ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=C.device)
     call('eap_gemm_f32_reduce_xb' if b_blocked else 'eap_gemm_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA),
-         _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws),
-         tag={'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)})
+         _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), batch, _ptr(ws), tag=tag)
 
 
 def so3_prep(q_xyz, s_xyz, idx, q_pose, s_pose, anchors, identity_anchor):

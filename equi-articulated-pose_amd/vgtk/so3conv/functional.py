@@ -370,7 +370,7 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
 #   'blocked'     X blocked by anchor quads, contraction = csrc/gemm_f32.hip (eap_gemm_f32_xb)
 #   'reference'   X [C*K, P*A] as the reference's einsum writes it, contraction = csrc/gemm_f32.hip
 X_LAYOUT = os.environ.get('EAP_X_LAYOUT', 'transposed')
-LIBRARY_SMALL_GEMMS = os.environ.get('EAP_LIBRARY_GEMMS', '1') != '0'   # the two Z-based gradient GEMMs (plain row-major operands) through the library as well; False: csrc/gemm_f32.hip
+LIBRARY_SMALL_GEMMS = os.environ.get('EAP_LIBRARY_GEMMS', '0') != '0'   # the two Z-based gradient GEMMs (plain row-major operands) through the library as well; False: csrc/gemm_f32.hip
 BLOCKED_X = True     # test knob: False forces the reference layout
 
 
@@ -392,8 +392,10 @@ class _InterConv(torch.autograd.Function):
         b, c, ks, p, na = x.shape
         o = W.shape[0]
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=x.device)
-        if layout == 2:
+        if layout == 2 and LIBRARY_SMALL_GEMMS:      # A/B knob only: the same contraction through hipBLASLt
             _hip.library_contract(W, x.view(b, p * na, c * ks), y.view(b, o, p * na))
+        elif layout == 2:                            # Y = W . (X^T)^T, both operands k-contiguous (csrc/gemm_dma_f32.hip)
+            _hip.gemm(0, 1, o, p * na, c * ks, W, c * ks, 0, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b)
         else:
             _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
         ctx.layout = layout
@@ -432,6 +434,8 @@ class _InterConv(torch.autograd.Function):
             rcap, any_nonident = head.decide()
             if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
                 head = None
+            rcap = min((rcap + 3) & ~3, n)       # slots past a cloud's last referenced row are empty (rows = -1): K = rcap * na
+                                                 # of the gradient GEMMs becomes a multiple of 16
         if head is not None:
             rows = head.rows[:, :rcap].contiguous()
             off, cnt = head.off[:, :rcap].contiguous(), head.cnt[:, :rcap].contiguous()

@@ -237,6 +237,20 @@ int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, const float
                         int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
                         int64_t ldc, int batch, float *workspace, eap_stream_t stream);
 
+/* The same GEMMs with both operands fed by global -> LDS DMA through a three-stage ring (csrc/gemm_dma_f32.hip);
+ * conventions of eap_gemm_f32 / eap_gemm_f32_reduce.  Needs K % 16 == 0, leading dimensions and batch strides
+ * multiples of 4, 16-byte aligned bases, and a multiple of 4 rows for an operand whose rows are contiguous
+ * (transA = 1: M % 4 == 0; transB = 0: N % 4 == 0); eap_gemm_dma_f32_supported tells (1 / 0). */
+int eap_gemm_dma_f32_supported(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                               int64_t strideA, const float *B, int64_t ldb, int64_t strideB);
+int eap_gemm_dma_f32(int transA, int transB, int M, int N, int K, const float *A, int64_t lda, int64_t strideA,
+                     const float *B, int64_t ldb, int64_t strideB, float *C, int64_t ldc, int64_t strideC,
+                     int batch, eap_stream_t stream);
+int64_t eap_gemm_dma_f32_reduce_workspace(int M, int N, int K, int batch);
+int eap_gemm_dma_f32_reduce(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
+                            int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C, int64_t ldc,
+                            int batch, float *workspace, eap_stream_t stream);
+
 /* ---- blocked intermediate: the forward's grouped tensor X with coalesced row-end stores --------
  * X_blocked[b][p][a/4][c][k][4] holds the same numbers as X[b][c][k][p][a].  The grouping kernels
  * write 384 contiguous bytes per (channel, anchor quad) instead of 16-byte pieces 983 KB apart, and

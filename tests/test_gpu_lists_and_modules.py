@@ -175,3 +175,55 @@ def test_zpconv_modules(dev):
     np.testing.assert_array_equal(i2.cpu().numpy(), idx.numpy())
     assert rel_err(w2.cpu().numpy(), w.numpy()) < 1e-5
     assert rel_err(y.feats.detach().cpu().numpy(), ref.view(2, 5, 128, 12).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K,batch', [(512, 1920, 3072, 1), (128, 2040, 1536, 2), (256, 128, 32, 1), (130, 260, 48, 2),
+                                        (64, 4, 16, 1), (300, 1000, 160, 3), (12288, 128, 960, 2)])
+def test_gemm_dma_all_operand_layouts(dev, M, N, K, batch):
+    """csrc/gemm_dma_f32.hip (DMA-fed ring) in its four operand layouts + the k-split batch reduction, against
+    float64 matmul; ragged M / N tiles, a single k-tile, K = 2 k-tiles (ring shorter than its depth)."""
+    from vgtk import _hip
+    gen = torch.Generator().manual_seed(21)
+    A = torch.randn(M, K, generator=gen)
+    B = torch.randn(batch, K, N, generator=gen)
+    ref = torch.matmul(A.double(), B.double()).numpy()
+    tol = 2e-6 if K <= 256 else 1e-5
+    Ad, Bd = A.to(dev), B.to(dev)
+    At = A.t().contiguous().to(dev)                       # stored [K, M]
+    Bt = B.transpose(1, 2).contiguous().to(dev)           # stored [N, K]
+    for ta, tb, a, lda, bm, ldb in ((0, 0, Ad, K, Bd, N), (0, 1, Ad, K, Bt, K), (1, 0, At, M, Bd, N), (1, 1, At, M, Bt, K)):
+        if (ta and M % 4) or (not tb and N % 4):
+            assert not _hip._dma_ok(ta, tb, M, N, K, a, lda, 0, bm, ldb, K * N)
+            continue
+        assert _hip._dma_ok(ta, tb, M, N, K, a, lda, 0, bm, ldb, K * N)
+        C = torch.full((batch, M, N), float('nan'), device=dev)
+        _hip.call('eap_gemm_dma_f32', C, ta, tb, M, N, K, _hip._ptr(a), _hip._I64(lda), _hip._I64(0), _hip._ptr(bm), _hip._I64(ldb),
+                  _hip._I64(K * N), _hip._ptr(C), _hip._I64(N), _hip._I64(M * N), batch)
+        assert rel_err(C.cpu().numpy(), ref) < tol, (ta, tb)
+    # batch-reduced weight-gradient shape: C[M, K'] = sum_b G_b[M, N] X_b[K', N]^T, contraction over N (long)
+    if N % 16 == 0:
+        G = torch.randn(batch, M, N, generator=gen)
+        X = torch.randn(batch, 40, N, generator=gen)
+        ref2 = torch.einsum('bmn,bkn->mk', G.double(), X.double()).numpy()
+        C2 = torch.full((M, 40), float('nan'), device=dev)
+        _hip.gemm_reduce(0, 1, M, 40, N, G.to(dev), N, M * N, X.to(dev), N, 40 * N, C2, 40, batch)
+        assert rel_err(C2.cpu().numpy(), ref2) < 1e-5
+
+
+def test_gemm_dma_is_transpose_detecting_and_deterministic(dev):
+    from vgtk import _hip
+    n = 256
+    A = torch.eye(n, device=dev)
+    B = (torch.arange(n * n, dtype=torch.float32).view(1, n, n) % 251).to(dev)
+    C = torch.empty(1, n, n, device=dev)
+    _hip.call('eap_gemm_dma_f32', C, 0, 0, n, n, n, _hip._ptr(A), _hip._I64(n), _hip._I64(0), _hip._ptr(B), _hip._I64(n), _hip._I64(n * n),
+              _hip._ptr(C), _hip._I64(n), _hip._I64(n * n), 1)
+    assert torch.equal(C, B)
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(512, 3072, generator=gen).to(dev); Y = torch.randn(1, 1024, 3072, generator=gen).to(dev)
+    outs = []
+    for _ in range(3):
+        C = torch.empty(1, 512, 1024, device=dev)
+        _hip.gemm(0, 1, 512, 1024, 3072, X, 3072, 0, Y, 3072, 1024 * 3072, C, 1024, 512 * 1024, 1)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
