@@ -115,18 +115,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_dma_f32_kernel(DmaArgs
     const long long stepB = BKN ? (long long)BK * g.ldb : BK;
     const unsigned lds0 = lds_addr(smem);
     const unsigned dstA = lds0 + (unsigned)wave * 1024u, dstB = lds0 + (unsigned)BM * 64u + (unsigned)wave * 1024u;
-    auto issue = [&](int stage) {
+    // one DMA piece (u < A_PIECES: of the A tile, else of the B tile) of the k-tile that goes to `stage`
+    auto issue_piece = [&](int u, int stage) {
         const unsigned sb = (unsigned)stage * STAGE_BYTES;
-#pragma unroll
-        for (int u = 0; u < A_PIECES; ++u) {
+        if (u < A_PIECES) {
             glds16(srcA[u], __builtin_amdgcn_readfirstlane(dstA + sb + (unsigned)u * (NT * 16u)));
             srcA[u] += stepA;
+        } else {
+            const int v = u - A_PIECES;
+            glds16(srcB[v], __builtin_amdgcn_readfirstlane(dstB + sb + (unsigned)v * (NT * 16u)));
+            srcB[v] += stepB;
         }
+    };
+    auto issue = [&](int stage) {
 #pragma unroll
-        for (int u = 0; u < B_PIECES; ++u) {
-            glds16(srcB[u], __builtin_amdgcn_readfirstlane(dstB + sb + (unsigned)u * (NT * 16u)));
-            srcB[u] += stepB;
-        }
+        for (int u = 0; u < A_PIECES + B_PIECES; ++u) issue_piece(u, stage);
     };
 
     // ---- fragment read offsets (floats).  k-contiguous image: row (li), slot j ^ ((li >> 2) & 3), the second MFMA
@@ -191,7 +194,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_dma_f32_kernel(DmaArgs
         // ... and so have everyone's; everyone has finished reading k-tile it - 1, whose stage is refilled next
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                                   // no LDS read may move above the barrier
-        if (it + 2 < nt) issue(stage >= 1 ? stage - 1 : STAGES - 1);     // (it + 2) % 3 == (stage + 2) % 3
+        // k-tile it + 2 goes to the stage everyone has just left; its pieces are requested one per k-block, from
+        // the MIDDLE of the block's MFMAs: eight waves bursting 24 DMA instructions right behind the barrier
+        // queue on the CU's one address path and nobody reaches an MFMA until it drains (13 % of the kernel in
+        // the first version of this loop)
+        const bool more = it + 2 < nt;
+        const int nstage = stage >= 1 ? stage - 1 : STAGES - 1;          // (it + 2) % 3 == (stage + 2) % 3
         const float *sf = reinterpret_cast<const float *>(smem) + (size_t)stage * (STAGE_BYTES / 4);
         // fragments of k-block j + 1 are requested before the MFMAs of k-block j are issued
         Frag fa[2], fb[2];
@@ -216,6 +224,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_dma_f32_kernel(DmaArgs
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b[s][1], acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b[s][0], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b[s][1], acc[1][1], 0, 0, 0);
+                if (s == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && j < A_PIECES + B_PIECES) issue_piece(j, nstage);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

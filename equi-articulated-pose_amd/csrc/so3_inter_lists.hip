@@ -61,7 +61,7 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // LAYOUT of the output: 0 = [b,c,k,row,a] (reference), 1 = blocked by anchor quads, 2 = transposed [row*na+a][c*ks+k]
 template <bool LISTS, int LAYOUT>
 __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
-    int C, int PF, int na, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, float inv_sigma,
+    int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, int AG, int gsz, int RPB, float inv_sigma,
     const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
     const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
     const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
 
     // ---- DMA: thread -> NSTD fixed 16-byte pieces of a chunk's LDS image ---------------------------
-    const float *fb = F + (size_t)bi * C * PF * na;
+    const float *fb = F + (size_t)bi * C * PF * fpitch;       // fpitch: floats between consecutive feature rows (>= na)
     const int total4 = NBK * CB * npg;                    // a multiple of 64: whole waves in or out
     const unsigned lds_f = lds_addr(s_f);
     const unsigned buf_bytes = (unsigned)(NBK * CB) * (unsigned)pitch * 4u;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         const int row = f / npg, slot = f - row * npg;
         const int nl = row / CB, cl = row - nl * CB;
         const int piece = rotate ? (slot + npg - cl % npg) % npg : slot;
-        dma_off[u] = (unsigned)min(c0 + cl, C - 1) * (unsigned)PF * (unsigned)na + (unsigned)(a0 + 4 * piece);
+        dma_off[u] = (unsigned)min(c0 + cl, C - 1) * (unsigned)PF * (unsigned)fpitch + (unsigned)(a0 + 4 * piece);
         nl_pack |= (unsigned)nl << (3 * u);
     }
     // The ring of entry -> (feature row, offset vector) runs two chunks ahead of the MFMAs and is
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         for (int u = 0; u < NSTD; ++u) {
             int pe = s_p[slot * NBK + ((nl_pack >> (3 * u)) & 7)];
             if (!LISTS) pe = (unsigned)pe < (unsigned)PF ? pe : 0;     // shadow row: any valid row, weight 0
-            src_off[u] = dma_off[u] + __umul24((unsigned)pe, (unsigned)na);
+            src_off[u] = dma_off[u] + __umul24((unsigned)pe, (unsigned)fpitch);
         }
     };
     auto issue = [&](int u, int buf) {
@@ -355,12 +355,13 @@ bool geometry(int na, int ks, Geometry &g) {
 }
 
 template <bool LISTS>
-int launch(int blocked, int b, int C, int PF, int na, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
+int launch(int blocked, int b, int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
            const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
            const float *rk, const int32_t *nonident, float *out, hipStream_t s, const char *what) {
     Geometry g;
     if (!geometry(na, ks, g)) return eap::bad_arg("so3_group_lists: unsupported anchor / kernel-point count");
-    if ((long long)C * PF * na >= (1ll << 31)) return eap::bad_arg("so3_group_lists: one cloud's features exceed 2^31 elements");
+    if (fpitch < na || (fpitch & 3) != 0) return eap::bad_arg("so3_group_lists: the feature row pitch must be a multiple of 4, at least the anchor count");
+    if ((long long)C * PF * fpitch >= (1ll << 31)) return eap::bad_arg("so3_group_lists: one cloud's features exceed 2^31 elements");
     if (((long long)ks * R * na * 4 + 32ll * R * na + 64) * 4 >= (1ll << 31)) return eap::bad_arg("so3_group_lists: output rows too far apart for 32-bit store offsets");
     auto kern = blocked == 2 ? so3_group_lists_kernel<LISTS, LISTS ? 0 : 2> : blocked == 1 ? so3_group_lists_kernel<LISTS, LISTS ? 0 : 1>
                                                                                           : so3_group_lists_kernel<LISTS, 0>;
@@ -370,7 +371,7 @@ int launch(int blocked, int b, int C, int PF, int na, int ks, int R, int nn, int
     // first chunk are in flight during the current row's last chunk)
     const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
     dim3 grid((R + RPB - 1) / RPB * g.AG, (C + CB - 1) / CB, b);
-    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, 1.0f / sigma, F,
+    hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, fpitch, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
     return eap::check_launch(what);
 }
@@ -389,14 +390,14 @@ bool group_lists_supported(int na, int ks) {
 int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                     const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int blocked, float *out,
                     hipStream_t s) {
-    return launch<false>(blocked, b, c, n, na, ks, p, nn, 0, sigma, feats, nullptr, nullptr, nullptr, idx, gx, rk, nonident, out, s,
+    return launch<false>(blocked, b, c, n, na, na, ks, p, nn, 0, sigma, feats, nullptr, nullptr, nullptr, idx, gx, rk, nonident, out, s,
                          "so3_inter_group_fwd (lists)");
 }
 
-int group_lists_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
+int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
                     const float *ent_gx, const float *rk, float *z, hipStream_t s) {
-    return launch<true>(0, b, o, p, na, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, nullptr, z, s,
+    return launch<true>(0, b, o, p, na, gy_pitch, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, nullptr, z, s,
                         "so3_inter_group_inv (lists)");
 }
 

@@ -13,6 +13,7 @@ Differences a caller can observe (all documented in DESIGN.md):
   * gradients flow to `feats` and `W` (what the reference trains); xyz / pose are treated as data.
   * float32 device tensors only -- there is no CPU path.
 """
+import math
 import os
 import weakref
 
@@ -487,25 +488,30 @@ def so3_contract(W, x):
 # ------------------------------------------------------------------------------------------------
 # grouping entry points
 # ------------------------------------------------------------------------------------------------
-def _check_stride(stride, pooling, feats):
-    if stride != 1:
-        raise NotImplementedError(
-            'stride > 1 (furthest-point-sampled centres) is outside the accelerated path: the shipped '
-            'models force stride 1 (SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L2191)')
+def _strided_centres(xyz, pose, stride, lazy_sample):
+    """Centres of a strided conv (functional.py:L931-934 -> spconv/functional.py:L468-477): ceil(p / stride)
+    points, furthest-point sampled (native FPS kernel) or, with lazy_sample, the first ones.
+    -> sample_idx int32 [b,p2], sample_xyz [b,3,p2], sampled_pose [b,p2,4,4] or None."""
+    n_sample = math.ceil(xyz.shape[2] / stride)
+    sample_idx, sample_xyz = pctk.furthest_sample(xyz, n_sample, lazy_sample)
+    sampled_pose = None if pose is None else batched_index_select(pose, 1, sample_idx.long()).contiguous()
+    return sample_idx, sample_xyz.contiguous(), sampled_pose
 
 
-def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, permute):
+def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, permute, q_xyz=None, q_pose=None):
     if feats.dtype != torch.float32 or xyz.dtype != torch.float32:
         raise RuntimeError('so3conv: float32 only')
     _hip.check_input(xyz)
     if not feats.is_cuda:
         raise RuntimeError('so3conv: feats must be a device tensor')
-    ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
+    q_xyz = xyz if q_xyz is None else q_xyz
+    ball_idx = cuda_nn.ball_query(q_xyz, xyz, radius, n_neighbor)
     rk = rotated_kernels(anchors, kernels)
     mult = ident = None
-    rot = None
+    rot = q_rot = None
     if pose is not None:
         rot = pose.contiguous()
+        q_rot = rot if q_pose is None else q_pose.contiguous()
         if rot.shape[-2:] != (4, 4) or rot.dtype != torch.float32:
             raise RuntimeError('so3conv: pose must be float32 [b,p,4,4]')
         if permute:
@@ -513,25 +519,28 @@ def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, 
             if mult is None:
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
-    gx, nonident = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
     new_feats = _InterGroup.apply(feats, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), new_feats
 
 
-def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute):
+def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute, q_xyz=None, q_pose=None):
     """ball query + prep + fused (grouping . contraction) -> (ball_idx, InterWeights, y [b,o,p,a]).
-    What InterSO3PoseConv / InterSO3Conv.forward run for stride 1."""
+    What InterSO3PoseConv / InterSO3Conv.forward run; q_xyz / q_pose = the sampled centres of a strided conv
+    (default: every point is a centre)."""
     if feats.dtype != torch.float32 or xyz.dtype != torch.float32 or W.dtype != torch.float32:
         raise RuntimeError('so3conv: float32 only')
     _hip.check_input(xyz)
     if not feats.is_cuda or not W.is_cuda:
         raise RuntimeError('so3conv: feats and W must be device tensors')
-    ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
+    q_xyz = xyz if q_xyz is None else q_xyz
+    ball_idx = cuda_nn.ball_query(q_xyz, xyz, radius, n_neighbor)
     rk = rotated_kernels(anchors, kernels)
-    mult = ident = rot = None
+    mult = ident = rot = q_rot = None
     if pose is not None:
         rot = pose.contiguous()
+        q_rot = rot if q_pose is None else q_pose.contiguous()
         if rot.shape[-2:] != (4, 4) or rot.dtype != torch.float32:
             raise RuntimeError('so3conv: pose must be float32 [b,p,4,4]')
         if permute:
@@ -539,7 +548,7 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
             if mult is None:
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
-    gx, nonident = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
     y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
@@ -548,14 +557,27 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
 def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, radius, sigma,
                            inter_idx=None, inter_w=None, lazy_sample=True, radius_expansion=1.0,
                            pooling=None):
-    """Pose-free grouping (functional.py:L144-203), stride 1.
-    -> inter_idx [b,p,nn], inter_w, new_xyz, new_feats [b,c,ks,p,na], sample_idx."""
-    _check_stride(stride, pooling, feats)
+    """Pose-free grouping (functional.py:L144-203), any stride.
+    -> inter_idx [b,p2,nn], inter_w, new_xyz, new_feats [b,c,ks,p2,na], sample_idx."""
+    if pooling is not None and stride > 1 and feats.shape[1] > 1:
+        # low-pass blur before a strided conv (functional.py:L158-173)
+        if pooling == 'stride':
+            pool_stride, stride_nn, stride = stride, int(n_neighbor * stride ** 0.5), 1
+        elif pooling == 'no-stride':
+            pool_stride, stride_nn = 1, n_neighbor
+        else:
+            raise NotImplementedError(f"Pooling mode {pooling} is not implemented!")
+        feats, xyz = inter_so3conv_blurring(xyz, feats, stride_nn, radius, pool_stride, inter_idx, lazy_sample)
+        inter_idx = None
     if inter_idx is None:
+        if stride > 1:
+            sample_idx, new_xyz, _ = _strided_centres(xyz, None, stride, lazy_sample)
+        else:
+            new_xyz = xyz
+            sample_idx = torch.arange(xyz.shape[2], dtype=torch.long, device=xyz.device).unsqueeze(0).repeat(xyz.shape[0], 1)
         inter_idx, inter_w, new_feats = _inter_group(xyz, None, feats, n_neighbor, anchors, kernels,
-                                                     radius * radius_expansion, sigma, False)
-        sample_idx = torch.arange(xyz.shape[2], dtype=torch.long, device=xyz.device).unsqueeze(0).repeat(xyz.shape[0], 1)
-        return inter_idx, inter_w, xyz, new_feats, sample_idx
+                                                     radius * radius_expansion, sigma, False, q_xyz=new_xyz)
+        return inter_idx, inter_w, new_xyz, new_feats, sample_idx
     # cached neighbourhood from an earlier layer (functional.py:L195-201)
     if isinstance(inter_w, InterWeights):
         new_feats = _InterGroup.apply(feats, inter_idx, inter_w.gx, inter_w.rk, None, inter_w.sigma, 0, None)
@@ -567,12 +589,19 @@ def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, rad
 def inter_so3poseconv_grouping_strided(xyz, pose, feats, stride, n_neighbor, anchors, kernels, radius,
                                        sigma, inter_idx=None, inter_w=None, lazy_sample=True,
                                        radius_expansion=1.0, pooling=None, permute_modes=0):
-    """Pose-aware grouping, stride-1 branch of functional.py:L896-1286 (the neighbourhood is
-    recomputed on every call, exactly like the reference: passed-in inter_idx / inter_w are
-    ignored and handed back unchanged).
-    -> inter_idx (as passed in), inter_w, new_xyz, new_feats [b,c,ks,p,na], sample_idx (None),
-       sampled_pose."""
-    _check_stride(stride, pooling, feats)
+    """Pose-aware grouping (functional.py:L896-1286).  stride > 1 with no cached index: centres are
+    furthest-point sampled, poses gathered, the ball query runs centres -> all points with the expanded
+    radius (L931-1013) and the returned inter_idx is None (L1013); otherwise the stride-1 branch (L1025-1261:
+    the neighbourhood is recomputed on every call, passed-in inter_idx / inter_w are ignored and inter_idx is
+    handed back unchanged).
+    -> inter_idx, inter_w, new_xyz, new_feats [b,c,ks,p2,na], sample_idx, sampled_pose."""
+    if pooling is not None and stride > 1 and feats.shape[1] > 1:
+        raise ValueError('xyz_pooling is not None?!!')                 # functional.py:L913
+    if inter_idx is None and stride > 1:
+        sample_idx, new_xyz, sampled_pose = _strided_centres(xyz, pose, stride, lazy_sample)
+        _, w, new_feats = _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius * radius_expansion, sigma,
+                                       permute_modes != 0, q_xyz=new_xyz, q_pose=sampled_pose)
+        return None, w, new_xyz, new_feats, sample_idx, sampled_pose
     _, w, new_feats = _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma,
                                    permute_modes != 0)
     return inter_idx, w, xyz, new_feats, None, pose

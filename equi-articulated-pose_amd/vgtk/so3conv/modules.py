@@ -131,11 +131,19 @@ class InterSO3PoseConv(nn.Module):
         self.register_buffer('kernels', torch.from_numpy(kernels))
 
     def forward(self, x, inter_idx=None, inter_w=None, seg=None):
-        if self.stride != 1:
-            L._check_stride(self.stride, self.pooling, x.feats)
+        if self.pooling is not None and self.stride > 1 and x.feats.shape[1] > 1:
+            raise ValueError('xyz_pooling is not None?!!')             # functional.py:L913
+        if inter_idx is None and self.stride > 1:
+            # strided branch (functional.py:L931-1013): furthest-point sampled centres (native FPS kernel unless
+            # lazy_sample), their poses, centres -> all points ball query; returns inter_idx = None (L1013)
+            sample_idx, q_xyz, q_pose = L._strided_centres(x.xyz, x.pose, self.stride, self.lazy_sample)
+            _, w, feats = L.inter_so3conv_fused(x.xyz, x.pose, x.feats, self.basic_conv.W, self.n_neighbor,
+                                                self.anchors, self.kernels, self.radius, self.sigma,
+                                                self.permute_modes != 0, q_xyz=q_xyz, q_pose=q_pose)
+            return None, w, sample_idx, SphericalPointCloudPose(q_xyz, feats, self.anchors, q_pose)
         # stride-1 branch of the reference (functional.py:L1025-1286): the neighbourhood is recomputed
         # on every call and the passed-in inter_idx is handed back unchanged; grouping + contraction
-        # run as one autograd node (csrc/so3_inter_*.hip + gemm_f32.hip)
+        # run as one autograd node (csrc/so3_inter_*.hip + gemm_dma_f32.hip)
         _, w, feats = L.inter_so3conv_fused(x.xyz, x.pose, x.feats, self.basic_conv.W, self.n_neighbor,
                                             self.anchors, self.kernels, self.radius, self.sigma,
                                             self.permute_modes != 0)

@@ -185,6 +185,13 @@ int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int
                                 const float *rk, const uint8_t *multinv, int identity_anchor,
                                 float *z, eap_stream_t stream);
 
+/* so3_inter_group_inv without anchor permutation, gy stored with a row pitch: gy [b,o,p,gy_pitch], gy_pitch a
+ * multiple of 4 and >= na (64 makes every 60-anchor row start on a 256-byte boundary). */
+int eap_so3_inter_group_inv_pitch_f32(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap,
+                                      float sigma, const float *gy, const int32_t *rows, const int32_t *off,
+                                      const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
+                                      const float *rk, float *z, eap_stream_t stream);
+
 /* Inverse neighbour lists for so3_inter_group_inv, built on the device (the autograd transpose of the
  * gather at so3conv/functional.py:L1221-1252 needs, per referenced support row, the (point, slot) pairs
  * that reference it).  idx int32 [b,p,nn] with values in [0,n) (other values are ignored), n <= 16384.

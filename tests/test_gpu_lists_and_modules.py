@@ -227,3 +227,66 @@ def test_gemm_dma_is_transpose_detecting_and_deterministic(dev):
         _hip.gemm(0, 1, 512, 1024, 3072, X, 3072, 0, Y, 3072, 1024 * 3072, C, 1024, 512 * 1024, 1)
         outs.append(C)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+@pytest.mark.parametrize('chans,kind', [((1, 16), 'identity'), ((16, 32), 'random')])
+def test_strided_pose_conv(dev, chans, kind, lazy):
+    """InterSO3PoseConv with stride 2 -- furthest-point sampled (or lazily taken) centres,
+    gathered poses, centres -> all points ball query (so3conv/functional.py:L931-1013) -- against the oracle:
+    sample indices exact, outputs, dF, dW."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    from test_gpu_bench_shapes import make_poses
+    c, o = chans
+    P, B, radius, sigma, nn = 256, 2, 0.16, 0.0128, 32
+    xyz_np, lab, _ = synth_clouds.laptop_batch(33, B, P)
+    gen = torch.Generator().manual_seed(8)
+    pose = make_poses(gen, [kind] * B, lab, P)
+    xyz = T(xyz_np)
+    torch.manual_seed(6)
+    conv = sptk.InterSO3PoseConv(c, o, 1, 2, radius, sigma, nn, lazy_sample=lazy, kanchor=60, permute_modes=1)
+    f = torch.ones(B, 1, P, 60) if c == 1 else torch.randn(B, c, P, 60, generator=gen)
+    fr = f.clone().requires_grad_(True)
+    Wr = conv.basic_conv.W.detach().clone().requires_grad_(True)
+    _, w_ref, new_xyz, nf, sidx, spose = so3_ref.inter_so3poseconv_grouping_strided_sampled(
+        xyz, pose, fr, 2, nn, conv.anchors, conv.kernels, radius, sigma, permute_modes=1, lazy_sample=lazy,
+        skip_perm_search=(kind == 'identity'))
+    y_ref = so3_ref.basic_so3conv(Wr, nf)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    gf_ref, gw_ref = torch.autograd.grad(y_ref, [fr, Wr], gy)
+    conv = conv.to(dev)
+    fd = f.to(dev).requires_grad_(True)
+    inter_idx, w, sample_idx, out = conv(zptk.SphericalPointCloudPose(xyz.to(dev), fd, None, pose.to(dev)))
+    assert inter_idx is None
+    np.testing.assert_array_equal(sample_idx.cpu().numpy(), sidx.numpy())
+    assert out.feats.shape == (B, o, P // 2, 60)
+    np.testing.assert_array_equal(out.xyz.cpu().numpy(), new_xyz.numpy())
+    np.testing.assert_array_equal(out.pose.cpu().numpy(), spose.numpy())
+    assert rel_err(w.materialize().cpu().numpy(), w_ref.numpy()) < 5e-6
+    assert rel_err(out.feats.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
+    gF, gW = torch.autograd.grad(out.feats, [fd, conv.basic_conv.W], gy.to(dev))
+    assert rel_err(gF.cpu().numpy(), gf_ref.numpy()) < 1e-5
+    assert rel_err(gW.cpu().numpy(), gw_ref.numpy()) < 2e-5
+
+
+def test_strided_pose_free_conv(dev):
+    """InterSO3Conv with stride 2 (so3conv/functional.py:L144-203): sampled centres, xyz and sample_idx returned."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    xyz = T(synth_clouds.laptop_batch(34, 2, 128)[0])
+    torch.manual_seed(7)
+    conv = sptk.InterSO3Conv(4, 6, 1, 2, 0.2, 0.02, 16, lazy_sample=False, kanchor=60)
+    f = torch.randn(2, 4, 128, 60)
+    sidx = T(native.furthest_point_sampling(xyz.numpy(), 64))
+    cx = so3_ref.group_nd(xyz, sidx)
+    idx, gxyz = so3_ref.ball_query(cx, xyz, 0.2, 16)
+    wref = so3_ref.inter_so3conv_grouping_anchor(gxyz - cx.unsqueeze(3), conv.anchors, conv.kernels, 0.02)
+    ref = so3_ref.basic_so3conv(conv.basic_conv.W.detach(), so3_ref.inter_zpconv_grouping_naive(idx, wref, so3_ref.add_shadow_feature(f)))
+    conv = conv.to(dev)
+    inter_idx, inter_w, sample_idx, out = conv(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None))
+    np.testing.assert_array_equal(sample_idx.cpu().numpy(), sidx.numpy())
+    np.testing.assert_array_equal(inter_idx.cpu().numpy(), idx.numpy())
+    assert rel_err(out.feats.detach().cpu().numpy(), ref.numpy()) < 1e-5
