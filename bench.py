@@ -46,13 +46,15 @@ class Backbone(nn.Module):
     SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L505-508 with build_model's
     hyper-parameters (L2089-2225)."""
 
-    def __init__(self, input_num):
+    def __init__(self, input_num, plan_points=None):
         super().__init__()
         import synth_clouds
         import vgtk.so3conv as sptk
         self.convs = nn.ModuleList()
         self.norms = nn.ModuleList()
-        for (c, o, r, s) in synth_clouds.backbone_layers(input_num):
+        # plan_points: take the radii / sigmas build_model derives for THAT input size (e.g. the 512-point plan on
+        # 4096-point clouds: small balls, most support rows referenced -- the textbook-backward regime)
+        for (c, o, r, s) in synth_clouds.backbone_layers(plan_points or input_num):
             self.convs.append(sptk.InterSO3PoseConv(c, o, 1, 1, r, s, NN, kanchor=NA, permute_modes=1))
             self.norms.append(sptk.BatchNormLeakyReLU(o, negative_slope=0.01))   # = nn.BatchNorm2d + F.leaky_relu, fused (csrc/bn_act.hip)
         # stand-in for the pose head's output layer: pooled features -> per-slot, per-anchor
@@ -223,6 +225,8 @@ def zpconv_roofline(dev, points, clouds=2, channels=64):
 
 
 KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
+    'eap_gemm_dma_f32': 'gemm_dma_f32_kernel (v_mfma_f32_32x32x2_f32, DMA-fed 3-stage ring)',
+    'eap_gemm_dma_f32_reduce': 'gemm_dma_f32_kernel (v_mfma_f32_32x32x2_f32, DMA-fed 3-stage ring), split-K',
     'eap_gemm_f32': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
     'eap_gemm_f32_reduce': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K',
     'eap_so3_inter_group_fwd_f32': 'so3_group_lists_kernel<false, 0> (v_mfma_f32_32x32x2_f32)',
@@ -260,6 +264,61 @@ def summarize_kernels(records):
     return by_name, shapes
 
 
+def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, warmup=2):
+    """One more configuration of the same step on this GPU, a few steps: -> dict(value, ms_per_step, ...)."""
+    import synth_clouds
+    from vgtk import _hip
+    torch.manual_seed(2913)
+    model = Backbone(points, plan_points).to(dev)
+    params = [p for p in model.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, batch, points)
+    xyz, pose = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(pose_np).to(dev)
+
+    def step():
+        if fwd_only:
+            with torch.no_grad():
+                model.hypotheses(model(xyz, pose))
+            return
+        opt.zero_grad(set_to_none=True)
+        feats = model(xyz, pose)
+        StandInLoss.apply(feats, model.pose_head.weight, model.pose_head.bias).backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    _hip.KERNEL_TIMES = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
+    kern, _ = summarize_kernels(records)
+    top = sorted(kern.items(), key=lambda kv: -kv[1]['ms'])[:4]
+    out = {'clouds_per_gpu': batch, 'points': points, 'pass': 'fwd' if fwd_only else 'fwd+bwd+Adam',
+           'radii_of_input_size': plan_points or points, 'value': batch * steps / dt, 'unit': 'point-clouds/sec',
+           'ms_per_step': dt / steps * 1e3, 'steps': steps,
+           'top_kernels_ms_per_step': {n: round(k['ms'] / steps, 2) for n, k in top}}
+    del model, opt, xyz, pose
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_configs(dev):
+    """Short runs of the other BASELINE.json shapes on one GPU (each a few steps, same code path as the timed
+    run): config 2 (forward only), configs 3 / 4 per-GPU shape (16 clouds), config 5 per-GPU shape (8 clouds of
+    8192 points), and the small-radius regime in which more than a quarter of the support rows are referenced and
+    the backward takes the textbook dX route."""
+    return [
+        dict(name='config 2: 8 x 4096, forward only', **quick_run(dev, 8, 4096, fwd_only=True)),
+        dict(name='configs 3/4 per-GPU shape: 16 x 4096', **quick_run(dev, 16, 4096)),
+        dict(name='config 5 per-GPU shape: 8 x 8192', **quick_run(dev, 8, 8192)),
+        dict(name='8 x 4096 with the 512-point radii (textbook-backward regime)', **quick_run(dev, 8, 4096, plan_points=512)),
+    ]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -270,6 +329,8 @@ def main():
     ap.add_argument('--fwd-only', action='store_true', help='BASELINE config 2 (forward only)')
     ap.add_argument('--separable', action='store_true', help='the separable (inter + intra + skip) glb_backbone instead of the inter backbone; implies --fwd-only as in the reference')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--plan-points', type=int, default=None, help='radii / sigmas of the backbone built for this input size (default: --points)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configurations')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -286,7 +347,7 @@ def main():
     torch.manual_seed(2913)
     if args.separable:
         args.fwd_only = True
-    model = (SeparableBackbone if args.separable else Backbone)(args.points).to(dev)
+    model = (SeparableBackbone(args.points) if args.separable else Backbone(args.points, args.plan_points)).to(dev)
     for m in model.modules():           # the reference converts its BatchNorms to SyncBatchNorm for multi-GPU runs
         if hasattr(m, 'sync') and hasattr(m, 'negative_slope'):
             m.sync = world > 1
@@ -341,7 +402,7 @@ def main():
         # fabric-side bytes per launch of the dominant entry, from the rocprofv3 FETCH_SIZE /
         # WRITE_SIZE passes committed under profiles/ (collected at the default workload only)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_p_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) else 'r01_p_pmc_traffic.json')
         if os.path.exists(pmc) and args.points == 4096 and args.batch == 8 and not args.fwd_only:
             d = json.load(open(pmc))['per_launch_bytes'].get(dom_name)
             if d:
@@ -371,6 +432,11 @@ def main():
             'dominant_kernel': dom_name,
             'launch_shapes': shapes[:8],
         }
+        default_cfg = args.points == 4096 and args.batch == 8 and not args.fwd_only and not args.separable and args.plan_points is None
+        if world == 1 and default_cfg and not args.no_other_configs:
+            del model, opt, xyz, pose
+            torch.cuda.empty_cache()
+            line['other_configs'] = other_configs(dev)
         if world == 1 and not args.fwd_only:
             line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
         if world == 1 and not args.no_cpu_baseline:

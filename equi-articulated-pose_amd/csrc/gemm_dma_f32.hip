@@ -1,5 +1,5 @@
-// csrc/gemm_dma_f32.hip -- the dense contractions of the SO(3) convolution on the fp32 matrix cores, operands fed
-// by global -> LDS DMA through a three-stage ring.
+// csrc/gemm_dma_f32.hip -- the dense contractions of the SO(3) convolution on the fp32 matrix cores: ONE wave per
+// SIMD, operands fed by global -> LDS DMA through a four-stage ring.
 //
 //     C_z[M,N] = op(A_z)[M,K] * op(B_z)[K,N]            row-major, z = batch item (optionally x k-split)
 //
@@ -10,27 +10,36 @@
 //   textbook backward's dX = W^T dY (A stored [K,M], B row-contiguous).
 // Exact fp32: v_mfma_f32_32x32x2_f32 is an fmaf chain, no reduced-precision path.
 //
-// Why a second GEMM kernel: csrc/gemm_f32.hip stages operands through registers (global -> VGPR -> ds_write, 12
-// scalar LDS stores per k-tile for k-contiguous operands) and drains everything at one __syncthreads per 16-deep
-// k-tile; rocprofv3 counters (profiles/r02_a_*): matrix pipe busy 83 %, waves parked 14 % of their cycles.  Here
-//   * operands go global -> LDS by DMA (global_load_lds_dwordx4): no staging registers, no LDS store pass;
-//   * three LDS stages, the DMA runs two k-tiles ahead, waits are COUNTED (vmcnt(N), never 0 inside the loop) and
-//     the one barrier per k-tile is a raw s_barrier, so loads stay in flight across it;
+// Design, from the counters (profiles/r02_gemm_pmc.json):
+//   csrc/gemm_f32.hip (register staging, 2 x 8 waves per CU, one __syncthreads per k-tile): matrix pipe busy 81 %,
+//   waves parked 21 % of their cycles.  A first DMA version with the same 2 x 8-wave geometry: 86 %.  The vendor
+//   library's kernel on the same product: 96 % -- with ONE wave per SIMD that owns the matrix pipe.  Sixteen waves in
+//   two barrier groups keep stalling each other: whenever a group waits for its slowest wave, the gaps of the other
+//   group on that SIMD go unfilled.  So here:
+//   * a workgroup is 4 waves, one per SIMD, each with a (32 MI) x (32 NI) tile of accumulators (up to 128 x 128 =
+//     256 VGPRs; the file is 512 per lane with one wave per SIMD); block tile 256 x 256 (or 128 x 256 / 256 x 128);
+//   * operands go global -> LDS by DMA (global_load_lds_dwordx4): no staging registers, no LDS store pass; the DMA
+//     instructions are issued one per MFMA k-step from inside the MFMA stream, never in a burst;
+//   * four LDS stages of one 16-deep k-tile each; the DMA runs three tiles ahead, waits are COUNTED (vmcnt(N)) and
+//     the one barrier per k-tile is a raw s_barrier, so loads stay in flight across it.  The barrier of tile t
+//     certifies tile t + 1, so the fragments of the next tile's first k-block are read BEFORE the current tile's
+//     last MFMAs are issued: the matrix pipe never waits for LDS behind a barrier;
 //   * k-contiguous operand: LDS image [row][4 k-blocks of 16 bytes] with the k-block slot XOR-ed by (row >> 2) & 3
 //     -- applied on the per-lane SOURCE address of the DMA (its destination is lane-linear) and on the
-//     ds_read_b128 address -- so the fragment reads (32 rows x 16 bytes per half-wave) are bank-conflict free; one
-//     ds_read_b128 per row feeds TWO MFMA k-steps (elements {h, 2 + h} for the half-wave h);
+//     ds_read_b128 address -- so the fragment reads (32 rows x 16 bytes per half-wave) are bank-conflict free
+//     (SQ_LDS_BANK_CONFLICT = 0); one ds_read_b128 per row feeds TWO MFMA k-steps (elements {h, 2 + h} for the
+//     half-wave h);
 //   * row-contiguous operand ([K][rows] in memory): LDS image [k][rows], fragment = 32 consecutive floats per
 //     half-wave (conflict-free ds_read_b32).  Both images use the same k <-> (step, half-wave) assignment.
-// Block tile (64 NWM) x 128 x 16, NWM x 2 waves, wave tile 64 x 64 (2 x 2 MFMA tiles); 72 KB of LDS at NWM = 4 and
-// <= 128 VGPRs: two workgroups per CU.
 #include "common.h"
+
+#include <type_traits>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16, BN = 128, NWN = 2, STAGES = 3;
+constexpr int BK = 16, STAGES = 4, NT = 256;
 
 __device__ inline unsigned lds_addr(const void *ptr) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
@@ -52,13 +61,18 @@ struct DmaArgs {
     int splits, kchunk;          // k-splits per batch item (1 = plain GEMM), K elements per split (multiple of BK)
 };
 
-struct Frag { float4 q[2]; float s[2][2]; };
+// fragments of one k-block of an operand: k-contiguous image -> NI_ x 16 bytes (q), row-contiguous -> 2 x NI_ floats (s)
+template <int NI_>
+struct Frag { float4 q[NI_]; float s[2][NI_]; };
 
-// AKM: A stored [K, M] (m contiguous) instead of [M, K];  BKN: B stored [K, N] (n contiguous) instead of [N, K]
-template <int NWM, bool AKM, bool BKN>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_dma_f32_kernel(DmaArgs g) {
-    constexpr int BM = 64 * NWM, NT = 64 * NWM * NWN;
-    constexpr int A_PIECES = BM * 4 / NT, B_PIECES = BN * 4 / NT;      // 16-byte DMA pieces per thread and stage
+// WM x WN = 4 waves, wave tile (32 MI) x (32 NI).  AKM: A stored [K, M] (m contiguous) instead of [M, K];
+// BKN: B stored [K, N] (n contiguous) instead of [N, K]
+template <int WM, int WN, int MI, int NI, bool AKM, bool BKN>
+__global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
+    static_assert(WM * WN == 4, "four waves: one per SIMD");
+    constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+    constexpr int A_PIECES = BM * 4 / NT, B_PIECES = BN * 4 / NT, NP = A_PIECES + B_PIECES;   // 16-byte DMA pieces per thread and stage
+    static_assert(NP <= 8, "one DMA piece per MFMA k-step");
     constexpr unsigned STAGE_BYTES = (BM + BN) * BK * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_dma_f32_kernel(DmaArgs
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / NWN, wn = wave % NWN;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     // ---- DMA sources ----------------------------------------------------------------------------------------
@@ -127,124 +141,139 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_dma_f32_kernel(DmaArgs
             srcB[v] += stepB;
         }
     };
-    auto issue = [&](int stage) {
+    auto issue_tile = [&](int stage) {
 #pragma unroll
-        for (int u = 0; u < A_PIECES + B_PIECES; ++u) issue_piece(u, stage);
+        for (int u = 0; u < NP; ++u) issue_piece(u, stage);
     };
 
-    // ---- fragment read offsets (floats).  k-contiguous image: row (li), slot j ^ ((li >> 2) & 3), the second MFMA
+    // ---- fragment read offsets (floats).  k-contiguous image: row (li), slot j ^ ((li >> 2) & 3), the i-th MFMA
     // tile of the operand 32 rows = 512 floats further.  row-contiguous image [k][R]: element (k, row) ----
     int offA[4], offB[4];
     {
         const int c = (li >> 2) & 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            offA[j] = AKM ? 0 : (wm * 64 + li) * 16 + ((j ^ c) << 2);
-            offB[j] = BKN ? 0 : BM * 16 + (wn * 64 + li) * 16 + ((j ^ c) << 2);
+            offA[j] = AKM ? 0 : (wm * 32 * MI + li) * 16 + ((j ^ c) << 2);
+            offB[j] = BKN ? 0 : BM * 16 + (wn * 32 * NI + li) * 16 + ((j ^ c) << 2);
         }
     }
-    const int rowA = lh * BM + wm * 64 + li;                    // [k][BM] image: + k0 * BM, k0 = 4j (+2)
-    const int rowB = BM * 16 + lh * BN + wn * 64 + li;          // [k][BN] image
+    const int rowA = lh * BM + wm * 32 * MI + li;               // [k][BM] image: + k0 * BM, k0 = 4j (+2)
+    const int rowB = BM * 16 + lh * BN + wn * 32 * NI + li;     // [k][BN] image
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // operands of the two MFMA k-steps of k-block j: step 0 takes k = 4j + h, step 1 k = 4j + 2 + h (h = half-wave)
-    auto load_a = [&](const float *sf, int j, Frag &f) {
+    auto load_a = [&](const float *sf, int j, Frag<MI> &f) {
         if (!AKM) {
-            f.q[0] = *reinterpret_cast<const float4 *>(sf + offA[j]);
-            f.q[1] = *reinterpret_cast<const float4 *>(sf + offA[j] + 512);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f.q[i] = *reinterpret_cast<const float4 *>(sf + offA[j] + i * 512);
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) f.s[s][i] = sf[rowA + (4 * j + 2 * s) * BM + i * 32];
+                for (int i = 0; i < MI; ++i) f.s[s][i] = sf[rowA + (4 * j + 2 * s) * BM + i * 32];
         }
     };
-    auto load_b = [&](const float *sf, int j, Frag &f) {
+    auto load_b = [&](const float *sf, int j, Frag<NI> &f) {
         if (!BKN) {
-            f.q[0] = *reinterpret_cast<const float4 *>(sf + offB[j]);
-            f.q[1] = *reinterpret_cast<const float4 *>(sf + offB[j] + 512);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) f.q[i] = *reinterpret_cast<const float4 *>(sf + offB[j] + i * 512);
         } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) f.s[s][i] = sf[rowB + (4 * j + 2 * s) * BN + i * 32];
+                for (int i = 0; i < NI; ++i) f.s[s][i] = sf[rowB + (4 * j + 2 * s) * BN + i * 32];
         }
     };
-    auto pick = [&](const Frag &f, bool rowmajor, int s, int i) -> float {
-        if (rowmajor) return f.s[s][i];
-        const float4 v = f.q[i];
-        return s == 0 ? (lh ? v.y : v.x) : (lh ? v.w : v.z);
-    };
+    auto pick = [&](const float4 &v, int s) -> float { return s == 0 ? (lh ? v.y : v.x) : (lh ? v.w : v.z); };
 
     const int nt = (kend - kbeg) / BK;
-    if (nt > 0) issue(0);
-    if (nt > 1) issue(1);
+    const float *lds_f = reinterpret_cast<const float *>(smem);
+    // two fragment sets, named (never indexed at run time: they must stay in registers)
+    Frag<MI> fa0, fa1;
+    Frag<NI> fb0, fb1;
+    if (nt > 0) {
+        issue_tile(0);
+        if (nt > 1) issue_tile(1);
+        if (nt > 2) issue_tile(2);
+        if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_a(lds_f, 0, fa0);
+        load_b(lds_f, 0, fb0);
+    }
     int stage = 0;
     for (int it = 0; it < nt; ++it) {
-        // my pieces of k-tile `it` have landed (those of it + 1 may still be in flight) ...
-        if (it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PIECES + B_PIECES) : "memory");
+        // my pieces of k-tile it + 1 have landed (those of it + 2 may still be in flight) ...
+        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and so have everyone's; everyone has finished reading k-tile it - 1, whose stage is refilled next
+        // ... and so have everyone's; everyone has finished reading k-tile it - 1, whose stage takes k-tile it + 3
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                                   // no LDS read may move above the barrier
-        // k-tile it + 2 goes to the stage everyone has just left; its pieces are requested one per k-block, from
-        // the MIDDLE of the block's MFMAs: eight waves bursting 24 DMA instructions right behind the barrier
-        // queue on the CU's one address path and nobody reaches an MFMA until it drains (13 % of the kernel in
-        // the first version of this loop)
-        const bool more = it + 2 < nt;
-        const int nstage = stage >= 1 ? stage - 1 : STAGES - 1;          // (it + 2) % 3 == (stage + 2) % 3
-        const float *sf = reinterpret_cast<const float *>(smem) + (size_t)stage * (STAGE_BYTES / 4);
-        // fragments of k-block j + 1 are requested before the MFMAs of k-block j are issued
-        Frag fa[2], fb[2];
-        load_a(sf, 0, fa[0]);
-        load_b(sf, 0, fb[0]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cur = j & 1, nxt = cur ^ 1;
+        const bool more = it + 3 < nt;
+        const bool next_tile = it + 1 < nt;
+        const int nstage = stage == 0 ? STAGES - 1 : stage - 1;          // (it + 3) % 4
+        const int fstage = stage + 1 == STAGES ? 0 : stage + 1;          // (it + 1) % 4
+        const float *sf = lds_f + (size_t)stage * (STAGE_BYTES / 4);
+        const float *sn = lds_f + (size_t)fstage * (STAGE_BYTES / 4);
+        // one k-block: request the NEXT block's fragments (of the next k-tile after the last block), then the
+        // 2 x MI x NI MFMAs of this one with one DMA piece of k-tile it + 3 per k-step inside the MFMA stream
+        auto kblock = [&](auto jc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) {
+            constexpr int j = decltype(jc)::value;
             if (j < 3) {
-                load_a(sf, j + 1, fa[nxt]);
-                load_b(sf, j + 1, fb[nxt]);
+                load_a(sf, j + 1, na_);
+                load_b(sf, j + 1, nb_);
+            } else if (next_tile) {
+                load_a(sn, 0, na_);
+                load_b(sn, 0, nb_);
             }
-            float a[2][2], b[2][2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) { a[s][i] = pick(fa[cur], AKM, s, i); b[s][i] = pick(fb[cur], BKN, s, i); }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b[s][0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], b[s][1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b[s][0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], b[s][1], acc[1][1], 0, 0, 0);
-                if (s == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more && j < A_PIECES + B_PIECES) issue_piece(j, nstage);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                float a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = AKM ? ca.s[s][i] : pick(ca.q[i], s);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) b[i] = BKN ? cb.s[s][i] : pick(cb.q[i], s);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NI; ++jn) {
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+                        if (i == 0 && jn == NI - 1 && 2 * j + s < NP) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue_piece(2 * j + s, nstage);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
+        };
+        kblock(std::integral_constant<int, 0>{}, fa0, fb0, fa1, fb1);
+        kblock(std::integral_constant<int, 1>{}, fa1, fb1, fa0, fb0);
+        kblock(std::integral_constant<int, 2>{}, fa0, fb0, fa1, fb1);
+        kblock(std::integral_constant<int, 3>{}, fa1, fb1, fa0, fb0);
+        stage = fstage;
     }
 
     // ---- epilogue: D[i][j] of a 32x32 tile sits at col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5):
     // per register the two half-waves write one 128-byte row segment each
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + li;
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * 32 * NI + j * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M && col < g.N) C[(long long)row * g.ldc + col] = acc[i][j][r];
             }
         }
@@ -260,28 +289,32 @@ __global__ void dma_reduce_slabs_kernel(long long mn, int N, int slabs, const fl
     C[(e / N) * ldc + (e % N)] = s;
 }
 
-template <int NWM, bool AKM, bool BKN>
+template <int WM, int WN, int MI, int NI, bool AKM, bool BKN>
 int launch_one(DmaArgs g, int zcount, hipStream_t s) {
-    constexpr int BM = 64 * NWM;
+    constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     const size_t shmem = (size_t)STAGES * (BM + BN) * BK * 4;
-    auto kern = gemm_dma_f32_kernel<NWM, AKM, BKN>;
+    auto kern = gemm_dma_f32_kernel<WM, WN, MI, NI, AKM, BKN>;
     int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
                           "gemm_dma_f32 shared memory");
     if (e) return e;
-    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, zcount), dim3(64 * NWM * NWN), shmem, s, g);
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, zcount), dim3(NT), shmem, s, g);
     return eap::check_launch("gemm_dma_f32");
+}
+
+template <bool AKM, bool BKN>
+int launch_shape(const DmaArgs &g, int zcount, hipStream_t s) {
+    // block tile 256 x 256 (wave tile 128 x 128); 128 x 256 for M <= 128; 256 x 128 for N <= 128
+    if (g.M <= 128) return launch_one<1, 4, 4, 2, AKM, BKN>(g, zcount, s);
+    if (g.N <= 128) return launch_one<4, 1, 2, 4, AKM, BKN>(g, zcount, s);
+    return launch_one<2, 2, 4, 4, AKM, BKN>(g, zcount, s);
 }
 
 int launch(bool akm, bool bkn, const DmaArgs &g, int zcount, hipStream_t s) {
     if (zcount > 65535) return eap::bad_arg("gemm_dma_f32: batch * splits exceeds 65535");
-    if (g.M > 128) {
-        if (akm) return bkn ? launch_one<4, true, true>(g, zcount, s) : launch_one<4, true, false>(g, zcount, s);
-        return bkn ? launch_one<4, false, true>(g, zcount, s) : launch_one<4, false, false>(g, zcount, s);
-    }
-    if (akm) return bkn ? launch_one<2, true, true>(g, zcount, s) : launch_one<2, true, false>(g, zcount, s);
-    return bkn ? launch_one<2, false, true>(g, zcount, s) : launch_one<2, false, false>(g, zcount, s);
+    if (akm) return bkn ? launch_shape<true, true>(g, zcount, s) : launch_shape<true, false>(g, zcount, s);
+    return bkn ? launch_shape<false, true>(g, zcount, s) : launch_shape<false, false>(g, zcount, s);
 }
 
 bool supported(int transA, int transB, int M, int N, int K, const float *A, int64_t lda, int64_t sA, const float *B,
@@ -295,9 +328,10 @@ bool supported(int transA, int transB, int M, int N, int K, const float *A, int6
 }
 
 int pick_splits(int M, int N, int K, int batch) {
-    // enough blocks to fill 256 CUs about three times over, at least 8 k-tiles per split
-    const int tiles = ((M + 255) / 256) * ((N + BN - 1) / BN) * batch;
-    int splits = (1536 + tiles - 1) / tiles;
+    // one workgroup per CU: enough blocks to fill 256 CUs about four times over, at least 8 k-tiles per split
+    const int bm = M <= 128 ? 128 : 256, bn = N <= 128 ? 128 : 256;
+    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+    int splits = (1024 + tiles - 1) / tiles;
     const int max_splits = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -2,3 +2,4 @@ from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose  # noqa: F4
 from .functional import *  # noqa: F401,F403
 from .modules import *  # noqa: F401,F403
 from .blocks import BatchNormLeakyReLU, InstanceNormLeakyReLU  # noqa: F401
+from .heads import InvPPOutBlockOurs, anchor_attention_pool, orbit_selection, slot_masked_mean, rotation_from_angle_axis  # noqa: F401

@@ -322,6 +322,21 @@ int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, const float *
                              const float *invstd, const float *k2, const float *k3, float *gx,
                              eap_stream_t stream);
 
+/* ---- heads on the backbone's [b,c,n,na] feature map ------------------------ */
+/* Anchor attention pooling, InvPPOutBlockOurs.forward (SPConvNets/utils/base_so3conv.py:L905-912):
+ * conf[b,n,a] = softmax_a(logits[b,n,a] * temperature), out[b,c,n] = sum_a x[b,c,n,a] conf[b,n,a].  na % 4 == 0, <= 64.
+ * Backward: dx [b,c,n,na], dlogits [b,n,na] from g [b,c,n]. */
+int eap_anchor_attn_pool_fwd_f32(int b, int c, int n, int na, float temperature, const float *x, const float *logits,
+                                 float *out, float *conf, eap_stream_t stream);
+int eap_anchor_attn_pool_bwd_f32(int b, int c, int n, int na, float temperature, const float *x, const float *logits,
+                                 const float *g, float *dx, float *dlogits, eap_stream_t stream);
+/* Masked point averages of every slot in one pass (SO3OutBlockRTWithMaskSep, SPConvNets/models/model_utils.py:L470-484,
+ * L549-552): out[b,s,c,a] = inv_den[b,s] * sum_n mask[b,s,n] x[b,c,n,a];  ns <= 8.  Backward w.r.t. x. */
+int eap_slot_masked_mean_fwd_f32(int b, int ns, int c, int n, int na, const float *x, const float *mask,
+                                 const float *inv_den, float *out, eap_stream_t stream);
+int eap_slot_masked_mean_bwd_f32(int b, int ns, int c, int n, int na, const float *g, const float *mask,
+                                 const float *inv_den, float *dx, eap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,3 +290,70 @@ def test_strided_pose_free_conv(dev):
     np.testing.assert_array_equal(sample_idx.cpu().numpy(), sidx.numpy())
     np.testing.assert_array_equal(inter_idx.cpu().numpy(), idx.numpy())
     assert rel_err(out.feats.detach().cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_anchor_attention_pool_and_invariant_head(dev):
+    """InvPPOutBlockOurs (base_so3conv.py:L842-917) with attention pooling -- the fused
+    anchor softmax + weighted sum against the reference's torch formulation, outputs and all gradients."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    torch.manual_seed(12)
+    params = {'dim_in': 24, 'mlp': [16, 12], 'fc': [12], 'k': 12, 'kanchor': 60, 'temperature': 3.0}
+    head = sptk.InvPPOutBlockOurs(params, pooling_method='attention').to(dev)
+    x = torch.randn(2, 24, 37, 60, device=dev, requires_grad=True)
+    out, conf = head(zptk.SphericalPointCloud(None, x, None))
+    # reference formulation in plain torch on the same device
+    xr = x.detach().clone().requires_grad_(True)
+    h = xr
+    for lid, lin in enumerate(head.linear):
+        h = F_relu(head.norm[lid](lin(h)))
+    logit = head.attention_layer(h)
+    cref = torch.softmax(logit * 3.0, dim=-1)
+    oref = (h * cref).sum(-1)
+    assert out.shape == (2, 12, 37) and conf.shape == (2, 37, 60)
+    assert rel_err(out.detach().cpu().numpy(), oref.detach().cpu().numpy()) < 2e-6
+    assert rel_err(conf.cpu().numpy(), cref.squeeze(1).detach().cpu().numpy()) < 2e-6
+    g = torch.randn_like(out)
+    names = [n for n, _ in head.named_parameters()]
+    grads = torch.autograd.grad(out, [x] + list(head.parameters()), g, retain_graph=True)
+    grefs = torch.autograd.grad(oref, [xr] + list(head.parameters()), g)
+    for nme, a, b in zip(['x'] + names, grads, grefs):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, nme
+    # the other pooling modes are plain reductions
+    for mode in ('max', 'mean'):
+        h2 = sptk.InvPPOutBlockOurs(params, pooling_method=mode).to(dev)
+        assert h2(zptk.SphericalPointCloud(None, x.detach(), None)).shape == (2, 12, 37)
+
+
+def F_relu(t):
+    return torch.nn.functional.relu(t)
+
+
+def test_slot_masked_mean_and_orbit_selection(dev):
+    """the per-slot masked point averages of the pose head, every slot in one pass, against
+    torch; and the orbit arg-min of ...pn_38_multi_stage.py:L1381-1399."""
+    import vgtk.so3conv as sptk
+    torch.manual_seed(13)
+    b, c, n, na, ns = 2, 19, 333, 60, 3
+    x = torch.randn(b, c, n, na, device=dev, requires_grad=True)
+    mask = (torch.rand(b, ns, n, device=dev) > 0.6).float()
+    mask[0, 2] = 0.0                                               # an empty slot: clamp(min=1e-8) -> zeros
+    out = sptk.slot_masked_mean(x, mask)
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.einsum('bcna,bsn->bsca', xr, mask) / mask.sum(-1).clamp(min=1e-8)[:, :, None, None]
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-6
+    g = torch.randn_like(out)
+    assert rel_err(torch.autograd.grad(out, x, g)[0].cpu().numpy(), torch.autograd.grad(ref, xr, g)[0].cpu().numpy()) < 2e-6
+    soft = torch.rand(b, ns, n, device=dev)
+    assert rel_err(sptk.slot_masked_mean(x.detach(), soft).cpu().numpy(),
+                   (torch.einsum('bcna,bsn->bsca', x.detach(), soft) / soft.sum(-1)[:, :, None, None]).cpu().numpy()) < 2e-6
+    d1, d2 = torch.rand(b, ns, 60, device=dev), torch.rand(b, ns, 60, device=dev)
+    dist, orbit = sptk.orbit_selection(d1, d2)
+    assert torch.equal(orbit, (d1 + d2).argmin(-1)) and torch.equal(dist, (d1 + d2).min(-1)[0])
+    dist, orbit = sptk.orbit_selection(d1, d2, slot_single_cd=1, slot_single_mode=1)
+    assert torch.equal(orbit[:, 0], d1.sum(1).argmin(-1)) and orbit.shape == (b, ns)
+    ang = torch.rand(5, 7, device=dev) * 6.0
+    ax = torch.nn.functional.normalize(torch.randn(5, 7, 3, device=dev), dim=-1)
+    R = sptk.rotation_from_angle_axis(ang, ax)
+    assert rel_err((R @ R.transpose(-1, -2)).cpu().numpy(), torch.eye(3).expand(5, 7, 3, 3).numpy()) < 1e-5
+    assert rel_err((R @ ax.unsqueeze(-1)).squeeze(-1).cpu().numpy(), ax.cpu().numpy()) < 1e-5
