@@ -1,5 +1,5 @@
 // csrc/gemm_dma_f32.hip -- the dense contractions of the SO(3) convolution on the fp32 matrix cores: ONE wave per
-// SIMD, operands fed by global -> LDS DMA through a four-stage ring.
+// SIMD, 256 accumulator registers per wave, operands streamed through a three-stage LDS ring.
 //
 //     C_z[M,N] = op(A_z)[M,K] * op(B_z)[K,N]            row-major, z = batch item (optionally x k-split)
 //
@@ -10,47 +10,40 @@
 //   textbook backward's dX = W^T dY (A stored [K,M], B row-contiguous).
 // Exact fp32: v_mfma_f32_32x32x2_f32 is an fmaf chain, no reduced-precision path.
 //
-// Design, from the counters (profiles/r02_gemm_pmc.json):
-//   csrc/gemm_f32.hip (register staging, 2 x 8 waves per CU, one __syncthreads per k-tile): matrix pipe busy 81 %,
-//   waves parked 21 % of their cycles.  A first DMA version with the same 2 x 8-wave geometry: 86 %.  The vendor
-//   library's kernel on the same product: 96 % -- with ONE wave per SIMD that owns the matrix pipe.  Sixteen waves in
-//   two barrier groups keep stalling each other: whenever a group waits for its slowest wave, the gaps of the other
-//   group on that SIMD go unfilled.  So here:
-//   * a workgroup is 4 waves, one per SIMD, each with a (32 MI) x (32 NI) tile of accumulators (up to 128 x 128 =
-//     256 VGPRs; the file is 512 per lane with one wave per SIMD); block tile 256 x 256 (or 128 x 256 / 256 x 128);
-//   * operands go global -> LDS by DMA (global_load_lds_dwordx4): no staging registers, no LDS store pass; the DMA
-//     instructions are issued one per MFMA k-step from inside the MFMA stream, never in a burst;
-//   * four LDS stages of one 16-deep k-tile each; the DMA runs three tiles ahead, waits are COUNTED (vmcnt(N)) and
-//     the one barrier per k-tile is a raw s_barrier, so loads stay in flight across it.  The barrier of tile t
-//     certifies tile t + 1, so the fragments of the next tile's first k-block are read BEFORE the current tile's
-//     last MFMAs are issued: the matrix pipe never waits for LDS behind a barrier;
-//   * k-contiguous operand: LDS image [row][4 k-blocks of 16 bytes] with the k-block slot XOR-ed by (row >> 2) & 3
-//     -- applied on the per-lane SOURCE address of the DMA (its destination is lane-linear) and on the
-//     ds_read_b128 address -- so the fragment reads (32 rows x 16 bytes per half-wave) are bank-conflict free
+// Design, step by step from the counters (profiles/r02_gemm_pmc.json; SQ_VALU_MFMA_BUSY_CYCLES / cycles / SIMDs):
+//   1. csrc/gemm_f32.hip -- register staging, 2 x 8 waves per CU, one __syncthreads per k-tile: matrix pipe busy
+//      81 %, waves parked (SQ_WAIT_ANY) 21 % of their cycles.  The vendor library's kernel on the same product:
+//      96 %, with ONE wave per SIMD that owns the matrix pipe and nobody to wait for.
+//   2. global -> LDS DMA (global_load_lds_dwordx4) instead of register staging, same 2 x 8-wave geometry: 86 %.
+//   3. one wave per SIMD, 128 x 128 accumulator tile per wave, DMA-fed 4-stage ring: parked time 21 % -> 5 %, but
+//      still 86 % busy: with a single wave per SIMD nothing covers the issue cost of a DMA instruction (60-180
+//      cycles each against the 64-cycle shadow of an MFMA; eight per k-tile).
+//   4. this file: one wave per SIMD, and the operands travel global -> VGPR -> LDS.  A plain global_load_dwordx4
+//      issues in a few cycles, its data is not needed until the NEXT k-tile (eight staging quads = 32 of the 512
+//      VGPRs a lone wave owns), and the ds_write_b128 that parks it in LDS is one more filler in an MFMA shadow:
+//      per MFMA k-step exactly one load and one store ride along.
+// Pipeline (all waits by the compiler, no inline asm): tile t is multiplied out of stage t % 3 while tile t + 2 is
+// being written into stage (t + 2) % 3 from registers loaded during tile t - 1, and tile t + 3 is being loaded.  One
+// __syncthreads per k-tile; the barrier of tile t certifies stage (t + 1) % 3, so the fragments of the next tile's
+// first k-block are read BEFORE the current tile's last MFMAs are issued: the pipe never waits for LDS behind a
+// barrier.
+//   * k-contiguous operand: LDS image [row][4 k-blocks of 16 bytes], the k-block slot XOR-ed by (row >> 2) & 3 on
+//     the ds_write and the ds_read_b128 side: fragment reads (32 rows x 16 bytes per half-wave) are conflict-free
 //     (SQ_LDS_BANK_CONFLICT = 0); one ds_read_b128 per row feeds TWO MFMA k-steps (elements {h, 2 + h} for the
 //     half-wave h);
 //   * row-contiguous operand ([K][rows] in memory): LDS image [k][rows], fragment = 32 consecutive floats per
 //     half-wave (conflict-free ds_read_b32).  Both images use the same k <-> (step, half-wave) assignment.
+// Block tile 256 x 256 (wave tile 128 x 128), or 128 x 256 / 256 x 128 for small M / N; 96 KB of LDS.
 #include "common.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16, STAGES = 4, NT = 256;
-
-__device__ inline unsigned lds_addr(const void *ptr) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
-}
-// wave-wide 16-byte-per-lane global -> LDS DMA (lane l's bytes land at lds_dst + 16 l); inline asm so that
-// hipcc's waitcnt bookkeeping does not drain it at the next LDS read -- waits are placed by hand below
-__device__ inline void glds16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
+constexpr int BK = 16, STAGES = 3, NT = 256;
 
 struct DmaArgs {
     int M, N, K;
@@ -60,6 +53,23 @@ struct DmaArgs {
     int tiles_m, tiles_n;
     int splits, kchunk;          // k-splits per batch item (1 = plain GEMM), K elements per split (multiple of BK)
 };
+
+// the k-tile in flight: eight named 16-byte quads (an indexed array of vectors is not promoted to registers)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct Staging {
+    f32x4 v0, v1, v2, v3, v4, v5, v6, v7;
+    template <int U>
+    __device__ __forceinline__ f32x4 &at() {
+        if constexpr (U == 0) return v0; else if constexpr (U == 1) return v1; else if constexpr (U == 2) return v2;
+        else if constexpr (U == 3) return v3; else if constexpr (U == 4) return v4; else if constexpr (U == 5) return v5;
+        else if constexpr (U == 6) return v6; else return v7;
+    }
+};
+
+template <typename F, int... U>
+__device__ __forceinline__ void for_each_piece(F &&f, std::integer_sequence<int, U...>) {
+    (f(std::integral_constant<int, U>{}), ...);
+}
 
 // fragments of one k-block of an operand: k-contiguous image -> NI_ x 16 bytes (q), row-contiguous -> 2 x NI_ floats (s)
 template <int NI_>
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
     static_assert(WM * WN == 4, "four waves: one per SIMD");
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     constexpr int A_PIECES = BM * 4 / NT, B_PIECES = BN * 4 / NT, NP = A_PIECES + B_PIECES;   // 16-byte DMA pieces per thread and stage
-    static_assert(NP <= 8, "one DMA piece per MFMA k-step");
+    static_assert(NP >= 4 && NP <= 8, "one staged piece per MFMA k-step");
     constexpr unsigned STAGE_BYTES = (BM + BN) * BK * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -99,52 +109,64 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    // ---- DMA sources ----------------------------------------------------------------------------------------
-    // k-contiguous tile: piece q = (row q >> 2, LDS slot q & 3) holds k-block (q & 3) ^ ((row >> 2) & 3)
-    // row-contiguous tile: piece q = (k q / (R/4), 4 rows starting at 4 (q % (R/4)))
-    const float *srcA[A_PIECES], *srcB[B_PIECES];
+    // ---- staging: thread t moves NP 16-byte pieces per k-tile, global -> VGPR -> LDS ------------------------------
+    // k-contiguous tile: piece q = (row q >> 2, k-block q & 3), parked at LDS slot (q & 3) ^ ((row >> 2) & 3) of its row
+    // row-contiguous tile: piece q = (k q / (R/4), 4 rows starting at 4 (q % (R/4))), LDS image [k][R]
+    const float *src[NP];
+    int ldsoff[NP];                                              // floats, within a stage
 #pragma unroll
-    for (int u = 0; u < A_PIECES; ++u) {
-        const int q = u * NT + t;
-        if (!AKM) {
-            const int row = q >> 2, j = (q & 3) ^ ((row >> 2) & 3);
-            srcA[u] = A + (long long)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * j;
+    for (int u = 0; u < NP; ++u) {
+        const bool isA = u < A_PIECES;
+        const int q = (isA ? u : u - A_PIECES) * NT + t;
+        if (isA) {
+            if (!AKM) {
+                const int row = q >> 2, j = q & 3;
+                src[u] = A + (long long)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * j;
+                ldsoff[u] = row * 16 + ((j ^ ((row >> 2) & 3)) << 2);
+            } else {
+                const int k = q / (BM / 4), c4 = (q % (BM / 4)) * 4;
+                src[u] = A + (long long)(kbeg + k) * g.lda + min(m0 + c4, g.M - 4);
+                ldsoff[u] = k * BM + c4;
+            }
         } else {
-            const int k = q / (BM / 4), c4 = (q % (BM / 4)) * 4;
-            srcA[u] = A + (long long)(kbeg + k) * g.lda + min(m0 + c4, g.M - 4);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < B_PIECES; ++u) {
-        const int q = u * NT + t;
-        if (!BKN) {
-            const int row = q >> 2, j = (q & 3) ^ ((row >> 2) & 3);
-            srcB[u] = B + (long long)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * j;
-        } else {
-            const int k = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
-            srcB[u] = B + (long long)(kbeg + k) * g.ldb + min(n0 + c4, g.N - 4);
+            if (!BKN) {
+                const int row = q >> 2, j = q & 3;
+                src[u] = B + (long long)min(n0 + row, g.N - 1) * g.ldb + kbeg + 4 * j;
+                ldsoff[u] = BM * 16 + row * 16 + ((j ^ ((row >> 2) & 3)) << 2);
+            } else {
+                const int k = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
+                src[u] = B + (long long)(kbeg + k) * g.ldb + min(n0 + c4, g.N - 4);
+                ldsoff[u] = BM * 16 + k * BN + c4;
+            }
         }
     }
     const long long stepA = AKM ? (long long)BK * g.lda : BK;
     const long long stepB = BKN ? (long long)BK * g.ldb : BK;
-    const unsigned lds0 = lds_addr(smem);
-    const unsigned dstA = lds0 + (unsigned)wave * 1024u, dstB = lds0 + (unsigned)BM * 64u + (unsigned)wave * 1024u;
-    // one DMA piece (u < A_PIECES: of the A tile, else of the B tile) of the k-tile that goes to `stage`
-    auto issue_piece = [&](int u, int stage) {
-        const unsigned sb = (unsigned)stage * STAGE_BYTES;
-        if (u < A_PIECES) {
-            glds16(srcA[u], __builtin_amdgcn_readfirstlane(dstA + sb + (unsigned)u * (NT * 16u)));
-            srcA[u] += stepA;
-        } else {
-            const int v = u - A_PIECES;
-            glds16(srcB[v], __builtin_amdgcn_readfirstlane(dstB + sb + (unsigned)v * (NT * 16u)));
-            srcB[v] += stepB;
-        }
+    float *lds_w = reinterpret_cast<float *>(smem);
+    Staging stg;                                                 // the k-tile in flight
+    // (pieces are always named by compile-time constants: the arrays must stay in registers)
+    // `advance` = 0 past the last k-tile: the piece is simply re-read (never used) so that the loop body has no
+    // branch around a load and the compiler can count its waits (vmcnt(N), not vmcnt(0))
+    auto load_piece = [&](auto uc, long long advance = 1) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        stg.template at<u>() = *reinterpret_cast<const f32x4 *>(src[u]);
+        src[u] += (u < A_PIECES ? stepA : stepB) * advance;
     };
-    auto issue_tile = [&](int stage) {
-#pragma unroll
-        for (int u = 0; u < NP; ++u) issue_piece(u, stage);
+    auto park_piece = [&](auto uc, int stage) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        *reinterpret_cast<f32x4 *>(lds_w + (size_t)stage * (STAGE_BYTES / 4) + ldsoff[u]) = stg.template at<u>();
     };
+#define EAP_EACH_PIECE(STMT)                                                                                     \
+    do {                                                                                                         \
+        { constexpr std::integral_constant<int, 0> uc{}; STMT; }                                                 \
+        { constexpr std::integral_constant<int, 1> uc{}; STMT; }                                                 \
+        { constexpr std::integral_constant<int, 2> uc{}; STMT; }                                                 \
+        { constexpr std::integral_constant<int, 3> uc{}; STMT; }                                                 \
+        if constexpr (NP > 4) { constexpr std::integral_constant<int, 4> uc{}; STMT; }                           \
+        if constexpr (NP > 5) { constexpr std::integral_constant<int, 5> uc{}; STMT; }                           \
+        if constexpr (NP > 6) { constexpr std::integral_constant<int, 6> uc{}; STMT; }                           \
+        if constexpr (NP > 7) { constexpr std::integral_constant<int, 7> uc{}; STMT; }                           \
+    } while (0)
 
     // ---- fragment read offsets (floats).  k-contiguous image: row (li), slot j ^ ((li >> 2) & 3), the i-th MFMA
     // tile of the operand 32 rows = 512 floats further.  row-contiguous image [k][R]: element (k, row) ----
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // operands of the two MFMA k-steps of k-block j: step 0 takes k = 4j + h, step 1 k = 4j + 2 + h (h = half-wave)
-    auto load_a = [&](const float *sf, int j, Frag<MI> &f) {
+    auto load_a = [&](const float *sf, int j, Frag<MI> &f) __attribute__((always_inline)) {
         if (!AKM) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) f.q[i] = *reinterpret_cast<const float4 *>(sf + offA[j] + i * 512);
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
                 for (int i = 0; i < MI; ++i) f.s[s][i] = sf[rowA + (4 * j + 2 * s) * BM + i * 32];
         }
     };
-    auto load_b = [&](const float *sf, int j, Frag<NI> &f) {
+    auto load_b = [&](const float *sf, int j, Frag<NI> &f) __attribute__((always_inline)) {
         if (!BKN) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) f.q[i] = *reinterpret_cast<const float4 *>(sf + offB[j] + i * 512);
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
                 for (int i = 0; i < NI; ++i) f.s[s][i] = sf[rowB + (4 * j + 2 * s) * BN + i * 32];
         }
     };
-    auto pick = [&](const float4 &v, int s) -> float { return s == 0 ? (lh ? v.y : v.x) : (lh ? v.w : v.z); };
+    auto pick = [&](const float4 &v, int s) __attribute__((always_inline)) -> float { return s == 0 ? (lh ? v.y : v.x) : (lh ? v.w : v.z); };
 
     const int nt = (kend - kbeg) / BK;
     const float *lds_f = reinterpret_cast<const float *>(smem);
@@ -199,34 +221,55 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
     Frag<MI> fa0, fa1;
     Frag<NI> fb0, fb1;
     if (nt > 0) {
-        issue_tile(0);
-        if (nt > 1) issue_tile(1);
-        if (nt > 2) issue_tile(2);
-        if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-        else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        // tiles 0 and 1 into their stages, tile 2 into the staging registers
+        EAP_EACH_PIECE(load_piece(uc, nt > 1 ? 1 : 0));
+        EAP_EACH_PIECE(park_piece(uc, 0));
+        EAP_EACH_PIECE(load_piece(uc, nt > 2 ? 1 : 0));
+        EAP_EACH_PIECE(park_piece(uc, 1));
+        EAP_EACH_PIECE(load_piece(uc, nt > 3 ? 1 : 0));
+        __syncthreads();
         load_a(lds_f, 0, fa0);
         load_b(lds_f, 0, fb0);
     }
     int stage = 0;
     for (int it = 0; it < nt; ++it) {
-        // my pieces of k-tile it + 1 have landed (those of it + 2 may still be in flight) ...
-        if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and so have everyone's; everyone has finished reading k-tile it - 1, whose stage takes k-tile it + 3
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                                   // no LDS read may move above the barrier
-        const bool more = it + 3 < nt;
+        // everyone has finished reading k-tile it - 1 (its stage takes k-tile it + 2 now) and has parked its pieces
+        // of k-tile it + 1
+        if (it > 0) __syncthreads();
         const bool next_tile = it + 1 < nt;
-        const int nstage = stage == 0 ? STAGES - 1 : stage - 1;          // (it + 3) % 4
-        const int fstage = stage + 1 == STAGES ? 0 : stage + 1;          // (it + 1) % 4
+        const long long adv = it + 4 < nt ? 1 : 0;      // after loading k-tile it + 3 the pointers move on only if k-tile it + 4 exists
+        const int pstage = stage == 0 ? STAGES - 1 : stage - 1;          // (it + 2) % 3
+        const int fstage = stage + 1 == STAGES ? 0 : stage + 1;          // (it + 1) % 3
         const float *sf = lds_f + (size_t)stage * (STAGE_BYTES / 4);
         const float *sn = lds_f + (size_t)fstage * (STAGE_BYTES / 4);
         // one k-block: request the NEXT block's fragments (of the next k-tile after the last block), then the
-        // 2 x MI x NI MFMAs of this one with one DMA piece of k-tile it + 3 per k-step inside the MFMA stream
-        auto kblock = [&](auto jc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) {
+        // 2 x MI x NI MFMAs of this one; per k-step one staged piece of k-tile it + 2 is parked in LDS and its
+        // register reloaded with the same piece of k-tile it + 3, from inside the MFMA stream
+        auto kstep = [&](auto jc, auto sc, const Frag<MI> &ca, const Frag<NI> &cb) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, s = decltype(sc)::value, u = 2 * j + s;
+            float a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = AKM ? ca.s[s][i] : pick(ca.q[i], s);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) b[i] = BKN ? cb.s[s][i] : pick(cb.q[i], s);
+            __builtin_amdgcn_sched_barrier(0);                 // operands first, then the MFMA stream in this order
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+                    if constexpr (u < NP) {
+                        if (i == 0 && jn == NI - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            park_piece(std::integral_constant<int, u>{}, pstage);     // (a stage nobody reads once it + 2 >= nt)
+                            load_piece(std::integral_constant<int, u>{}, adv);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto kblock = [&](auto jc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             if (j < 3) {
                 load_a(sf, j + 1, na_);
@@ -235,27 +278,9 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
                 load_a(sn, 0, na_);
                 load_b(sn, 0, nb_);
             }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float a[MI], b[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = AKM ? ca.s[s][i] : pick(ca.q[i], s);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) b[i] = BKN ? cb.s[s][i] : pick(cb.q[i], s);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < NI; ++jn) {
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
-                        if (i == 0 && jn == NI - 1 && 2 * j + s < NP) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (more) issue_piece(2 * j + s, nstage);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);                 // the next block's fragment reads are issued HERE
+            kstep(jc, std::integral_constant<int, 0>{}, ca, cb);
+            kstep(jc, std::integral_constant<int, 1>{}, ca, cb);
         };
         kblock(std::integral_constant<int, 0>{}, fa0, fb0, fa1, fb1);
         kblock(std::integral_constant<int, 1>{}, fa1, fb1, fa0, fb0);

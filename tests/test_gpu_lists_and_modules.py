@@ -318,7 +318,9 @@ def test_anchor_attention_pool_and_invariant_head(dev):
     grads = torch.autograd.grad(out, [x] + list(head.parameters()), g, retain_graph=True)
     grefs = torch.autograd.grad(oref, [xr] + list(head.parameters()), g)
     for nme, a, b in zip(['x'] + names, grads, grefs):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, nme
+        # conv biases in front of a training-mode BatchNorm have an exactly-zero gradient (rounding noise on both sides)
+        scale = max(float(b.abs().max()), 1e-3)
+        assert float((a - b).abs().max()) < 2e-5 * scale, nme
     # the other pooling modes are plain reductions
     for mode in ('max', 'mean'):
         h2 = sptk.InvPPOutBlockOurs(params, pooling_method=mode).to(dev)
