@@ -36,6 +36,7 @@
 // Block tile 256 x 256 (wave tile 128 x 128), or 128 x 256 / 256 x 128 for small M / N; 96 KB of LDS.
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -77,7 +78,9 @@ struct Frag { float4 q[NI_]; float s[2][NI_]; };
 
 // WM x WN = 4 waves, wave tile (32 MI) x (32 NI).  AKM: A stored [K, M] (m contiguous) instead of [M, K];
 // BKN: B stored [K, N] (n contiguous) instead of [N, K]
-template <int WM, int WN, int MI, int NI, bool AKM, bool BKN>
+// DBG (timing experiments only, results are wrong for DBG > 0): 1 = no staging traffic inside the k-loop,
+// 2 = also no fragment reads, 3 = also no operand selection
+template <int WM, int WN, int MI, int NI, bool AKM, bool BKN, int DBG = 0>
 __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
     static_assert(WM * WN == 4, "four waves: one per SIMD");
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
@@ -245,24 +248,57 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
         // one k-block: request the NEXT block's fragments (of the next k-tile after the last block), then the
         // 2 x MI x NI MFMAs of this one; per k-step one staged piece of k-tile it + 2 is parked in LDS and its
         // register reloaded with the same piece of k-tile it + 3, from inside the MFMA stream
-        auto kstep = [&](auto jc, auto sc, const Frag<MI> &ca, const Frag<NI> &cb) __attribute__((always_inline)) {
+        // the r-th fragment read of k-block jn of the stage at `base` (A tiles first, then B tiles; a row-contiguous
+        // operand has two reads per tile, one per k-step)
+        constexpr int RA = AKM ? 2 * MI : MI, RB = BKN ? 2 * NI : NI, NREADS = RA + RB, NMFMA = 2 * MI * NI;
+        constexpr int SPAN = NMFMA - 8;
+        static_assert((NREADS - 1) * SPAN / NREADS + 1 < NMFMA, "fragment reads must fit in the k-block");
+        auto frag_read = [&](const float *base, int jn, int r, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
+            if (r < RA) {
+                if (!AKM) na_.q[r] = *reinterpret_cast<const float4 *>(base + offA[jn] + r * 512);
+                else na_.s[r / MI][r % MI] = base[rowA + (4 * jn + 2 * (r / MI)) * BM + (r % MI) * 32];
+            } else {
+                const int q = r - RA;
+                if (!BKN) nb_.q[q] = *reinterpret_cast<const float4 *>(base + offB[jn] + q * 512);
+                else nb_.s[q / NI][q % NI] = base[rowB + (4 * jn + 2 * (q / NI)) * BN + (q % NI) * 32];
+            }
+        };
+        // one MFMA k-step of k-block j.  Between the MFMAs ride, evenly spaced: the fragment reads of the NEXT
+        // k-block (a lone wave that issues its eight ds_read_b128 back to back leaves the matrix pipe idle for
+        // ~200 cycles per k-block: -10 % measured), one parked staging piece and its reload
+        auto kstep = [&](auto jc, auto sc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, s = decltype(sc)::value, u = 2 * j + s;
+            const float *nbase = j < 3 ? sf : sn;
+            constexpr int njn = j < 3 ? j + 1 : 0;
+            const bool do_reads = j < 3 || next_tile;
             float a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = AKM ? ca.s[s][i] : pick(ca.q[i], s);
+            for (int i = 0; i < MI; ++i) a[i] = DBG == 3 ? ca.q[i].x : AKM ? ca.s[s][i] : pick(ca.q[i], s);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) b[i] = BKN ? cb.s[s][i] : pick(cb.q[i], s);
+            for (int i = 0; i < NI; ++i) b[i] = DBG == 3 ? cb.q[i].x : BKN ? cb.s[s][i] : pick(cb.q[i], s);
             __builtin_amdgcn_sched_barrier(0);                 // operands first, then the MFMA stream in this order
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jn = 0; jn < NI; ++jn) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+                    const int gm = s * MI * NI + i * NI + jn;                  // MFMA number within the k-block
+                    if constexpr (DBG < 2) {
+#pragma unroll
+                        for (int r = 0; r < NREADS; ++r)
+                            if (r * SPAN / NREADS + 1 == gm) {                 // the last one >= 8 MFMAs before its use
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (do_reads) frag_read(nbase, njn, r, na_, nb_);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
                     if constexpr (u < NP) {
                         if (i == 0 && jn == NI - 1) {
                             __builtin_amdgcn_sched_barrier(0);
-                            park_piece(std::integral_constant<int, u>{}, pstage);     // (a stage nobody reads once it + 2 >= nt)
-                            load_piece(std::integral_constant<int, u>{}, adv);
+                            if constexpr (DBG == 0) {
+                                park_piece(std::integral_constant<int, u>{}, pstage);     // (a stage nobody reads once it + 2 >= nt)
+                                load_piece(std::integral_constant<int, u>{}, adv);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -270,17 +306,8 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         };
         auto kblock = [&](auto jc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            if (j < 3) {
-                load_a(sf, j + 1, na_);
-                load_b(sf, j + 1, nb_);
-            } else if (next_tile) {
-                load_a(sn, 0, na_);
-                load_b(sn, 0, nb_);
-            }
-            __builtin_amdgcn_sched_barrier(0);                 // the next block's fragment reads are issued HERE
-            kstep(jc, std::integral_constant<int, 0>{}, ca, cb);
-            kstep(jc, std::integral_constant<int, 1>{}, ca, cb);
+            kstep(jc, std::integral_constant<int, 0>{}, ca, cb, na_, nb_);
+            kstep(jc, std::integral_constant<int, 1>{}, ca, cb, na_, nb_);
         };
         kblock(std::integral_constant<int, 0>{}, fa0, fb0, fa1, fb1);
         kblock(std::integral_constant<int, 1>{}, fa1, fb1, fa0, fb0);
@@ -328,6 +355,18 @@ int launch_one(DmaArgs g, int zcount, hipStream_t s) {
     return eap::check_launch("gemm_dma_f32");
 }
 
+template <int DBG>
+int launch_debug(DmaArgs g, int zcount, hipStream_t s) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    const size_t shmem = (size_t)STAGES * 512 * BK * 4;
+    auto kern = gemm_dma_f32_kernel<2, 2, 4, 4, false, false, DBG>;
+    int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "gemm_dma_f32 debug");
+    if (e) return e;
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, zcount), dim3(NT), shmem, s, g);
+    return eap::check_launch("gemm_dma_f32 (debug variant)");
+}
+
 template <bool AKM, bool BKN>
 int launch_shape(const DmaArgs &g, int zcount, hipStream_t s) {
     // block tile 256 x 256 (wave tile 128 x 128); 128 x 256 for M <= 128; 256 x 128 for N <= 128
@@ -338,6 +377,12 @@ int launch_shape(const DmaArgs &g, int zcount, hipStream_t s) {
 
 int launch(bool akm, bool bkn, const DmaArgs &g, int zcount, hipStream_t s) {
     if (zcount > 65535) return eap::bad_arg("gemm_dma_f32: batch * splits exceeds 65535");
+    if (!akm && !bkn && g.M > 128 && g.N > 128) {       // EAP_GEMM_DEBUG=1..3: ablation variants for timing (tools/gemm_only.py)
+        static const int dbg = getenv("EAP_GEMM_DEBUG") ? atoi(getenv("EAP_GEMM_DEBUG")) : 0;
+        if (dbg == 1) return launch_debug<1>(g, zcount, s);
+        if (dbg == 2) return launch_debug<2>(g, zcount, s);
+        if (dbg == 3) return launch_debug<3>(g, zcount, s);
+    }
     if (akm) return bkn ? launch_shape<true, true>(g, zcount, s) : launch_shape<true, false>(g, zcount, s);
     return bkn ? launch_shape<false, true>(g, zcount, s) : launch_shape<false, false>(g, zcount, s);
 }

@@ -317,9 +317,11 @@ def test_anchor_attention_pool_and_invariant_head(dev):
     names = [n for n, _ in head.named_parameters()]
     grads = torch.autograd.grad(out, [x] + list(head.parameters()), g, retain_graph=True)
     grefs = torch.autograd.grad(oref, [xr] + list(head.parameters()), g)
+    top = max(float(b.abs().max()) for b in grefs)
     for nme, a, b in zip(['x'] + names, grads, grefs):
-        # conv biases in front of a training-mode BatchNorm have an exactly-zero gradient (rounding noise on both sides)
-        scale = max(float(b.abs().max()), 1e-3)
+        # conv biases in front of a training-mode BatchNorm have an exactly-zero gradient (rounding noise on both
+        # sides, ~1e-6): the bar is relative to the tensor's own scale, floored at 1 % of the largest gradient
+        scale = max(float(b.abs().max()), 1e-2 * top)
         assert float((a - b).abs().max()) < 2e-5 * scale, nme
     # the other pooling modes are plain reductions
     for mode in ('max', 'mean'):
