@@ -72,14 +72,15 @@ __device__ __forceinline__ void for_each_piece(F &&f, std::integer_sequence<int,
     (f(std::integral_constant<int, U>{}), ...);
 }
 
-// fragments of one k-block of an operand: k-contiguous image -> NI_ x 16 bytes (q), row-contiguous -> 2 x NI_ floats (s)
+// fragments of one k-PAIR (8 k's, four MFMA k-steps) of an operand: k-contiguous image -> NI_ x 16 bytes (q: this
+// half-wave's own k-block of the pair, all four elements used), row-contiguous -> 4 x NI_ floats (s)
 template <int NI_>
-struct Frag { float4 q[NI_]; float s[2][NI_]; };
+struct Frag { float4 q[NI_]; float s[4][NI_]; };
 
 // WM x WN = 4 waves, wave tile (32 MI) x (32 NI).  AKM: A stored [K, M] (m contiguous) instead of [M, K];
 // BKN: B stored [K, N] (n contiguous) instead of [N, K]
-// DBG (timing experiments only, results are wrong for DBG > 0): 1 = no staging traffic inside the k-loop,
-// 2 = also no fragment reads, 3 = also no operand selection
+// DBG (timing experiments only, results are wrong for DBG > 0; profiles/r02_gemm_ablation.txt): 1 = no staging
+// traffic inside the k-loop, 2 = also no fragment reads (the bare MFMA stream: 152.6 TFLOP/s)
 template <int WM, int WN, int MI, int NI, bool AKM, bool BKN, int DBG = 0>
 __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
     static_assert(WM * WN == 4, "four waves: one per SIMD");
@@ -171,19 +172,23 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
         if constexpr (NP > 7) { constexpr std::integral_constant<int, 7> uc{}; STMT; }                           \
     } while (0)
 
-    // ---- fragment read offsets (floats).  k-contiguous image: row (li), slot j ^ ((li >> 2) & 3), the i-th MFMA
-    // tile of the operand 32 rows = 512 floats further.  row-contiguous image [k][R]: element (k, row) ----
-    int offA[4], offB[4];
+    // ---- fragment reads.  A k-tile is two k-PAIRS of 8 k's.  In MFMA k-step s (0..3) of pair p the half-wave h
+    // supplies k = 8p + 4h + s: for a k-contiguous image that is element s of the 16-byte k-block 2p + h of the
+    // lane's row -- ONE ds_read_b128 per row and pair, every byte of it used, no selects (a first version read the
+    // same k-block in both half-waves and used half of it: twice the LDS reads, and every ds_read_b128 of a lone
+    // wave costs the matrix pipe ~25 cycles).  Slot of k-block j in row r: j ^ ((r >> 2) & 3); MFMA tile i of the
+    // operand is 32 rows = 512 floats further.  Row-contiguous image [k][R]: element (k, row). ----
+    int offA[2], offB[2];
     {
         const int c = (li >> 2) & 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            offA[j] = AKM ? 0 : (wm * 32 * MI + li) * 16 + ((j ^ c) << 2);
-            offB[j] = BKN ? 0 : BM * 16 + (wn * 32 * NI + li) * 16 + ((j ^ c) << 2);
+        for (int p = 0; p < 2; ++p) {
+            offA[p] = AKM ? 0 : (wm * 32 * MI + li) * 16 + (((2 * p + lh) ^ c) << 2);
+            offB[p] = BKN ? 0 : BM * 16 + (wn * 32 * NI + li) * 16 + (((2 * p + lh) ^ c) << 2);
         }
     }
-    const int rowA = lh * BM + wm * 32 * MI + li;               // [k][BM] image: + k0 * BM, k0 = 4j (+2)
-    const int rowB = BM * 16 + lh * BN + wn * 32 * NI + li;     // [k][BN] image
+    const int rowA = 4 * lh * BM + wm * 32 * MI + li;           // [k][BM] image: + (8p + s) * BM
+    const int rowB = BM * 16 + 4 * lh * BN + wn * 32 * NI + li; // [k][BN] image
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -193,30 +198,20 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // operands of the two MFMA k-steps of k-block j: step 0 takes k = 4j + h, step 1 k = 4j + 2 + h (h = half-wave)
-    auto load_a = [&](const float *sf, int j, Frag<MI> &f) __attribute__((always_inline)) {
-        if (!AKM) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) f.q[i] = *reinterpret_cast<const float4 *>(sf + offA[j] + i * 512);
+    // the r-th fragment read of k-pair p of the stage at `base` (A tiles first, then B tiles; a row-contiguous
+    // operand has four reads per tile, one per k-step)
+    constexpr int RA = AKM ? 4 * MI : MI, RB = BKN ? 4 * NI : NI, NREADS = RA + RB, NMFMA = 4 * MI * NI;
+    auto frag_read = [&](const float *base, int p, int r, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
+        if (r < RA) {
+            if (!AKM) na_.q[r] = *reinterpret_cast<const float4 *>(base + offA[p] + r * 512);
+            else na_.s[r / MI][r % MI] = base[rowA + (8 * p + r / MI) * BM + (r % MI) * 32];
         } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) f.s[s][i] = sf[rowA + (4 * j + 2 * s) * BM + i * 32];
+            const int q = r - RA;
+            if (!BKN) nb_.q[q] = *reinterpret_cast<const float4 *>(base + offB[p] + q * 512);
+            else nb_.s[q / NI][q % NI] = base[rowB + (8 * p + q / NI) * BN + (q % NI) * 32];
         }
     };
-    auto load_b = [&](const float *sf, int j, Frag<NI> &f) __attribute__((always_inline)) {
-        if (!BKN) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) f.q[i] = *reinterpret_cast<const float4 *>(sf + offB[j] + i * 512);
-        } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < NI; ++i) f.s[s][i] = sf[rowB + (4 * j + 2 * s) * BN + i * 32];
-        }
-    };
-    auto pick = [&](const float4 &v, int s) __attribute__((always_inline)) -> float { return s == 0 ? (lh ? v.y : v.x) : (lh ? v.w : v.z); };
+    auto elem = [](const float4 &v, int s) __attribute__((always_inline)) -> float { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; };
 
     const int nt = (kend - kbeg) / BK;
     const float *lds_f = reinterpret_cast<const float *>(smem);
@@ -231,8 +226,8 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
         EAP_EACH_PIECE(park_piece(uc, 1));
         EAP_EACH_PIECE(load_piece(uc, nt > 3 ? 1 : 0));
         __syncthreads();
-        load_a(lds_f, 0, fa0);
-        load_b(lds_f, 0, fb0);
+#pragma unroll
+        for (int r = 0; r < NREADS; ++r) frag_read(lds_f, 0, r, fa0, fb0);
     }
     int stage = 0;
     for (int it = 0; it < nt; ++it) {
@@ -248,47 +243,33 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
         // one k-block: request the NEXT block's fragments (of the next k-tile after the last block), then the
         // 2 x MI x NI MFMAs of this one; per k-step one staged piece of k-tile it + 2 is parked in LDS and its
         // register reloaded with the same piece of k-tile it + 3, from inside the MFMA stream
-        // the r-th fragment read of k-block jn of the stage at `base` (A tiles first, then B tiles; a row-contiguous
-        // operand has two reads per tile, one per k-step)
-        constexpr int RA = AKM ? 2 * MI : MI, RB = BKN ? 2 * NI : NI, NREADS = RA + RB, NMFMA = 2 * MI * NI;
+        // one MFMA k-step (s = 0..3) of k-pair p.  Between the MFMAs ride, evenly spaced: the fragment reads of the
+        // NEXT pair (of the next k-tile's first pair after the second), one parked staging piece and its reload
         constexpr int SPAN = NMFMA - 8;
-        static_assert((NREADS - 1) * SPAN / NREADS + 1 < NMFMA, "fragment reads must fit in the k-block");
-        auto frag_read = [&](const float *base, int jn, int r, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
-            if (r < RA) {
-                if (!AKM) na_.q[r] = *reinterpret_cast<const float4 *>(base + offA[jn] + r * 512);
-                else na_.s[r / MI][r % MI] = base[rowA + (4 * jn + 2 * (r / MI)) * BM + (r % MI) * 32];
-            } else {
-                const int q = r - RA;
-                if (!BKN) nb_.q[q] = *reinterpret_cast<const float4 *>(base + offB[jn] + q * 512);
-                else nb_.s[q / NI][q % NI] = base[rowB + (4 * jn + 2 * (q / NI)) * BN + (q % NI) * 32];
-            }
-        };
-        // one MFMA k-step of k-block j.  Between the MFMAs ride, evenly spaced: the fragment reads of the NEXT
-        // k-block (a lone wave that issues its eight ds_read_b128 back to back leaves the matrix pipe idle for
-        // ~200 cycles per k-block: -10 % measured), one parked staging piece and its reload
-        auto kstep = [&](auto jc, auto sc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value, s = decltype(sc)::value, u = 2 * j + s;
-            const float *nbase = j < 3 ? sf : sn;
-            constexpr int njn = j < 3 ? j + 1 : 0;
-            const bool do_reads = j < 3 || next_tile;
+        static_assert((NREADS - 1) * SPAN / NREADS + 1 < NMFMA, "fragment reads must fit in the k-pair");
+        auto kstep = [&](auto pc, auto sc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value, s = decltype(sc)::value, u = 4 * p + s;
+            const float *nbase = p == 0 ? sf : sn;
+            constexpr int np = p == 0 ? 1 : 0;
+            const bool do_reads = p == 0 || next_tile;
             float a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = DBG == 3 ? ca.q[i].x : AKM ? ca.s[s][i] : pick(ca.q[i], s);
+            for (int i = 0; i < MI; ++i) a[i] = AKM ? ca.s[s][i] : elem(ca.q[i], s);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) b[i] = DBG == 3 ? cb.q[i].x : BKN ? cb.s[s][i] : pick(cb.q[i], s);
-            __builtin_amdgcn_sched_barrier(0);                 // operands first, then the MFMA stream in this order
+            for (int i = 0; i < NI; ++i) b[i] = BKN ? cb.s[s][i] : elem(cb.q[i], s);
+            __builtin_amdgcn_sched_barrier(0);                 // then the MFMA stream in this order
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jn = 0; jn < NI; ++jn) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
-                    const int gm = s * MI * NI + i * NI + jn;                  // MFMA number within the k-block
+                    const int gm = s * MI * NI + i * NI + jn;                  // MFMA number within the k-pair
                     if constexpr (DBG < 2) {
 #pragma unroll
                         for (int r = 0; r < NREADS; ++r)
                             if (r * SPAN / NREADS + 1 == gm) {                 // the last one >= 8 MFMAs before its use
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (do_reads) frag_read(nbase, njn, r, na_, nb_);
+                                if (do_reads) frag_read(nbase, np, r, na_, nb_);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                     }
@@ -305,14 +286,14 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
                 }
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto kblock = [&](auto jc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
-            kstep(jc, std::integral_constant<int, 0>{}, ca, cb, na_, nb_);
-            kstep(jc, std::integral_constant<int, 1>{}, ca, cb, na_, nb_);
+        auto kpair = [&](auto pc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
+            kstep(pc, std::integral_constant<int, 0>{}, ca, cb, na_, nb_);
+            kstep(pc, std::integral_constant<int, 1>{}, ca, cb, na_, nb_);
+            kstep(pc, std::integral_constant<int, 2>{}, ca, cb, na_, nb_);
+            kstep(pc, std::integral_constant<int, 3>{}, ca, cb, na_, nb_);
         };
-        kblock(std::integral_constant<int, 0>{}, fa0, fb0, fa1, fb1);
-        kblock(std::integral_constant<int, 1>{}, fa1, fb1, fa0, fb0);
-        kblock(std::integral_constant<int, 2>{}, fa0, fb0, fa1, fb1);
-        kblock(std::integral_constant<int, 3>{}, fa1, fb1, fa0, fb0);
+        kpair(std::integral_constant<int, 0>{}, fa0, fb0, fa1, fb1);
+        kpair(std::integral_constant<int, 1>{}, fa1, fb1, fa0, fb0);
         stage = fstage;
     }
 
@@ -381,7 +362,6 @@ int launch(bool akm, bool bkn, const DmaArgs &g, int zcount, hipStream_t s) {
         static const int dbg = getenv("EAP_GEMM_DEBUG") ? atoi(getenv("EAP_GEMM_DEBUG")) : 0;
         if (dbg == 1) return launch_debug<1>(g, zcount, s);
         if (dbg == 2) return launch_debug<2>(g, zcount, s);
-        if (dbg == 3) return launch_debug<3>(g, zcount, s);
     }
     if (akm) return bkn ? launch_shape<true, true>(g, zcount, s) : launch_shape<true, false>(g, zcount, s);
     return bkn ? launch_shape<false, true>(g, zcount, s) : launch_shape<false, false>(g, zcount, s);
