@@ -60,14 +60,6 @@ int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float si
 int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
-// csrc/so3_inter_lists2.hip: second generation of the same kernel (matrix waves + loader waves); enabled unless EAP_LISTS_V2=0
-bool group_lists2_enabled(int na, int ks);
-int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
-                     const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int blocked, float *out,
-                     hipStream_t s);
-int group_lists2_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
-                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
-                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
 // csrc/zpconv_rows.hip: native inter zpconv forward near HBM speed (shared neighbour list per point)
 bool inter_zpconv_rows_supported(int np, int nq, int na, int ks, int nn, int c);
 int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx, const float *w,

@@ -34,7 +34,8 @@ for layer in (2, 1):
                   _hip._ptr(off), _hip._ptr(cnt), _hip._ptr(ent_p), _hip._ptr(ent_gx), _hip._ptr(rk), _hip._ptr(out))
     run(gy, NA, z); run(gy64, 64, z64)
     torch.cuda.synchronize()
-    assert torch.equal(z, z64)
+    if not os.environ.get("EAP_LISTS_DEBUG"):
+        assert torch.equal(z, z64)
     res = {60: [], 64: []}
     for _ in range(5):
         for pitch, src, out in ((NA, gy, z), (64, gy64, z64)):
