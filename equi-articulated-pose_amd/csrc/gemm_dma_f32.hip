@@ -245,8 +245,6 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
         // register reloaded with the same piece of k-tile it + 3, from inside the MFMA stream
         // one MFMA k-step (s = 0..3) of k-pair p.  Between the MFMAs ride, evenly spaced: the fragment reads of the
         // NEXT pair (of the next k-tile's first pair after the second), one parked staging piece and its reload
-        constexpr int SPAN = NMFMA - 8;
-        static_assert((NREADS - 1) * SPAN / NREADS + 1 < NMFMA, "fragment reads must fit in the k-pair");
         auto kstep = [&](auto pc, auto sc, const Frag<MI> &ca, const Frag<NI> &cb, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value, s = decltype(sc)::value, u = 4 * p + s;
             const float *nbase = p == 0 ? sf : sn;
@@ -263,25 +261,24 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
 #pragma unroll
                 for (int jn = 0; jn < NI; ++jn) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
-                    const int gm = s * MI * NI + i * NI + jn;                  // MFMA number within the k-pair
-                    if constexpr (DBG < 2) {
+                    // Everything that is not an MFMA rides in ONE cluster per k-step, right here: a lone wave pays
+                    // ~26 cycles of matrix-pipe time for every PLACE where other instructions sit between two MFMAs,
+                    // almost regardless of how many there are (tools/microbench/mfma_stream.hip: 5 or 10 VALU ops per
+                    // gap both cost 64 -> 90 cycles per MFMA).  Spread over the stream, the 24 riders of a k-tile cost
+                    // 7.6 %; clustered per k-step (a quarter of the next pair's fragment reads, one parked staging
+                    // piece, its reload) they cost 8 gaps.
+                    if (i == 0 && jn == NI - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (DBG < 2) {
 #pragma unroll
-                        for (int r = 0; r < NREADS; ++r)
-                            if (r * SPAN / NREADS + 1 == gm) {                 // the last one >= 8 MFMAs before its use
-                                __builtin_amdgcn_sched_barrier(0);
-                                if (do_reads) frag_read(nbase, np, r, na_, nb_);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                    }
-                    if constexpr (u < NP) {
-                        if (i == 0 && jn == NI - 1) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (DBG == 0) {
-                                park_piece(std::integral_constant<int, u>{}, pstage);     // (a stage nobody reads once it + 2 >= nt)
-                                load_piece(std::integral_constant<int, u>{}, adv);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int r = 0; r < NREADS; ++r)
+                                if (r * 4 / NREADS == s && do_reads) frag_read(nbase, np, r, na_, nb_);
                         }
+                        if constexpr (u < NP && DBG == 0) {
+                            park_piece(std::integral_constant<int, u>{}, pstage);     // (a stage nobody reads once it + 2 >= nt)
+                            load_piece(std::integral_constant<int, u>{}, adv);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
