@@ -111,7 +111,7 @@ class SeparableBackbone(nn.Module):
             y = zptk.SphericalPointCloud(y.xyz, self.inter_norm[i](y.feats), y.anchors)
             y = self.intra[i](y)
             f = self.intra_norm[i](y.feats)
-            f = f + self.skip_norm[i](self.skip[i](skip))
+            f = self.skip_norm[i](self.skip[i](skip), residual=f)        # relu(norm(skip)) + intra output, one pass
             x = zptk.SphericalPointCloudPose(x.xyz, f, y.anchors, x.pose)
         return x.feats
 

@@ -65,9 +65,12 @@ __global__ __launch_bounds__(TB) void bn_stats_kernel(int c, long n, int nseg, c
     block_reduce2(s, q, psum + o, psq + o);
 }
 
+// RES: y = leaky_relu(x * scale + shift) + res -- the separable block's skip connection
+// (`x.feats + skip_feature`, SPConvNets/utils/base_so3poseconv.py:L319-328) folded into the epilogue pass
+template <bool RES>
 __global__ __launch_bounds__(TB) void bn_act_fwd_kernel(int c, long n, float slope, const float *__restrict__ x,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
-                                                       float *__restrict__ y) {
+                                                       const float *__restrict__ res, float *__restrict__ y) {
     const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
     const float sc = scale[ci], sh = shift[ci];
     const size_t r0 = ((size_t)bi * c + ci) * n;
@@ -80,9 +83,16 @@ __global__ __launch_bounds__(TB) void bn_act_fwd_kernel(int c, long n, float slo
             a.x = fmaf(a.x, sc, sh); a.y = fmaf(a.y, sc, sh); a.z = fmaf(a.z, sc, sh); a.w = fmaf(a.w, sc, sh);
             a.x = a.x > 0.f ? a.x : a.x * slope; a.y = a.y > 0.f ? a.y : a.y * slope;
             a.z = a.z > 0.f ? a.z : a.z * slope; a.w = a.w > 0.f ? a.w : a.w * slope;
+            if (RES) {
+                const float4 r = *reinterpret_cast<const float4 *>(res + r0 + i);
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
             *reinterpret_cast<float4 *>(y + r0 + i) = a;
         } else {
-            for (long j = i; j < n; ++j) { const float p = fmaf(x[r0 + j], sc, sh); y[r0 + j] = p > 0.f ? p : p * slope; }
+            for (long j = i; j < n; ++j) {
+                const float p = fmaf(x[r0 + j], sc, sh);
+                y[r0 + j] = (p > 0.f ? p : p * slope) + (RES ? res[r0 + j] : 0.f);
+            }
         }
     }
 }
@@ -166,8 +176,17 @@ extern "C" int eap_bn_act_fwd_f32(int b, int c, int64_t n, float slope, const fl
                                   const float *shift, float *y, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_fwd: row length must be a multiple of 4; at most 65535 channels / clouds");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift, y);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift,
+                       (const float *)nullptr, y);
     return eap::check_launch("bn_act_fwd");
+}
+
+extern "C" int eap_bn_act_add_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale,
+                                      const float *shift, const float *res, float *y, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_add_fwd: row length must be a multiple of 4; at most 65535 channels / clouds");
+    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift, res, y);
+    return eap::check_launch("bn_act_add_fwd");
 }
 
 extern "C" int eap_bn_act_bwd_reduce_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x,

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
 
     // the r-th fragment read of k-pair p of the stage at `base` (A tiles first, then B tiles; a row-contiguous
     // operand has four reads per tile, one per k-step)
-    constexpr int RA = AKM ? 4 * MI : MI, RB = BKN ? 4 * NI : NI, NREADS = RA + RB, NMFMA = 4 * MI * NI;
+    constexpr int RA = AKM ? 4 * MI : MI, RB = BKN ? 4 * NI : NI, NREADS = RA + RB;
     auto frag_read = [&](const float *base, int p, int r, Frag<MI> &na_, Frag<NI> &nb_) __attribute__((always_inline)) {
         if (r < RA) {
             if (!AKM) na_.q[r] = *reinterpret_cast<const float4 *>(base + offA[p] + r * 512);

@@ -262,9 +262,12 @@ def bn_stats(x, b, c, n):
     return ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64)
 
 
-def bn_act_fwd(x, b, c, n, scale, shift, slope):
+def bn_act_fwd(x, b, c, n, scale, shift, slope, residual=None):
     y = torch.empty_like(x)
-    call('eap_bn_act_fwd_f32', x, b, c, _I64(n), _F32(slope), _ptr(x), _ptr(scale), _ptr(shift), _ptr(y))
+    if residual is None:
+        call('eap_bn_act_fwd_f32', x, b, c, _I64(n), _F32(slope), _ptr(x), _ptr(scale), _ptr(shift), _ptr(y))
+    else:
+        call('eap_bn_act_add_fwd_f32', x, b, c, _I64(n), _F32(slope), _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y))
     return y
 
 

@@ -56,8 +56,12 @@ from .. import _hip  # noqa: E402  (after the pure-torch helpers: they are unit-
 class _BNAct(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, sync):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, sync, residual=None):
         x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+            if residual.shape != x.shape:
+                raise RuntimeError('BatchNormLeakyReLU: residual must have the shape of the input')
         b, c = x.shape[0], x.shape[1]
         n = x.numel() // (b * c)
         count = b * n
@@ -75,7 +79,8 @@ class _BNAct(torch.autograd.Function):
         scale64 = weight.double() * invstd
         scale = scale64.float()
         shift = (bias.double() - mean * scale64).float()
-        y = _hip.bn_act_fwd(x, b, c, n, scale, shift, slope)
+        y = _hip.bn_act_fwd(x, b, c, n, scale, shift, slope, residual)
+        ctx.has_res = residual is not None
         ctx.save_for_backward(x, scale, shift, mean.float(), invstd.float())
         ctx.training, ctx.slope, ctx.dims, ctx.sync, ctx.count = training, slope, (b, c, n), sync, count
         return y
@@ -96,7 +101,7 @@ class _BNAct(torch.autograd.Function):
                 k2 = torch.zeros_like(scale)
                 k3 = torch.zeros_like(scale)
             g_x = _hip.bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, ctx.slope)
-        return g_x, sgx.float(), sg.float(), None, None, None, None, None, None, None
+        return g_x, sgx.float(), sg.float(), None, None, None, None, None, None, None, (gy if ctx.has_res else None)
 
 
 class BatchNormLeakyReLU(nn.BatchNorm2d):
@@ -108,13 +113,16 @@ class BatchNormLeakyReLU(nn.BatchNorm2d):
         self.negative_slope = negative_slope
         self.sync = sync          # batch statistics over all ranks (what nn.SyncBatchNorm does for the reference)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """leaky_relu(BatchNorm(x)) (+ residual: the separable block's `x.feats + skip_feature`,
+        base_so3poseconv.py:L319-328, added in the same pass).  In eval mode the normalisation is already folded
+        into one per-channel scale / shift (no statistics pass): a single read + write of the tensor."""
         if not x.is_cuda:
             raise RuntimeError('BatchNormLeakyReLU: tensor must be a CUDA(HIP) tensor (no CPU fallback)')
         if self.training:
             self.num_batches_tracked.add_(1)
         return _BNAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                            self.momentum, self.eps, self.negative_slope, self.sync)
+                            self.momentum, self.eps, self.negative_slope, self.sync, residual)
 
 
 class InstanceNormLeakyReLU(nn.Module):

@@ -475,6 +475,58 @@ class _InterConv(torch.autograd.Function):
         return gF, gW, None, None, None, None, None, None, None
 
 
+INTRA_DW_SLICE = 64      # channels whose 12-tap gather is materialised at a time for the intra weight gradient
+
+
+class _IntraConv(torch.autograd.Function):
+    """Intra SO(3) conv  y[b,o,p,a] = sum_{c,t} W[o, c*T + t] F[b,c,p,idx[a,t]]  (functional.py:L2553-2602 +
+    modules.py:L48-55) WITHOUT the [B,C,T,P,A] gathered tensor (48 GB at C = 512, B = 8) in either direction:
+      forward   implicit GEMM, the gather folded into the operand load (eap_so3_intra_conv_f32);
+      dF        the same kernel: every column idx[:,t] is a permutation of the anchors, so
+                dF[b,c,p,a'] = sum_{o,t} W[o, c*T + t] dY[b,o,p, inv_t(a')] -- weights regrouped to [C, O*T], gather
+                table inv[a', t];
+      dW        sum_{b,p,a} dY[b,o,p,a] F[b,c,p,idx[a,t]]: the gather is materialised for INTRA_DW_SLICE channels at
+                a time (eap_so3_intra_group_fwd) and contracted by the k-split reduce GEMM (3 GB of scratch instead
+                of 48)."""
+
+    @staticmethod
+    def forward(ctx, feats, W, idx32):
+        feats, W = feats.contiguous(), W.contiguous()
+        ctx.save_for_backward(feats, W, idx32)
+        return _hip.so3_intra_conv(feats, W, idx32)
+
+    @staticmethod
+    def backward(ctx, gy):
+        feats, W, idx32 = ctx.saved_tensors
+        gy = gy.contiguous()
+        b, c, p, na = feats.shape
+        o, nt = W.shape[0], idx32.shape[1]
+        gF = gW = None
+        if ctx.needs_input_grad[0]:
+            inv = torch.empty_like(idx32)                                         # inv[idx[a,t], t] = a
+            inv.scatter_(0, idx32.long(), torch.arange(na, device=idx32.device, dtype=torch.int32)[:, None].expand(na, nt).contiguous())
+            W2 = W.view(o, c, nt).permute(1, 0, 2).reshape(c, o * nt).contiguous()
+            gF = _hip.so3_intra_conv(gy, W2, inv.contiguous())
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty(o, c, nt, dtype=torch.float32, device=gy.device)
+            pa = p * na
+            for c0 in range(0, c, INTRA_DW_SLICE):
+                c1 = min(c, c0 + INTRA_DW_SLICE)
+                g = _hip.so3_intra_group_fwd(feats[:, c0:c1].contiguous(), idx32)       # [b, cs, nt, p, na]
+                d = torch.empty(o, (c1 - c0) * nt, dtype=torch.float32, device=gy.device)
+                _hip.gemm_reduce(0, 1, o, (c1 - c0) * nt, pa, gy, pa, o * pa, g, pa, (c1 - c0) * nt * pa, d, (c1 - c0) * nt, b)
+                gW[:, c0:c1] = d.view(o, c1 - c0, nt)
+            gW = gW.view(o, c * nt)
+        return gF, gW, None
+
+
+def intra_so3conv(feats, W, intra_idx):
+    """feats [b,c,p,na], W [o, c*T], intra_idx [na,T] -> [b,o,p,na]; what IntraSO3Conv.forward runs."""
+    if feats.dtype != torch.float32 or not feats.is_cuda:
+        raise RuntimeError('intra_so3conv: float32 device tensors only')
+    return _IntraConv.apply(feats, W, intra_idx.to(torch.int32).contiguous())
+
+
 def so3_contract(W, x):
     """W [O, C*K], x [b, C*K, P*A] -> [b, O, P*A]."""
     _hip.check_input(x)

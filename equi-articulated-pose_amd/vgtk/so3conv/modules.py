@@ -166,16 +166,14 @@ class IntraSO3Conv(nn.Module):
         self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
 
     def forward(self, x):
-        W = self.basic_conv.W
-        if x.feats.is_cuda and x.feats.dtype == torch.float32 and x.feats.shape[3] % 4 == 0 and \
-                not (torch.is_grad_enabled() and (x.feats.requires_grad or W.requires_grad)):
-            # no gradient wanted (the frozen glb_backbone, inference): the 12-tap gather is folded into
-            # the contraction's operand load instead of materialising [B,C,12,P,A] (eap_so3_intra_conv_f32)
-            feats = _hip.so3_intra_conv(x.feats.contiguous(), W.contiguous(), self.intra_idx.to(torch.int32).contiguous())
+        feats = x.feats
+        if feats.is_cuda and feats.dtype == torch.float32 and feats.shape[3] % 4 == 0 and feats.shape[3] <= 64:
+            # implicit GEMM in both directions: the 12-tap gather is folded into the contraction's operand load, the
+            # [B,C,12,P,A] tensor of the reference (48 GB at C = 512) is never written (L._IntraConv)
+            out = L.intra_so3conv(feats, self.basic_conv.W, self.intra_idx)
         else:
-            feats = L.intra_so3conv_grouping(self.intra_idx, x.feats)
-            feats = self.basic_conv(feats)
-        return SphericalPointCloud(x.xyz, feats, self.anchors)
+            out = self.basic_conv(L.intra_so3conv_grouping(self.intra_idx, feats))
+        return SphericalPointCloud(x.xyz, out, self.anchors)
 
 
 class IntraSO3Conv2D(nn.Module):

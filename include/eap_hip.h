@@ -312,6 +312,10 @@ int eap_bn_stats_f32(int b, int c, int64_t n, const float *x, float *psum, float
 /* y = leaky_relu(x * scale[c] + shift[c], slope) */
 int eap_bn_act_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale,
                        const float *shift, float *y, eap_stream_t stream);
+/* y = leaky_relu(x * scale[c] + shift[c], slope) + res: the separable block's skip-add
+ * (SPConvNets/utils/base_so3poseconv.py:L319-328) in the same pass; res [b, c, n] */
+int eap_bn_act_add_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale,
+                           const float *shift, const float *res, float *y, eap_stream_t stream);
 /* partial sums of g and g * xhat,  g = gy * (x*scale+shift > 0 ? 1 : slope),  xhat = (x - mean) * invstd */
 int eap_bn_act_bwd_reduce_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x,
                               const float *scale, const float *shift, const float *mean,

@@ -361,3 +361,27 @@ def test_slot_masked_mean_and_orbit_selection(dev):
     R = sptk.rotation_from_angle_axis(ang, ax)
     assert rel_err((R @ R.transpose(-1, -2)).cpu().numpy(), torch.eye(3).expand(5, 7, 3, 3).numpy()) < 1e-5
     assert rel_err((R @ ax.unsqueeze(-1)).squeeze(-1).cpu().numpy(), ax.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_block_epilogue_with_skip_add(dev, training):
+    """`x.feats + relu(norm(skip))` (base_so3poseconv.py:L319-328) in the epilogue pass."""
+    import vgtk.so3conv as sptk
+    torch.manual_seed(21)
+    x = torch.randn(2, 9, 13, 60, device=dev) * 1.5 + 0.5
+    res = torch.randn(2, 9, 13, 60, device=dev)
+    g = torch.randn(2, 9, 13, 60, device=dev)
+    ref = torch.nn.BatchNorm2d(9).to(dev)
+    fused = sptk.BatchNormLeakyReLU(9, negative_slope=0.01).to(dev)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-1, 1); ref.running_var.uniform_(0.5, 2.0)
+    fused.load_state_dict(ref.state_dict())
+    ref.train(training); fused.train(training)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    xf, rf = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(ref(xr), 0.01) + rr
+    yf = fused(xf, residual=rf)
+    yr.backward(g); yf.backward(g)
+    assert float((yf - yr).abs().max()) <= 2e-6 * float(yr.abs().max())
+    assert float((xf.grad - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+    assert torch.equal(rf.grad, rr.grad)

@@ -628,19 +628,28 @@ def test_instancenorm_leaky_relu_block_epilogue(dev, vg):
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 24, 40, 37), (1, 130, 8, 300), (1, 64, 512, 64)])
 def test_intra_conv_implicit_gemm(dev, vg, shape):
-    """eap_so3_intra_conv_f32 (gather folded into the GEMM operand load) against the materialised
-    intra_so3conv_grouping + BasicSO3Conv path (so3conv/functional.py:L2553-2602, modules.py:L48-55)."""
+    """IntraSO3Conv = implicit GEMM in both directions (eap_so3_intra_conv_f32 forward and feature gradient, channel-
+    sliced weight gradient: no [B,C,12,P,A] tensor) against the materialised intra_so3conv_grouping + BasicSO3Conv
+    formulation (so3conv/functional.py:L2553-2602, modules.py:L48-55): output, dF, dW."""
     import vgtk.so3conv as sptk
     import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
     b, c, o, p = shape
     torch.manual_seed(11)
     conv = sptk.IntraSO3Conv(c, o).to(dev)
     feats = torch.randn(b, c, p, 60, device=dev)
-    x = zptk.SphericalPointCloud(torch.zeros(b, 3, p, device=dev), feats, conv.anchors)
+    g = torch.randn(b, o, p, 60, device=dev)
+    f1 = feats.clone().requires_grad_(True)
+    fast = conv(zptk.SphericalPointCloud(torch.zeros(b, 3, p, device=dev), f1, conv.anchors)).feats
+    gf1, gw1 = torch.autograd.grad(fast, [f1, conv.basic_conv.W], g)
+    f2 = feats.clone().requires_grad_(True)
+    slow = conv.basic_conv(L.intra_so3conv_grouping(conv.intra_idx, f2))          # materialised path
+    gf2, gw2 = torch.autograd.grad(slow, [f2, conv.basic_conv.W], g)
+    assert rel_err(fast.detach().cpu().numpy(), slow.detach().cpu().numpy()) < 1e-5
+    assert rel_err(gf1.cpu().numpy(), gf2.cpu().numpy()) < 1e-5
+    assert rel_err(gw1.cpu().numpy(), gw2.cpu().numpy()) < 2e-5
     with torch.no_grad():
-        fast = conv(x).feats                                   # implicit path
-    slow = conv(zptk.SphericalPointCloud(x.xyz, feats.clone().requires_grad_(True), conv.anchors)).feats   # materialised path
-    assert rel_err(fast.cpu().numpy(), slow.detach().cpu().numpy()) < 1e-5
+        assert torch.equal(conv(zptk.SphericalPointCloud(None, feats, conv.anchors)).feats, fast.detach())
 
 
 @pytest.mark.gpu
