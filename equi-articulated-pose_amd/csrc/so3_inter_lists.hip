@@ -11,13 +11,21 @@
 // Per (row, 32 channels, anchor group) this is a [32 x E] x [E x 24] product for every anchor,
 // mapped on v_mfma_f32_32x32x2_f32 (M = channels, N = kernel points padded to 32, K = entries):
 //   * A operand: the 16-byte pieces of the entries' feature rows go global -> LDS by DMA
-//     (global_load_lds_dwordx4), one wave-instruction after every second MFMA; no staging
-//     registers, no ds_write pass.  The LDS image of a chunk is [8 entries][32 channels][pieces];
-//     DMA cannot pad a row, so when the row length is a multiple of 8 dwords the pieces of channel
-//     row r are rotated by r (on the global-address side, for free) to keep the 32 channel lanes
-//     of an operand read on different banks.
-//   * B operand: never in memory.  Lane (k = l&31, e = l>>5) evaluates w = max(0, base_e + kc + g.k')
-//     in registers (k' = 2 A_a kappa_k / sigma, kc = -|kappa_k|^2 / sigma are per-lane constants).
+//     (global_load_lds_dwordx4, wave-uniform base in SGPRs + one 32-bit offset per lane), one
+//     wave-instruction after every second MFMA; no staging registers, no ds_write pass.  The LDS image of
+//     a chunk is [8 entries][32 channels][8 slots of 16 bytes]; the piece of anchors 4w..4w+3 of channel
+//     row r sits in slot (w + r) mod 8 (the rotation is applied on the global-address side, for free), so
+//     the 32 channel lanes of an operand read land on different banks and ONE ds_read_b128 brings the
+//     wave's four anchors.
+//   * B operand: never in memory.  Lane (k = l&31, e = l>>5) evaluates
+//     w = clamp(1 - |g|^2/s - |kappa_k|^2/s + g.(2 A_a kappa_k / s)) in registers.  The fp32 MFMA and the
+//     vector ALU share their multipliers on this part (tools/microbench/mfma_waves.hip: every VALU
+//     instruction between MFMAs costs its 4 cycles of matrix time at ANY occupancy; the round-1 loop
+//     spent 150 VALU instructions per 16 MFMAs and sat at 95 % of the resulting 63 % ceiling), so the
+//     loop is written for VALU count: weights of two anchors per packed instruction (v_pk_add/v_pk_fma,
+//     relu = the clamp modifier of the last FMA: 2 instructions per weight instead of 5), the per-entry
+//     term evaluated once per chunk by 8 lanes and handed out by ds_bpermute, every LDS address an
+//     immediate offset of one register, no 64-bit address arithmetic: ~48 VALU per 16 MFMAs.
 //   * The anchors of a row are split into two groups (32 + 28 at na = 60) handled by different
 //     workgroups: 4 anchors per wave = 64 accumulator VGPRs, under 128 VGPRs in total and 64 KB of
 //     LDS, so TWO workgroups share a CU.  A workgroup is alone for its chunk barrier, its DMA
@@ -31,13 +39,16 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CB = 32;        // channels per block (one MFMA M tile)
 constexpr int NBK = 8;        // entries per LDS stage (4 MFMA k-steps)
 constexpr int APW = 4;        // anchors per wave
 constexpr int NWV = 8;
 constexpr int TM = 64 * NWV;
-constexpr int NSTD = 4;       // DMA instructions per thread and chunk: NBK*CB*(pieces <= 8)/TM
+constexpr int NSTD = 4;       // DMA instructions per thread and chunk: NBK*CB*8 pieces / TM
+constexpr int PITCH = 32;     // floats per LDS row = 8 pieces, whatever the group's anchor count (see the DMA mapping)
+constexpr unsigned BUF_BYTES = NBK * CB * PITCH * 4;
 
 __device__ inline unsigned lds_addr(const void *ptr) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
@@ -48,6 +59,12 @@ __device__ inline void glds16(const void *gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane: no 64-bit VALU add per request
+__device__ inline void glds16s(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ inline void glds4(const void *gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -88,13 +105,12 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lk = lane & 31, lh = lane >> 5;
     const int a0 = ag * gsz, gcount = min(gsz, na - a0);      // anchors [a0, a0 + gcount) of this block
-    const int npg = gcount >> 2, pitch = gcount;               // 16-byte pieces per row, LDS row pitch (floats)
-    const bool rotate = (npg & 1) == 0;
-    const int al_beg = wave_u * APW;                           // first local anchor of this wave
+    const int npg = gcount >> 2;                               // 16-byte pieces per feature row that exist
+    const int al_beg = wave_u * APW;                           // first local anchor of this wave = piece wave_u
     const bool active = al_beg < gcount;                       // wave-uniform
 
-    float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][pitch]
-    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * pitch);   // [3][NBK] ring
+    float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][PITCH]
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * PITCH);   // [3][NBK] ring
     int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] ring
 
     // entries of the block: one list (backward), or the neighbours of rows_blk consecutive rows
@@ -115,23 +131,26 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     const int nchunk = LISTS ? nchunk_row : rows_blk * nchunk_row;
 
     // ---- per-lane weight constants of this wave's anchors (k = lane & 31) -------------------------
-    float kx[APW], ky[APW], kz[APW], kc[APW];
+    // On this part the fp32 MFMA and the vector ALU share their multipliers (vector fp32 peak = matrix fp32 peak;
+    // tools/microbench/mfma_waves.hip: every VALU instruction between MFMAs costs its 4 cycles of matrix time at any
+    // occupancy), so the weight w = relu(1 - |g|^2/s - |kappa|^2/s + 2 g.kappa'/s) is evaluated with as few VALU
+    // instructions as it takes: everything goes through packed operations on two anchors at a time -- the
+    // per-entry term joins -|kappa|^2/s in one packed add, then three packed FMAs, and the relu is the clamp
+    // modifier of the last one (weights never exceed 1): 2 instructions per weight instead of 5.
+    f32x2 kxp[APW / 2], kyp[APW / 2], kzp[APW / 2], kcp[APW / 2];
 #pragma unroll
     for (int ai = 0; ai < APW; ++ai) {
         const int a = a0 + min(al_beg + ai, gcount - 1);
         const float *r3 = rk + ((size_t)a * ks + min(lk, ks - 1)) * 3;
         const float x = r3[0], y = r3[1], z = r3[2];
-        kx[ai] = 2.f * inv_sigma * x; ky[ai] = 2.f * inv_sigma * y; kz[ai] = 2.f * inv_sigma * z;
-        kc[ai] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
+        kxp[ai >> 1][ai & 1] = 2.f * inv_sigma * x;
+        kyp[ai >> 1][ai & 1] = 2.f * inv_sigma * y;
+        kzp[ai >> 1][ai & 1] = 2.f * inv_sigma * z;
+        kcp[ai >> 1][ai & 1] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
     }
-    // operand read offsets of the two anchor pairs (rotation by the channel row, see the header)
-    int roff[APW / 2];
-#pragma unroll
-    for (int j = 0; j < APW / 2; ++j) {
-        const int al = min(al_beg + 2 * j, gcount - 2);
-        const int piece = al >> 2, slot = rotate ? (piece + lk) % npg : piece;
-        roff[j] = lk * pitch + 4 * slot + (al & 3);
-    }
+    // operand read: the wave's four anchors are ONE 16-byte piece (piece wave_u) of channel row lk, stored at slot
+    // (piece + row) mod 8 so that the 32 channel lanes of a read spread over the banks
+    const float4 *fa_lane = reinterpret_cast<const float4 *>(s_f + (size_t)(lh * CB + lk) * PITCH + 4 * ((wave_u + lk) & 7));
 
     f32x16 acc[APW];
 #pragma unroll
@@ -139,21 +158,19 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
 
-    // ---- DMA: thread -> NSTD fixed 16-byte pieces of a chunk's LDS image ---------------------------
-    const float *fb = F + (size_t)bi * C * PF * fpitch;       // fpitch: floats between consecutive feature rows (>= na)
-    const int total4 = NBK * CB * npg;                    // a multiple of 64: whole waves in or out
+    // ---- DMA: thread -> NSTD 16-byte pieces of a chunk's LDS image ---------------------------------
+    // A DMA instruction writes its 64 lanes' pieces to consecutive LDS addresses, so the image is
+    // [8 entries][32 channel rows][8 slots] with thread t of instruction u at flat piece u*512 + t: always the same
+    // channel row (t>>3)&31 and slot t&7, entry 2u + (t>>8) -- one request offset and one ring address serve the
+    // four instructions.  Slot -> piece by the row's rotation; pieces a smaller anchor group does not have are
+    // masked out (their slots stay unwritten and are never read).
+    // request address = slice base (SGPRs) + 32-bit byte offset per lane (the launcher bounds 32 rows of a cloud)
+    const float *fb = F + ((size_t)bi * C + c0) * PF * fpitch;   // fpitch: floats between consecutive feature rows (>= na)
     const unsigned lds_f = lds_addr(s_f);
-    const unsigned buf_bytes = (unsigned)(NBK * CB) * (unsigned)pitch * 4u;
-    unsigned dma_off[NSTD], nl_pack = 0;                  // nl_pack: the entry (0..7) of each of the thread's pieces, 3 bits each
-#pragma unroll
-    for (int u = 0; u < NSTD; ++u) {
-        const int f = min(u * TM + t, total4 - 1);
-        const int row = f / npg, slot = f - row * npg;
-        const int nl = row / CB, cl = row - nl * CB;
-        const int piece = rotate ? (slot + npg - cl % npg) % npg : slot;
-        dma_off[u] = (unsigned)min(c0 + cl, C - 1) * (unsigned)PF * (unsigned)fpitch + (unsigned)(a0 + 4 * piece);
-        nl_pack |= (unsigned)nl << (3 * u);
-    }
+    const unsigned row_bytes = (unsigned)fpitch * 4u;
+    const int d_cl = (t >> 3) & 31, d_piece = ((t & 7) - d_cl) & 7, d_nl = t >> 8;
+    const bool d_valid = d_piece < npg;
+    const unsigned dma_off = ((unsigned)(min(c0 + d_cl, C - 1) - c0) * (unsigned)PF * (unsigned)fpitch + (unsigned)(a0 + 4 * min(d_piece, npg - 1))) * 4u;
     // The ring of entry -> (feature row, offset vector) runs two chunks ahead of the MFMAs and is
     // filled by DMA as well (8 lanes of wave 0).  Entries past the end of the list repeat the last
     // one; they -- and the forward's shadow rows -- are given a dead offset vector (weight 0)
@@ -170,15 +187,14 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     auto prep_rows = [&](int slot) {
 #pragma unroll
         for (int u = 0; u < NSTD; ++u) {
-            int pe = s_p[slot * NBK + ((nl_pack >> (3 * u)) & 7)];
+            int pe = s_p[slot * NBK + 2 * u + d_nl];
             if (!LISTS) pe = (unsigned)pe < (unsigned)PF ? pe : 0;     // shadow row: any valid row, weight 0
-            src_off[u] = dma_off[u] + __umul24((unsigned)pe, (unsigned)fpitch);
+            src_off[u] = dma_off + __umul24((unsigned)pe, row_bytes);
         }
     };
     auto issue = [&](int u, int buf) {
-        const int f0 = u * TM + wave_u * 64;              // wave-uniform
-        if (f0 < total4)
-            glds16(fb + src_off[u], __builtin_amdgcn_readfirstlane(lds_f + (unsigned)buf * buf_bytes + (unsigned)f0 * 16u));
+        if (d_valid)
+            glds16s(fb, src_off[u], __builtin_amdgcn_readfirstlane(lds_f + (unsigned)buf * BUF_BYTES + (unsigned)(u * TM + wave_u * 64) * 16u));
     };
 
     if (nchunk > 0) {
@@ -193,40 +209,43 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     }
     __syncthreads();
 
-    // operands of one MFMA k-step (2 entries): the anchor pairs of this lane's channel row, the
-    // entry's offset vector and (forward) its support row for the shadow test
-    auto gather = [&](const float *fbuf, int gslot, int s, float (&fa)[APW], float4 &g, int &pe) {
-        const float *base = fbuf + (size_t)(2 * s + lh) * CB * pitch;
-#pragma unroll
-        for (int j = 0; j < APW / 2; ++j) {
-            const float2 v = *reinterpret_cast<const float2 *>(base + roff[j]);
-            fa[2 * j] = v.x; fa[2 * j + 1] = v.y;
-        }
+    // per chunk: lane e (mod 8) evaluates the per-entry term 1 - |g_e|^2/s of the chunk's entry e, or a dead value
+    // for entries past the end of the list and for the forward's shadow rows; the k-steps fetch theirs by bpermute
+    auto chunk_bases = [&](int ch, int gslot) {
+        const int e = lane & (NBK - 1);
+        const float4 g = s_g[gslot * NBK + e];
+        float b = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
+        bool dead = ch * NBK + e >= n_ent;
+        if (!LISTS) dead = dead || (unsigned)s_p[gslot * NBK + e] >= (unsigned)PF;
+        return __float_as_int(dead ? -1e30f : b);
+    };
+    // operands of one MFMA k-step (2 entries): the anchor pairs of this lane's channel row, the entry's offset
+    // vector and its per-entry term
+    auto gather = [&](const float4 *fab, int gslot, int bases, int s, float4 &fa, float4 &g, float &bk) {
+        fa = fab[s * (2 * CB * PITCH / 4)];
         g = s_g[gslot * NBK + 2 * s + lh];
-        if (!LISTS) pe = s_p[gslot * NBK + 2 * s + lh];
+        bk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (2 * s + lh), bases));
     };
     auto nothing = [] {};
-    auto step = [&](int je, const float4 g, int pe, const float (&fa)[APW], auto mid, auto end) {
-        float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
-        if (je >= n_ent || (!LISTS && (unsigned)pe >= (unsigned)PF)) base = -1e30f;    // dead entry: weight 0
-        float wv[APW];
+    auto step = [&](const float4 g, float bk, const float4 fv, auto mid, auto end) {
+        const float fa[APW] = {fv.x, fv.y, fv.z, fv.w};
+        f32x2 wv[APW / 2];
 #pragma unroll
-        for (int ai = 0; ai < APW; ++ai) {
-            float x = fmaf(g.x, kx[ai], kc[ai]);
-            x = fmaf(g.y, ky[ai], x);
-            x = fmaf(g.z, kz[ai], x);
-            wv[ai] = fmaxf(x + base, 0.0f);
+        for (int j = 0; j < APW / 2; ++j) {
+            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], kcp[j] + (f32x2){bk, bk});
+            x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
         }
         // unguarded: a wave whose last anchors fall off the group repeats its last one into
         // accumulators the epilogue never stores
         __builtin_amdgcn_s_setprio(3);                      // a wave with MFMAs ready goes first (-2.5 % on one box, A/B)
 #pragma unroll
         for (int ai = 0; ai < APW / 2; ++ai)
-            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
         mid();
 #pragma unroll
         for (int ai = APW / 2; ai < APW; ++ai)
-            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
         if (wave_u >= NWV / 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
         end();
     };
@@ -299,48 +318,54 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     if (wave_u >= NWV / 2) __builtin_amdgcn_s_setprio(2);
     int g0 = 0, g1 = 1, g2 = 2;                           // ring slots of chunks ch, ch+1, ch+2
     int ch_row = 0, row = r_begin;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1, nb = buf ^ 1;
-        const float *fbuf = s_f + (size_t)buf * NBK * CB * pitch;
-        const int je = ch * NBK + lh;
-        // Operands run two k-steps ahead of the MFMAs; the next chunk's rows are requested one
-        // wave-instruction per step, from the middle of the step's MFMAs.  Past the end of the
-        // list the ring repeats the last entry (a harmless reload of the idle buffer).
-        if (active) {
-            float fa0[APW], fa1[APW];
-            float4 ga, gb;
-            int pa = 0, pb = 0;
-            gather(fbuf, g0, 0, fa0, ga, pa);
-            gather(fbuf, g0, 1, fa1, gb, pb);
+    // two loops, one per kind of wave (a wave without anchors only feeds the DMA): the accumulators of the working
+    // waves then never meet a control-flow join, which the register allocator answered with a second copy of them
+    if (active) {
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int buf = ch & 1, nb = buf ^ 1;
+            const float4 *fbuf = fa_lane + buf * (NBK * CB * PITCH / 4);
+            // Operands run two k-steps ahead of the MFMAs; the next chunk's rows are requested one
+            // wave-instruction per step, from the middle of the step's MFMAs.  Past the end of the
+            // list the ring repeats the last entry (a harmless reload of the idle buffer).
+            float4 fa0, fa1, ga, gb;
+            float ba, bb;
+            const int bases = chunk_bases(ch, g0);
+            gather(fbuf, g0, bases, 0, fa0, ga, ba);
+            gather(fbuf, g0, bases, 1, fa1, gb, bb);
             prep_rows(g1);
             issue_idx((ch + 2) * NBK, g2);
             __builtin_amdgcn_sched_barrier(0);
-            step(je, ga, pa, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); });
+            step(ga, ba, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            gather(fbuf, g0, 2, fa0, ga, pa);
+            gather(fbuf, g0, bases, 2, fa0, ga, ba);
             __builtin_amdgcn_sched_barrier(0);
-            step(je + 2, gb, pb, fa1, [&] { issue(2, nb); }, [&] { issue(3, nb); });
+            step(gb, bb, fa1, [&] { issue(2, nb); }, [&] { issue(3, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            gather(fbuf, g0, 3, fa1, gb, pb);
+            gather(fbuf, g0, bases, 3, fa1, gb, bb);
             __builtin_amdgcn_sched_barrier(0);
-            step(je + 4, ga, pa, fa0, nothing, nothing);
+            step(ga, ba, fa0, nothing, nothing);
             __builtin_amdgcn_sched_barrier(0);
-            step(je + 6, gb, pb, fa1, nothing, nothing);
-        } else {
+            step(gb, bb, fa1, nothing, nothing);
+            dma_wait();
+            if (++ch_row == nchunk_row) {                 // block-uniform
+                store_row(row);
+                ch_row = 0;
+                ++row;
+            }
+            __syncthreads();
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
+        }
+        if (nchunk == 0) store_row(r_begin);              // unreferenced row: zeros
+    } else {
+        for (int ch = 0; ch < nchunk; ++ch) {
             prep_rows(g1);
 #pragma unroll
-            for (int u = 0; u < NSTD; ++u) issue(u, nb);
+            for (int u = 0; u < NSTD; ++u) issue(u, (ch & 1) ^ 1);
+            dma_wait();
+            __syncthreads();
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
         }
-        dma_wait();
-        if (++ch_row == nchunk_row) {                     // block-uniform
-            store_row(row);
-            ch_row = 0;
-            ++row;
-        }
-        __syncthreads();
-        const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
     }
-    if (nchunk == 0) store_row(r_begin);                  // unreferenced row: zeros
 }
 
 struct Geometry { int AG, gsz; size_t shmem; };
@@ -350,7 +375,7 @@ bool geometry(int na, int ks, Geometry &g) {
     if (na <= 0 || (na & 3) != 0 || na > 64 || ks <= 0 || ks > 32) return false;
     g.AG = na > 32 ? 2 : 1;
     g.gsz = g.AG == 1 ? na : ((na / 2 + 3) & ~3);
-    g.shmem = sizeof(float) * 2 * NBK * CB * g.gsz + 16 * 3 * NBK + 16 * NBK;     // the first group is the larger one
+    g.shmem = 2 * BUF_BYTES + 16 * 3 * NBK + 16 * NBK;
     return g.shmem <= 80 * 1024;
 }
 
@@ -361,7 +386,8 @@ int launch(int blocked, int b, int C, int PF, int na, int fpitch, int ks, int R,
     Geometry g;
     if (!geometry(na, ks, g)) return eap::bad_arg("so3_group_lists: unsupported anchor / kernel-point count");
     if (fpitch < na || (fpitch & 3) != 0) return eap::bad_arg("so3_group_lists: the feature row pitch must be a multiple of 4, at least the anchor count");
-    if ((long long)C * PF * fpitch >= (1ll << 31)) return eap::bad_arg("so3_group_lists: one cloud's features exceed 2^31 elements");
+    if ((long long)CB * PF * fpitch * 4 >= (1ll << 32) || PF >= (1 << 24) || fpitch * 4 >= (1 << 24))
+        return eap::bad_arg("so3_group_lists: 32 feature rows of a cloud exceed the 32-bit request offsets");
     if (((long long)ks * R * na * 4 + 32ll * R * na + 64) * 4 >= (1ll << 31)) return eap::bad_arg("so3_group_lists: output rows too far apart for 32-bit store offsets");
     auto kern = blocked == 2 ? so3_group_lists_kernel<LISTS, LISTS ? 0 : 2> : blocked == 1 ? so3_group_lists_kernel<LISTS, LISTS ? 0 : 1>
                                                                                           : so3_group_lists_kernel<LISTS, 0>;
