@@ -58,12 +58,13 @@ struct DmaArgs {
 // the k-tile in flight: eight named 16-byte quads (an indexed array of vectors is not promoted to registers)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Staging {
-    f32x4 v0, v1, v2, v3, v4, v5, v6, v7;
+    f32x4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9;
     template <int U>
     __device__ __forceinline__ f32x4 &at() {
         if constexpr (U == 0) return v0; else if constexpr (U == 1) return v1; else if constexpr (U == 2) return v2;
         else if constexpr (U == 3) return v3; else if constexpr (U == 4) return v4; else if constexpr (U == 5) return v5;
-        else if constexpr (U == 6) return v6; else return v7;
+        else if constexpr (U == 6) return v6; else if constexpr (U == 7) return v7; else if constexpr (U == 8) return v8;
+        else return v9;
     }
 };
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
     static_assert(WM * WN == 4, "four waves: one per SIMD");
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     constexpr int A_PIECES = BM * 4 / NT, B_PIECES = BN * 4 / NT, NP = A_PIECES + B_PIECES;   // 16-byte DMA pieces per thread and stage
-    static_assert(NP >= 4 && NP <= 8, "one staged piece per MFMA k-step");
+    static_assert(NP >= 4 && NP <= 10, "one staged piece per MFMA k-step (a second one in the first two for the 128 x 512 tile)");
     constexpr unsigned STAGE_BYTES = (BM + BN) * BK * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -170,6 +171,8 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
         if constexpr (NP > 5) { constexpr std::integral_constant<int, 5> uc{}; STMT; }                           \
         if constexpr (NP > 6) { constexpr std::integral_constant<int, 6> uc{}; STMT; }                           \
         if constexpr (NP > 7) { constexpr std::integral_constant<int, 7> uc{}; STMT; }                           \
+        if constexpr (NP > 8) { constexpr std::integral_constant<int, 8> uc{}; STMT; }                           \
+        if constexpr (NP > 9) { constexpr std::integral_constant<int, 9> uc{}; STMT; }                           \
     } while (0)
 
     // ---- fragment reads.  A k-tile is two k-PAIRS of 8 k's.  In MFMA k-step s (0..3) of pair p the half-wave h
@@ -278,6 +281,10 @@ __global__ __launch_bounds__(NT, 1) void gemm_dma_f32_kernel(DmaArgs g) {
                             park_piece(std::integral_constant<int, u>{}, pstage);     // (a stage nobody reads once it + 2 >= nt)
                             load_piece(std::integral_constant<int, u>{}, adv);
                         }
+                        if constexpr (u + 8 < NP && DBG == 0) {
+                            park_piece(std::integral_constant<int, u + 8>{}, pstage);
+                            load_piece(std::integral_constant<int, u + 8>{}, adv);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -347,7 +354,9 @@ int launch_debug(DmaArgs g, int zcount, hipStream_t s) {
 
 template <bool AKM, bool BKN>
 int launch_shape(const DmaArgs &g, int zcount, hipStream_t s) {
-    // block tile 256 x 256 (wave tile 128 x 128); 128 x 256 for M <= 128; 256 x 128 for N <= 128
+    // block tile 256 x 256 (wave tile 128 x 128); for M <= 128: 128 x 512 (the same wave tile) when that still leaves
+    // four workgroups per CU, else 128 x 256; 256 x 128 for N <= 128
+    if (g.M <= 128 && (long long)((g.N + 511) / 512) * zcount >= 1024) return launch_one<1, 4, 4, 4, AKM, BKN>(g, zcount, s);
     if (g.M <= 128) return launch_one<1, 4, 4, 2, AKM, BKN>(g, zcount, s);
     if (g.N <= 128) return launch_one<4, 1, 2, 4, AKM, BKN>(g, zcount, s);
     return launch_one<2, 2, 4, 4, AKM, BKN>(g, zcount, s);

@@ -210,6 +210,26 @@ def test_gemm_dma_all_operand_layouts(dev, M, N, K, batch):
         assert rel_err(C2.cpu().numpy(), ref2) < 1e-5
 
 
+@pytest.mark.gpu
+def test_gemm_dma_wide_tile_for_few_rows(dev):
+    """M <= 128 with enough column tiles takes the 128 x 512 block tile (ten staged pieces per thread): all four
+    operand layouts, ragged M and N, against float64."""
+    from vgtk import _hip
+    gen = torch.Generator().manual_seed(77)
+    M, N, K, batch = 100, 65536 + 24, 48, 8
+    A = torch.randn(M, K, generator=gen)
+    B = torch.randn(batch, K, N, generator=gen)
+    ref = torch.matmul(A.double(), B.double()).numpy()
+    Ad, Bd = A.to(dev), B.to(dev)
+    At = A.t().contiguous().to(dev)
+    Bt = B.transpose(1, 2).contiguous().to(dev)
+    for ta, tb, a, lda, bm, ldb in ((0, 0, Ad, K, Bd, N), (0, 1, Ad, K, Bt, K), (1, 0, At, M, Bd, N), (1, 1, At, M, Bt, K)):
+        C = torch.full((batch, M, N), float('nan'), device=dev)
+        _hip.call('eap_gemm_dma_f32', C, ta, tb, M, N, K, _hip._ptr(a), _hip._I64(lda), _hip._I64(0), _hip._ptr(bm), _hip._I64(ldb),
+                  _hip._I64(K * N), _hip._ptr(C), _hip._I64(N), _hip._I64(M * N), batch)
+        assert rel_err(C.cpu().numpy(), ref) < 2e-6, (ta, tb)
+
+
 def test_gemm_dma_is_transpose_detecting_and_deterministic(dev):
     from vgtk import _hip
     n = 256
