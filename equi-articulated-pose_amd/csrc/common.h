@@ -62,8 +62,13 @@ int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, i
                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
 // csrc/zpconv_rows.hip: native inter zpconv forward near HBM speed (shared neighbour list per point)
 bool inter_zpconv_rows_supported(int np, int nq, int na, int ks, int nn, int c);
+// (only_flagged != nullptr: clouds whose flag is zero are left untouched)
 int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx, const float *w,
-                          const float *feats, float *out, hipStream_t s);
+                          const float *feats, float *out, const int32_t *only_flagged, hipStream_t s);
+// csrc/zpconv_mfma.hip: the same op on the matrix cores for clouds with one neighbour list per point (skip[b] == 0)
+bool inter_zpconv_mfma_supported(int np, int nq, int na, int ks, int nn, int c);
+int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx0, const float *w,
+                          const float *feats, const int32_t *skip, float *out, hipStream_t s);
 // csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped
 int group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                    const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,

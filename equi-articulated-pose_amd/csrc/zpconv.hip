@@ -176,7 +176,7 @@ extern "C" int eap_inter_zpconv_fwd_f32(int b, int np, int nq, int na, int ks, i
                                         const float *w, const float *src, float *dst, eap_stream_t stream) {
     // HBM-speed path when the sizes fit (csrc/zpconv_rows.hip; it checks the index pattern itself)
     if (b > 0 && np > 0 && eap::inter_zpconv_rows_supported(np, nq, na, ks, ann, c))
-        return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, eap::S(stream));
+        return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, nullptr, eap::S(stream));
     return launch_inter<float, false>(b, np, nq, na, ks, ann, c, idx, w, src, dst, eap::S(stream));
 }
 EAP_INTER(eap_inter_zpconv_fwd_f64, double, false)

@@ -47,8 +47,11 @@ __host__ __device__ inline int w_pitch(int na) { return ((na + 3) & ~3) + ((((na
 
 __global__ __launch_bounds__(TM, 2) void inter_zpconv_rows_kernel(
     int np, int nq, int na, int ks, int nn, int c, int nkt, const int32_t *__restrict__ idx,
-    const float *__restrict__ w, const float *__restrict__ feats, float *__restrict__ out) {
+    const float *__restrict__ w, const float *__restrict__ feats, const int32_t *__restrict__ only_flagged,
+    float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // behind the matrix path (csrc/zpconv_mfma.hip) this kernel serves only the clouds whose index is irregular
+    if (only_flagged != nullptr && __builtin_amdgcn_readfirstlane(only_flagged[blockIdx.z]) == 0) return;
     const int PW = w_pitch(na);
     float *s_w = reinterpret_cast<float *>(smem);                  // [(n&3, k, n>>2)][PW]
     int *s_q = reinterpret_cast<int *>(s_w + KT * nn * PW);        // [nn]
@@ -223,14 +226,14 @@ bool inter_zpconv_rows_supported(int np, int nq, int na, int ks, int nn, int c) 
 }
 
 int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx, const float *w,
-                          const float *feats, float *out, hipStream_t s) {
+                          const float *feats, float *out, const int32_t *only_flagged, hipStream_t s) {
     const int nkt = (ks + KT - 1) / KT;
     const size_t shmem = sizeof(float) * KT * (size_t)nn * w_pitch(na) + 4 * (size_t)nn;
     int e = eap::hip_fail(hipFuncSetAttribute((const void *)inter_zpconv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
                           "inter_zpconv_forward shared memory");
     if (e) return e;
     dim3 grid(np * nkt, (c + NWV * CT - 1) / (NWV * CT), b);
-    hipLaunchKernelGGL(inter_zpconv_rows_kernel, grid, dim3(TM), shmem, s, np, nq, na, ks, nn, c, nkt, idx, w, feats, out);
+    hipLaunchKernelGGL(inter_zpconv_rows_kernel, grid, dim3(TM), shmem, s, np, nq, na, ks, nn, c, nkt, idx, w, feats, only_flagged, out);
     return eap::check_launch("inter_zpconv_forward (rows)");
 }
 

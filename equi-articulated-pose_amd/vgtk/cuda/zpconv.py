@@ -19,6 +19,13 @@ def inter_zpconv_forward(idx, w, feats):
     b, np_, na, ks, ann = idx.shape
     c, nq = feats.shape[1], feats.shape[2]
     out = torch.empty(b, c, ks, np_, na, dtype=feats.dtype, device=feats.device)
+    if feats.dtype == torch.float32:
+        # scratch for the device-side index check + the per-point neighbour lists (csrc/zpconv_mfma.hip)
+        nbytes = int(_hip.lib.eap_inter_zpconv_fwd_workspace(b, np_, ann))
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=feats.device)
+        _hip.call('eap_inter_zpconv_fwd_ws_f32', out, b, np_, nq, na, ks, ann, c,
+                  _hip._ptr(idx), _hip._ptr(w), _hip._ptr(feats), _hip._ptr(out), _hip._ptr(ws))
+        return out
     _hip.call('eap_inter_zpconv_fwd_' + _hip.suffix(feats), out, b, np_, nq, na, ks, ann, c,
               _hip._ptr(idx), _hip._ptr(w), _hip._ptr(feats), _hip._ptr(out))
     return out

@@ -81,6 +81,14 @@ int eap_inter_zpconv_fwd_f32(int b, int np, int nq, int na, int ks, int ann, int
 int eap_inter_zpconv_fwd_f64(int b, int np, int nq, int na, int ks, int ann, int c,
                              const int32_t *idx, const double *w, const double *feats,
                              double *out, eap_stream_t stream);
+/* The same op with a scratch buffer of eap_inter_zpconv_fwd_workspace(b, np, ann) BYTES (16-byte aligned): the index is
+ * checked on device for the pattern every reference caller produces (one neighbour list per point broadcast over
+ * (a,k): spconv/functional.py:L232-249) and those clouds run on the matrix cores (csrc/zpconv_mfma.hip); any other
+ * cloud, size or alignment falls through to eap_inter_zpconv_fwd_f32's kernels.  Same results either way. */
+int64_t eap_inter_zpconv_fwd_workspace(int b, int np, int ann);
+int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c,
+                                const int32_t *idx, const float *w, const float *feats, float *out,
+                                void *workspace, eap_stream_t stream);
 /* inter_zpconv_backward: zpconv_cuda.cpp:L58-75, kernel .cu:L77-116.
  * grad [b,c,ks,np,na] -> gfeats [b,c,nq,na]. */
 int eap_inter_zpconv_bwd_f32(int b, int np, int nq, int na, int ks, int ann, int c,

@@ -106,13 +106,16 @@ def test_inter_zpconv(dev, dtype, tol, shape):
     assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 10 * tol
 
 
-@pytest.mark.parametrize('case', ['shared', 'irregular', 'mixed'])
-@pytest.mark.parametrize('shape', [(2, 9, 50, 60, 24, 64, 40), (1, 5, 33, 28, 17, 32, 16), (1, 3, 20, 60, 24, 64, 130)])
+@pytest.mark.parametrize('case', ['shared', 'irregular', 'mixed', 'split'])
+@pytest.mark.parametrize('shape', [(2, 9, 50, 60, 24, 64, 40), (1, 5, 33, 28, 17, 32, 16), (1, 3, 20, 60, 24, 64, 130),
+                                   (3, 21, 40, 60, 24, 16, 64), (2, 6, 17, 12, 24, 24, 33)])
 def test_inter_zpconv_row_kernel(dev, case, shape):
-    """>= 8 channels: csrc/zpconv_rows.hip.  'shared' = the index the Python
+    """>= 8 channels: csrc/zpconv_mfma.hip (index check + matrix-core kernel for clouds whose index is one
+    neighbour list per point) and csrc/zpconv_rows.hip (every other cloud).  'shared' = the index the Python
     layer builds (one neighbour list per point broadcast over anchors and kernel points);
     'irregular' = an arbitrary 5-D index (the workgroup falls back to the gather loop);
-    'mixed' = some points of each kind."""
+    'mixed' = some points of each kind; 'split' = the first cloud shared, the others irregular (both paths in
+    one call, chosen per cloud on the device)."""
     import vgtk.cuda.zpconv as Z
     b, p, q, a, k, ann, c = shape
     rng = np.random.default_rng(7)
@@ -122,6 +125,11 @@ def test_inter_zpconv_row_kernel(dev, case, shape):
         idx = shared.copy()
     elif case == 'irregular':
         idx = random
+    elif case == 'split':
+        idx = np.where((np.arange(b) == 0)[:, None, None, None, None], shared, random).astype(np.int32)
+        if b > 1:
+            idx[1] = shared[1]
+            idx[1, p - 1, a - 1, k - 1, ann - 1] = (idx[1, p - 1, 0, 0, ann - 1] + 1) % q   # cloud 1: one deviating entry at the very end
     else:
         idx = np.where((np.arange(p) % 2 == 0)[None, :, None, None, None], shared, random).astype(np.int32)
         idx[0, 1, a - 1, k - 1, ann - 1] = (idx[0, 1, 0, 0, ann - 1] + 1) % q      # a single deviating entry in the last row
