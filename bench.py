@@ -193,10 +193,10 @@ def cpu_baseline(points, slab=64):
             'value_perm_search_short_circuited': out['short_circuit']}
 
 
-def zpconv_roofline(dev, points, clouds=2, channels=64):
-    """The standalone native zpconv forward (vgtk.cuda.zpconv.inter_zpconv_forward, the op the north
-    star puts an HBM-roofline target on): algorithmic bytes = idx + w read once,
-    feats, out written once; time = HIP events around 3 launches after a warm-up.  Separate from
+def zpconv_roofline(dev, points, clouds=8, channels=64):
+    """The standalone native zpconv ops (vgtk.cuda.zpconv.inter_zpconv_forward / _backward, the op the north
+    star puts an HBM-roofline target on): algorithmic bytes = idx + w read once, feats / grad
+    read once, out / gfeats written once; time = HIP events around 3 launches after a warm-up.  Separate from
     the timed steps (the shipped models never call this op: they use the fused grouping)."""
     import synth_clouds
     import vgtk.cuda.zpconv as Z
@@ -208,18 +208,30 @@ def zpconv_roofline(dev, points, clouds=2, channels=64):
     w = torch.rand(clouds, points, NA, KS, NN, device=dev)
     feats = torch.randn(clouds, channels, points, NA, device=dev)
     byts = 4.0 * clouds * (2.0 * points * NA * KS * NN + channels * points * NA + channels * KS * points * NA)
-    Z.inter_zpconv_forward(idx, w, feats)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
-        Z.inter_zpconv_forward(idx, w, feats)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 3
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 3
+
+    ms = timed(lambda: Z.inter_zpconv_forward(idx, w, feats))
+    grad = torch.randn(clouds, channels, KS, points, NA, device=dev)
+    ms_b = timed(lambda: Z.inter_zpconv_backward(idx, w, grad, points))
     gbs = byts / ms / 1e6
-    return {'bound': 'hbm', 'kernel': 'inter_zpconv_rows_kernel', 'entry': 'eap_inter_zpconv_fwd_f32', 'achieved': gbs,
+    return {'bound': 'hbm', 'kernel': 'zpconv_index_check_kernel + zpconv_mfma_kernel (v_mfma_f32_32x32x2_f32, streamed weights)',
+            'entry': 'eap_inter_zpconv_fwd_ws_f32', 'achieved': gbs,
             'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'ms': ms, 'bytes': byts,
+            'backward': {'entry': 'eap_inter_zpconv_bwd_ws_f32',
+                         'kernels': 'zpconv_index_check_kernel + zpconv_bwd_t_kernel (MFMA) + inv_lists + zpconv_bwd_sum_kernel (atomics-free)',
+                         'ms': ms_b, 'achieved': byts / ms_b / 1e6, 'frac': byts / ms_b / 1e6 / 8000.0,
+                         'bytes': byts, 'note': 'same algorithmic bytes as the forward (idx + w + grad read, gfeats written); the '
+                                                'per-(point, neighbour) products it writes and re-reads (4*P*NN*C*A bytes per cloud) are not counted'},
             'workload': f'{clouds} x {points} points, C={channels}, A={NA}, K={KS}, NN={NN}, one neighbour list per point '
                         f'broadcast over (a,k) as the Python layer builds it, radius {radius}'}
 

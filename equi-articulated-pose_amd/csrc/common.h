@@ -69,6 +69,11 @@ int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, 
 bool inter_zpconv_mfma_supported(int np, int nq, int na, int ks, int nn, int c);
 int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx0, const float *w,
                           const float *feats, const int32_t *skip, float *out, hipStream_t s);
+// index pattern check shared by the zpconv forward and backward (csrc/zpconv_mfma.hip), the flag-gated scatter backward
+// (csrc/zpconv.hip)
+int zpconv_index_check(int b, int np, int per_point, int nn, const int32_t *idx, int32_t *idx0, float *eid, int32_t *flag, hipStream_t s);
+int inter_zpconv_bwd_flagged(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx, const float *w,
+                             const float *grad, float *gfeats, const int32_t *only_flagged, hipStream_t s);
 // csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped
 int group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                    const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,

@@ -30,8 +30,9 @@ constexpr int ZP_THREADS = 256;
 template <typename T, int CC, bool BWD>
 __global__ __launch_bounds__(ZP_THREADS) void inter_zpconv_kernel(
     int np, int nq, int na, int ks, int ann, int c, const int32_t *__restrict__ idx,
-    const T *__restrict__ w, const T *__restrict__ src, T *__restrict__ dst) {
+    const T *__restrict__ w, const T *__restrict__ src, T *__restrict__ dst, const int32_t *__restrict__ only_flagged) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (only_flagged != nullptr && only_flagged[blockIdx.z] == 0) return;     // served by csrc/zpconv_bwd.hip
     const int pitch = KC * ann + 1;
     T *s_w = reinterpret_cast<T *>(smem);
     int32_t *s_idx = reinterpret_cast<int32_t *>(smem + sizeof(T) * (size_t)na * pitch);
@@ -97,10 +98,10 @@ __global__ __launch_bounds__(ZP_THREADS) void inter_zpconv_kernel(
 
 template <typename T, bool BWD>
 int launch_inter(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx,
-                 const T *w, const T *src, T *dst, hipStream_t s) {
+                 const T *w, const T *src, T *dst, hipStream_t s, const int32_t *only_flagged = nullptr) {
     if (b <= 0 || c <= 0) return 0;
     if (na > 64) return eap::bad_arg("inter_zpconv: at most 64 anchors are supported");
-    if (BWD) {
+    if (BWD && only_flagged == nullptr) {
         int e = eap::hip_fail(hipMemsetAsync(dst, 0, sizeof(T) * (size_t)b * c * nq * na, s),
                               "inter_zpconv_backward memset");
         if (e) return e;
@@ -118,7 +119,7 @@ int launch_inter(int b, int np, int nq, int na, int ks, int ann, int c, const in
                           "inter_zpconv shared memory");
     if (e) return e;
     dim3 grid(np, 1, b);
-    hipLaunchKernelGGL(kern, grid, dim3(ZP_THREADS), shmem, s, np, nq, na, ks, ann, c, idx, w, src, dst);
+    hipLaunchKernelGGL(kern, grid, dim3(ZP_THREADS), shmem, s, np, nq, na, ks, ann, c, idx, w, src, dst, only_flagged);
     return eap::check_launch(BWD ? "inter_zpconv_backward" : "inter_zpconv_forward");
 }
 
@@ -166,6 +167,14 @@ int launch_intra(int b, int np, int na_in, int na_out, int ks, int ann, int c, c
 }
 
 }  // namespace
+
+namespace eap {
+// the scatter kernel for the clouds whose flag is non-zero only, accumulating into an output the caller has zeroed
+int inter_zpconv_bwd_flagged(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx, const float *w,
+                             const float *grad, float *gfeats, const int32_t *only_flagged, hipStream_t s) {
+    return launch_inter<float, true>(b, np, nq, na, ks, ann, c, idx, w, grad, gfeats, s, only_flagged);
+}
+}  // namespace eap
 
 #define EAP_INTER(NAME, T, BWD)                                                                  \
     extern "C" int NAME(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx, \

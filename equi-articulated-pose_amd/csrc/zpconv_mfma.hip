@@ -33,8 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CT = 256;
 
+// (eid != nullptr: also entry ids for the backward's inverse lists -- float4 whose x holds the bits of p * nn + n)
 __global__ __launch_bounds__(CT) void zpconv_index_check_kernel(int np, int per_point, int nn, const int32_t *__restrict__ idx,
-                                                                int32_t *__restrict__ idx0, int32_t *__restrict__ flag) {
+                                                                int32_t *__restrict__ idx0, float4 *__restrict__ eid,
+                                                                int32_t *__restrict__ flag) {
     extern __shared__ int4 s_ref[];                                // the point's first row
     const int p = blockIdx.x, bi = blockIdx.y, t = threadIdx.x;
     const size_t pb = (size_t)bi * np + p;
@@ -45,6 +47,8 @@ __global__ __launch_bounds__(CT) void zpconv_index_check_kernel(int np, int per_
         s_ref[q] = v;
         reinterpret_cast<int4 *>(idx0 + pb * nn)[q] = v;
     }
+    if (eid != nullptr)
+        for (int n = t; n < nn; n += CT) eid[pb * nn + n] = make_float4(__uint_as_float((unsigned)(p * nn + n)), 0.f, 0.f, 0.f);
     __syncthreads();
     int mismatch = 0;
     // four independent 16-byte loads per thread in flight
@@ -362,6 +366,12 @@ __global__ __launch_bounds__(TM, 2) void zpconv_mfma_kernel(
 
 namespace eap {
 
+int zpconv_index_check(int b, int np, int per_point, int nn, const int32_t *idx, int32_t *idx0, float *eid, int32_t *flag, hipStream_t s) {
+    hipLaunchKernelGGL(zpconv_index_check_kernel, dim3(np, b), dim3(CT), (size_t)nn * 4, s, np, per_point, nn, idx, idx0,
+                       reinterpret_cast<float4 *>(eid), flag);
+    return eap::check_launch("inter_zpconv (index check)");
+}
+
 bool inter_zpconv_mfma_supported(int np, int nq, int na, int ks, int nn, int c) {
     if (na <= 0 || na > 64 || (na & 3) != 0 || ks <= 0 || ks > 32 || nn <= 0 || (nn % SBK) != 0 || c < 16) return false;
     if ((long long)CB * nq * na * 4 >= (1ll << 32) || (long long)ks * nn * 4 >= (1ll << 24)) return false;
@@ -406,8 +416,7 @@ extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks
     int32_t *idx0 = flag + 64 * ((b + 63) / 64);
     int e = eap::hip_fail(hipMemsetAsync(flag, 0, sizeof(int32_t) * b, s), "inter_zpconv_forward flags");
     if (e) return e;
-    hipLaunchKernelGGL(zpconv_index_check_kernel, dim3(np, b), dim3(CT), (size_t)ann * 4, s, np, na * ks * ann, ann, idx, idx0, flag);
-    e = eap::check_launch("inter_zpconv_forward (index check)");
+    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, idx0, nullptr, flag, s);
     if (e) return e;
     e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
     if (e) return e;

@@ -4,6 +4,10 @@ import torch
 from .. import _hip
 
 
+# upper bound of the backward's scratch buffer (the batch is processed in slices that fit)
+BWD_WORKSPACE_BYTES = 16 << 30
+
+
 def _check(idx, w, x):
     _hip.check_input(idx, w, x)
     if idx.dtype != torch.int32:
@@ -37,6 +41,17 @@ def inter_zpconv_backward(idx, w, grad, npoint):
     b, np_, na, ks, ann = idx.shape
     c = grad.shape[1]
     out = torch.empty(b, c, int(npoint), na, dtype=grad.dtype, device=grad.device)
+    if grad.dtype == torch.float32 and b > 0:
+        # atomics-free path (csrc/zpconv_bwd.hip): scratch for the per-(point, neighbour) products, a few clouds at a time
+        per_cloud = int(_hip.lib.eap_inter_zpconv_bwd_workspace(1, np_, int(npoint), na, ann, c))
+        step = max(1, min(b, BWD_WORKSPACE_BYTES // max(per_cloud, 1)))
+        ws = torch.empty((int(_hip.lib.eap_inter_zpconv_bwd_workspace(step, np_, int(npoint), na, ann, c)) + 3) // 4,
+                         dtype=torch.int32, device=grad.device)
+        for b0 in range(0, b, step):
+            nb = min(step, b - b0)
+            _hip.call('eap_inter_zpconv_bwd_ws_f32', out, nb, np_, int(npoint), na, ks, ann, c, _hip._ptr(idx[b0:b0 + nb]),
+                      _hip._ptr(w[b0:b0 + nb]), _hip._ptr(grad[b0:b0 + nb]), _hip._ptr(out[b0:b0 + nb]), _hip._ptr(ws))
+        return out
     _hip.call('eap_inter_zpconv_bwd_' + _hip.suffix(grad), out, b, np_, int(npoint), na, ks, ann, c,
               _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
     return out

@@ -97,6 +97,15 @@ int eap_inter_zpconv_bwd_f32(int b, int np, int nq, int na, int ks, int ann, int
 int eap_inter_zpconv_bwd_f64(int b, int np, int nq, int na, int ks, int ann, int c,
                              const int32_t *idx, const double *w, const double *grad,
                              double *gfeats, eap_stream_t stream);
+/* The same op without atomics, with a scratch buffer of eap_inter_zpconv_bwd_workspace(b, np, nq, na, ann, c) BYTES
+ * (256-byte aligned; dominated by 4*b*np*na*ann*c for the per-(point, neighbour) products -- split the batch to bound
+ * it): for clouds whose index is one neighbour list per point (checked on device) the products are formed in forward
+ * order on the matrix cores and summed per support point over device-built inverse lists, in a fixed order
+ * (csrc/zpconv_bwd.hip); any other cloud, size or alignment goes through eap_inter_zpconv_bwd_f32's scatter kernel. */
+int64_t eap_inter_zpconv_bwd_workspace(int b, int np, int nq, int na, int ann, int c);
+int eap_inter_zpconv_bwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c,
+                                const int32_t *idx, const float *w, const float *grad, float *gfeats,
+                                void *workspace, eap_stream_t stream);
 /* intra_zpconv_forward: zpconv_cuda.cpp:L77-92, kernel .cu:L120-156.
  * idx [na_out,ann], w [na_out,ks,ann], feats [b,c,np,na_in] -> out [b,c,ks,np,na_out]. */
 int eap_intra_zpconv_fwd_f32(int b, int np, int na_in, int na_out, int ks, int ann, int c,

@@ -138,6 +138,14 @@ def test_inter_zpconv_row_kernel(dev, case, shape):
     out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
     ref = native.inter_zpconv_forward(idx, w, feats)
     assert rel_err(out, ref) < 2e-6
+    # backward: csrc/zpconv_bwd.hip (products in forward order on the matrix cores + sorted sums) for the shared-index
+    # clouds, the scatter kernel for the others; twice -> the atomics-free part is bit-reproducible
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    got = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q)
+    assert rel_err(got.cpu().numpy(), native.inter_zpconv_backward(idx, w, g, q)) < 1e-5
+    if case == 'shared' and c % 4 == 0 and c >= 16:
+        again = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q)
+        assert torch.equal(got, again)
 
 
 @pytest.mark.parametrize('dtype,tol', [(np.float32, 2e-6), (np.float64, 1e-13)])
