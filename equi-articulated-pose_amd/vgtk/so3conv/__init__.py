@@ -2,4 +2,5 @@ from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose  # noqa: F4
 from .functional import *  # noqa: F401,F403
 from .modules import *  # noqa: F401,F403
 from .blocks import BatchNormLeakyReLU, InstanceNormLeakyReLU  # noqa: F401
-from .heads import InvPPOutBlockOurs, anchor_attention_pool, orbit_selection, slot_masked_mean, rotation_from_angle_axis  # noqa: F401
+from .heads import (InvPPOutBlockOurs, SO3OutBlockRTWithMaskSep, anchor_attention_pool, orbit_selection, slot_masked_mean,  # noqa: F401
+                    rotation_from_angle_axis)

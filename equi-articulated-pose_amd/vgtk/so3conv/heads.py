@@ -8,8 +8,13 @@ and 3), mirroring the reference classes so a maintainer can swap the import:
   slot_masked_mean         the masked per-slot point averages of SO3OutBlockRTWithMaskSep
                            (SPConvNets/models/model_utils.py:L470-484, L549-552) for ALL slots in one pass
   rotation_from_angle_axis model_utils.py angle -> R (Rodrigues), batched
+  SO3OutBlockRTWithMaskSep SPConvNets/models/model_utils.py:L363-677, the pose head (rotation / translation / axis /
+                           pivot regressors over the equivariant feature map): same constructor parameters,
+                           sub-module and state_dict names, same output dictionary.  Its 1x1-convolution stacks run on
+                           the path's own kernels (contraction GEMM + fused BatchNorm/ReLU epilogue); the small
+                           regressors and the masked translation average stay torch ops.
 
-The 1x1 convolutions / BatchNorms are dense torch layers (rocBLAS / MIOpen plumbing)."""
+InvPPOutBlockOurs' 1x1 convolutions / BatchNorms are dense torch layers (rocBLAS / MIOpen plumbing)."""
 import ctypes
 
 import torch
@@ -17,6 +22,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _hip
+from . import functional as L
+from .blocks import _BNAct
 
 _F32 = ctypes.c_float
 
@@ -151,3 +158,186 @@ def rotation_from_angle_axis(angle, axis):
                      y * x * C + z * s, c + y * y * C, y * z * C - x * s,
                      z * x * C - y * s, z * y * C + x * s, c + z * z * C], -1)
     return R.view(*angle.shape, 3, 3)
+
+
+def _unary_stack(x, linears, norms):
+    """relu(norm_i(conv1x1_i(x))) for every layer of a ModuleList pair (model_utils.py:L478-485): the 1x1 convolution
+    is the path's contraction GEMM (csrc/gemm_dma_f32.hip through so3_contract), BatchNorm + ReLU the fused block
+    epilogue (csrc/bn_act.hip, leaky slope 0) on the nn.BatchNorm2d's own parameters and running statistics."""
+    for lid, linear in enumerate(linears):
+        b, c, n, a = x.shape
+        y = L.so3_contract(linear.weight.view(linear.out_channels, c), x.reshape(b, c, n * a)).view(b, linear.out_channels, n, a)
+        if linear.bias is not None:
+            y = y + linear.bias.view(1, -1, 1, 1)
+        if norms is not None:
+            bn = norms[lid]
+            if bn.training:
+                bn.num_batches_tracked.add_(1)
+            x = _BNAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, 0.0, False)
+        else:
+            x = F.relu(y)
+    return x
+
+
+class SO3OutBlockRTWithMaskSep(nn.Module):
+    """The pose head of the articulated models (SPConvNets/models/model_utils.py:L363-677): two 1x1-conv stacks over
+    the equivariant feature map (rotation branch on `x.feats`, translation branch on `trans_feats`), point pooling, a
+    per-anchor rotation regressor (quaternion or angle), a dense per-point translation regressor rotated by the
+    anchors and averaged over the (masked) points, optional axis / pivot-point / central-point regressors.
+    Constructor parameters, sub-module names (state_dict keys) and the returned dictionary are the reference's."""
+
+    def __init__(self, params, norm=None, pooling_method='mean', global_scalar=False, use_anchors=False,
+                 feat_mode_num=60, num_heads=1, pred_R=True, representation='quat', num_in_channels=None, c_in_rot=None,
+                 c_in_trans=None, pred_axis=False, pred_pv_points=False, pv_points_in_dim=None, pred_central_points=False,
+                 central_points_in_dim=None, mtx_based_axis_regression=False):
+        super(SO3OutBlockRTWithMaskSep, self).__init__()
+        from .modules import PointnetSO3Conv
+        c_in = params['dim_in'] if num_in_channels is None else num_in_channels
+        mlp = params['mlp']
+        na = params['kanchor']
+        self.linear = nn.ModuleList()
+        self.trans_linear = nn.ModuleList()
+        self.temperature = params['temperature']
+        self.global_scalar = global_scalar
+        self.use_anchors = use_anchors
+        self.feat_mode_num = feat_mode_num
+        self.num_heads = num_heads
+        self.representation = representation
+        self.pred_axis = pred_axis
+        self.pred_pv_points = pred_pv_points
+        self.pred_central_points = pred_central_points
+        self.pv_points_in_dim = mlp[-1] if pv_points_in_dim is None else pv_points_in_dim
+        self.central_points_in_dim = mlp[-1] if central_points_in_dim is None else central_points_in_dim
+        self.mtx_based_axis_regression = mtx_based_axis_regression
+        self.pred_R = pred_R
+        self.norm = nn.ModuleList() if norm is not None else None
+        self.trans_norm = nn.ModuleList() if norm is not None else None
+        self.pooling_method = pooling_method
+        if self.pooling_method == 'pointnet':
+            self.pointnet = PointnetSO3Conv(mlp[-1], mlp[-1], na)
+        heads = 1 if self.feat_mode_num < 2 else num_heads
+        if self.pred_R:
+            self.regressor_layer = nn.Conv1d(mlp[-1], (4 if self.representation == 'quat' else 1) * heads, 1)
+        if self.pred_axis:
+            self.axis_regressor_layer = nn.Conv1d(mlp[-1], (4 if self.mtx_based_axis_regression else 3) * heads, 1)
+        if self.pred_pv_points:
+            self.pvp_regressor_layer = nn.Sequential(nn.Conv1d(self.pv_points_in_dim, 3 * heads, 1), nn.Sigmoid())
+        if self.pred_central_points:
+            self.central_point_regressor_layer = nn.Sequential(nn.Conv1d(self.central_points_in_dim, 3 * heads, 1), nn.Sigmoid())
+        if self.global_scalar:
+            self.regressor_scalar_layer = nn.Conv1d(mlp[-1], 1 * num_heads, 1)
+        c_in = c_in_rot if c_in_rot is not None else c_in
+        for c in mlp:
+            self.linear.append(nn.Conv2d(c_in, c, 1))
+            if norm is not None:
+                self.norm.append(nn.BatchNorm2d(c))
+            c_in = c
+        c_in = c_in_trans if c_in_trans is not None else params['dim_in'] if num_in_channels is None else num_in_channels
+        for c in mlp:
+            self.trans_linear.append(nn.Conv2d(c_in, c, 1))
+            if norm is not None:
+                self.trans_norm.append(nn.BatchNorm2d(c))
+            c_in = c
+        self.regressor_dense_layer = nn.Sequential(nn.Conv2d(2 * mlp[-1], mlp[-1], 1), nn.BatchNorm2d(mlp[-1]),
+                                                   nn.LeakyReLU(inplace=True), nn.Conv2d(c, 3 * num_heads, 1))
+
+    def _pool(self, feats, xyz, mask):
+        """-> (pooled [b,c,a], the per-point features the later layers see).  With 'max' pooling and a mask the
+        reference zeroes the masked points IN PLACE (model_utils.py:L530-533), so its dense translation branch reads the
+        zeroed map too; reproduced here."""
+        if self.pooling_method == 'mean':
+            return feats.mean(2), feats
+        if self.pooling_method == 'max':
+            if mask is not None:
+                feats = feats * (mask >= 0.5).to(feats.dtype).unsqueeze(1).unsqueeze(-1)
+            return feats.max(2)[0], feats
+        if self.pooling_method == 'pointnet':
+            from ..spconv import SphericalPointCloud
+            return self.pointnet(SphericalPointCloud(xyz, feats, None)), feats
+        raise NotImplementedError(f"Pooling mode {self.pooling_method} is not implemented!")
+
+    def forward(self, x, mask, trans_feats, trans_xyz=None, anchors=None, soft_mask=None, pre_feats=None, use_offset=True,
+                pred_pv_poitns_in_feats=None, pred_central_points_in_feats=None, pred_axis_in_feats=None):
+        import math
+        x_out = x.feats
+        if not x_out.is_cuda:
+            raise RuntimeError('SO3OutBlockRTWithMaskSep: tensors must be CUDA(HIP) tensors (no CPU fallback)')
+        if mask is not None:
+            x_out = x_out * mask.unsqueeze(1).unsqueeze(-1)
+        nb, _, _, na = x_out.shape
+        x_out, _ = self._pool(_unary_stack(x_out, self.linear, self.norm), x.xyz, mask)               # [b, c, a]
+        trans_x_xyz = x.xyz if trans_xyz is None else trans_xyz
+        trans_shared_feat = _unary_stack(trans_feats, self.trans_linear, self.trans_norm)            # [b, c, n, a]
+        trans_x_out, trans_shared_feat = self._pool(trans_shared_feat, trans_x_xyz, mask)
+
+        # dense branch: per point and anchor, 3 * num_heads translation components.  Layers 0-2 of the Sequential
+        # (conv, BatchNorm, LeakyReLU(0.01)) go through the fused epilogue
+        d0, dbn, dact, d1 = self.regressor_dense_layer
+        cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, trans_shared_feat.shape[2], -1), trans_shared_feat], dim=1).contiguous()
+        b, c2, n, a = cat.shape
+        y = L.so3_contract(d0.weight.view(d0.out_channels, c2), cat.reshape(b, c2, n * a)).view(b, d0.out_channels, n, a)
+        y = y + d0.bias.view(1, -1, 1, 1)
+        if dbn.training:
+            dbn.num_batches_tracked.add_(1)
+        y = _BNAct.apply(y, dbn.weight, dbn.bias, dbn.running_mean, dbn.running_var, dbn.training, dbn.momentum, dbn.eps,
+                         dact.negative_slope, False)
+        t_out = F.conv2d(y, d1.weight, d1.bias)                                                       # [b, 3 h, n, a]: 3 h output channels
+        t_out = t_out.reshape((nb, self.num_heads, 3) + t_out.shape[-2:])                             # [b, h, 3, n, a]
+        if self.global_scalar:
+            y_t = self.regressor_scalar_layer(trans_shared_feat.max(dim=-1)[0]).reshape(nb, self.num_heads, -1)
+            y_t = F.normalize(t_out, p=2, dim=2) * y_t.unsqueeze(2).unsqueeze(-1)
+            if self.use_anchors:
+                y_t = torch.matmul(anchors.unsqueeze(1), y_t.permute(0, 1, 4, 2, 3).contiguous())
+            else:
+                y_t = y_t.permute(0, 1, 4, 2, 3).contiguous()
+        else:
+            y_t = torch.matmul(anchors.unsqueeze(1), t_out.permute(0, 1, 4, 2, 3).contiguous())       # [b, h, a, 3, n]
+        if use_offset:
+            y_t = y_t + trans_x_xyz.unsqueeze(1).unsqueeze(1)
+        wts = mask if mask is not None else soft_mask
+        if wts is not None:
+            wts = wts.unsqueeze(1).unsqueeze(1).unsqueeze(1)
+            y_t = torch.sum(y_t * wts, dim=-1) / torch.clamp(torch.sum(wts, dim=-1), min=1e-8)
+            y_t = y_t.contiguous().permute(0, 1, 3, 2).contiguous()
+        else:
+            y_t = y_t.mean(dim=-1).permute(0, 1, 3, 2).contiguous()                                   # [b, h, 3, a]
+
+        output = {}
+        if self.pred_R:
+            if pre_feats is not None:
+                pre_feats = pre_feats.contiguous().unsqueeze(-1).repeat(1, 1, x_out.size(-1)).contiguous()
+                y = self.regressor_layer(pre_feats)
+            else:
+                y = self.regressor_layer(x_out)
+        else:
+            y = None
+        output['R'] = y
+        output['T'] = y_t
+        if self.pred_axis:
+            pred_axis_in_feats = x_out if pred_axis_in_feats is None else pred_axis_in_feats
+            y_axis = self.axis_regressor_layer(pred_axis_in_feats)
+            if self.mtx_based_axis_regression:
+                e = torch.sigmoid(y_axis.contiguous().view(y_axis.size(0), self.num_heads, 4, na))
+                alpha, beta = e[:, :, 0, :].unsqueeze(-2), e[:, :, 1, :].unsqueeze(-2)
+                maxx_angle = 45.0
+                y_angle = (maxx_angle / 180.) * beta * math.pi + ((90.0 - maxx_angle) / 180.0) * math.pi
+                xz_len = torch.cos(y_angle)
+                y_axis = torch.cat([torch.cos(alpha * 2.0 * math.pi) * xz_len, torch.sin(y_angle),
+                                    torch.sin(alpha * 2.0 * math.pi) * xz_len], dim=-2)
+            else:
+                y_axis = y_axis / torch.clamp(torch.norm(y_axis, dim=1, keepdim=True, p=2), min=1e-6)
+            output['axis'] = y_axis
+        else:
+            output['axis'] = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float32, device=x_out.device).unsqueeze(0).unsqueeze(
+                -1).contiguous().repeat(x_out.size(0), 1, y.size(-1))
+        if self.pred_pv_points:
+            pred_pv_poitns_in_feats = x_out if pred_pv_poitns_in_feats is None else pred_pv_poitns_in_feats
+            output['pv_points'] = self.pvp_regressor_layer(pred_pv_poitns_in_feats)
+        if self.pred_central_points:
+            pred_central_points_in_feats = x_out if pred_central_points_in_feats is None else pred_central_points_in_feats
+            output['central_points'] = self.central_point_regressor_layer(pred_central_points_in_feats)
+        if self.num_heads == 1:
+            for key, value in output.items():
+                if value is not None:
+                    output[key] = value.squeeze(1)
+        return output

@@ -405,3 +405,32 @@ def test_block_epilogue_with_skip_add(dev, training):
     assert float((yf - yr).abs().max()) <= 2e-6 * float(yr.abs().max())
     assert float((xf.grad - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
     assert torch.equal(rf.grad, rr.grad)
+
+
+def test_pose_head_matches_reference_golden(dev, golden):
+    """vgtk.so3conv.SO3OutBlockRTWithMaskSep (section 8(f) row 3) against tests/golden/pose_head.npz, produced by the
+    reference class (SPConvNets/models/model_utils.py:L363-677) on CPU with the same state_dict and inputs: the
+    whole output dictionary in training mode (batch statistics; running statistics after the step) and in eval mode."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    G = golden('pose_head.npz')
+    head = sptk.SO3OutBlockRTWithMaskSep({'dim_in': 16, 'mlp': [32, 24], 'kanchor': 60, 'temperature': 3.0}, norm=1, pooling_method='max',
+                                         pred_axis=True, pred_pv_points=True, pred_central_points=True, num_heads=1, representation='quat')
+    state = {k[len('state_'):]: torch.from_numpy(np.asarray(v)) for k, v in G.items() if k.startswith('state_')}
+    assert set(state) == set(head.state_dict().keys())
+    T = lambda k: torch.from_numpy(np.asarray(G[k])).to(dev)
+    for mode in ('train', 'eval'):
+        head.load_state_dict(state)
+        head = head.to(dev)
+        head.train(mode == 'train')
+        x = zptk.SphericalPointCloud(T('xyz'), T('feats'), None)
+        with torch.no_grad():
+            res = head(x, T('mask'), T('trans_feats'), trans_xyz=T('xyz'), anchors=T('anchors'))
+        for k in ('R', 'T', 'axis', 'pv_points', 'central_points'):
+            ref = np.asarray(G[f'{mode}_{k}'])
+            assert res[k].shape == ref.shape, k
+            assert rel_err(res[k].cpu().numpy(), ref) < 2e-5, (mode, k)
+        if mode == 'train':
+            for k, v in head.state_dict().items():
+                if 'running' in k:
+                    assert rel_err(v.cpu().numpy(), np.asarray(G[f'after_{k}'])) < 1e-5, k
