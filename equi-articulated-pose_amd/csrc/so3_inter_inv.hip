@@ -31,6 +31,7 @@ __device__ unsigned long long eap_inv_trace[8 * 16];
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CB = 32;        // dY channels per block (one MFMA M tile)
 constexpr int NBK = 8;        // entries per LDS stage (4 MFMA k-steps)
@@ -66,14 +67,14 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     const float *__restrict__ gy,
     const int32_t *__restrict__ rows, const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx, const float *__restrict__ rk,
-    const uint8_t *__restrict__ multinv, float *__restrict__ out) {
+    const uint8_t *__restrict__ multinv, const float *__restrict__ anchors, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int FP = DMA ? na : (na <= 60 ? 60 : FPMAX), FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
     float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * FP_);       // [3][NBK] (ring; [2][NBK] used without DMA)
     int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] entry -> query point (DMA), 16-byte multiple
-    float4 *s_rk = reinterpret_cast<float4 *>(s_p + 4 * NBK);               // [na][ks] scaled kernel points (HAS_MULT)
-    uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_rk + (HAS_MULT ? na * ks : 0));
+    float4 *s_A = reinterpret_cast<float4 *>(s_p + 4 * NBK);                // [na][3] rows of the anchor rotations (HAS_MULT)
+    uint8_t *s_mult = reinterpret_cast<uint8_t *>(s_A + (HAS_MULT ? 3 * na : 0));
 
     // Block -> (row, channel slice, cloud).  Every entry list walks the query points in ascending
     // order, so blocks that work on the SAME channel slice of the SAME cloud at the same time read
@@ -101,12 +102,26 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         const int words = (na * na) >> 2;
         for (int i = t; i < words; i += TM)
             reinterpret_cast<uint32_t *>(s_mult)[i] = reinterpret_cast<const uint32_t *>(multinv)[i];
-        for (int i = t; i < na * ks; i += TM) {       // w = max(0, base_e + kc + g . k')  (see step())
-            const float x = rk[i * 3], y = rk[i * 3 + 1], z = rk[i * 3 + 2];
-            s_rk[i] = make_float4(2.f * inv_sigma * x, 2.f * inv_sigma * y, 2.f * inv_sigma * z,
-                                  -inv_sigma * (x * x + y * y + z * z));
-        }
+        for (int i = t; i < 3 * na; i += TM) s_A[i] = make_float4(anchors[3 * i], anchors[3 * i + 1], anchors[3 * i + 2], 0.f);
+        __syncthreads();
     }
+    // Anchor permutation.  An entry with relative-rotation anchor r pairs the accumulator's anchor a' with the dY
+    // column a = multinv[r][a'], and its weight belongs to anchor a: w = relu(1 - |g - A_a kappa|^2 / s).  The
+    // anchors are a group and mult[r][a] = a' means A_a' = A_r A_a, so |g - A_a kappa| = |A_r g - A_a' kappa|:
+    // with the entry's offset vector rotated ONCE by A_r when it enters the LDS ring, the weights are those of the
+    // wave's OWN anchors -- per-lane register constants, as without permutation (round 1 looked the constants of
+    // every (entry, anchor) pair up in an LDS table: a 16-byte LDS read and an address computation per weight).
+    auto rotate_entry = [&](float4 g) {
+        if (HAS_MULT) {
+            const int r = __float_as_int(g.w);
+            if (r != identity_anchor && (unsigned)r < (unsigned)na && g.x < 1e17f) {
+                const float4 r0 = s_A[3 * r], r1 = s_A[3 * r + 1], r2 = s_A[3 * r + 2];
+                g = make_float4(r0.x * g.x + r0.y * g.y + r0.z * g.z, r1.x * g.x + r1.y * g.y + r1.z * g.z,
+                                r2.x * g.x + r2.y * g.y + r2.z * g.z, g.w);
+            }
+        }
+        return g;
+    };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // 8 waves, contiguous anchor ranges that all start at an EVEN anchor (8,8,8,8,8,8,6,6 at na = 60)
@@ -120,16 +135,16 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     //   base_e = 1 - |g|^2/sigma (once per entry),  k' = 2k/sigma,  kc = -|k|^2/sigma (constants):
     // 3 FMAs + add + max per weight instead of 9 operations; unused kernel-point columns carry
     // kc = -1e30 so their weight is 0
-    float kx[APW], ky[APW], kz[APW], kc[APW];
-    if (!HAS_MULT)
+    // evaluated with as few VALU instructions as it takes (they cost fp32-MFMA time on this part, csrc/so3_inter_lists.hip):
+    // two anchors per packed instruction, the relu as the clamp modifier of the last FMA
+    f32x2 kxp[APW / 2], kyp[APW / 2], kzp[APW / 2], kcp[APW / 2];
 #pragma unroll
-    for (int ai = 0; ai < APW; ++ai) {   // register constants (no permutation: anchors map to themselves)
+    for (int ai = 0; ai < APW; ++ai) {
         const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + lkc) * 3;
         const float x = r3[0], y = r3[1], z = r3[2];
-        kx[ai] = 2.f * inv_sigma * x; ky[ai] = 2.f * inv_sigma * y; kz[ai] = 2.f * inv_sigma * z;
-        kc[ai] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
+        kxp[ai >> 1][ai & 1] = 2.f * inv_sigma * x; kyp[ai >> 1][ai & 1] = 2.f * inv_sigma * y; kzp[ai >> 1][ai & 1] = 2.f * inv_sigma * z;
+        kcp[ai >> 1][ai & 1] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
     }
-    const float kdead = lk < ks ? 0.f : -1e30f;          // permuted path: added to the LDS constant
 
     f32x16 acc[APW];
 #pragma unroll
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
                 *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
                     live ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (t < NBK) s_g[buf * NBK + t] = gtmp;
+        if (t < NBK) s_g[buf * NBK + t] = rotate_entry(gtmp);
     };
 
     const int nchunk = (n_ent + NBK - 1) / NBK;
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     auto store_idx = [&](int slot) {
         if (wave_u == 0 && lane < NBK) {
             s_p[slot * NBK + lane] = idx_p;
-            s_g[slot * NBK + lane] = idx_g;
+            s_g[slot * NBK + lane] = rotate_entry(idx_g);
         }
     };
     auto prep_rows = [&](int slot) {
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     // identity): anchors map to themselves and the weight constants are per-lane registers.
     // HAS_MULT = true: the permuted anchor of every (entry, anchor) pair comes from the LDS
     // table, and so do its weight constants (read 4 at a time, one wait per group).
-    auto gather = [&](const float *fbuf, int gb, int s, float (&fa)[APW], int (&aw)[APW]) {
+    auto gather = [&](const float *fbuf, int gb, int s, float (&fa)[APW]) {
         const int nl = 2 * s + lh;
         const float *frow = fbuf + ((size_t)nl * CB + lk) * FP;
         if (!HAS_MULT) {   // anchors map to themselves: pairs of anchors = one aligned 8-byte read
@@ -271,62 +286,37 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             const int r = __float_as_int(s_g[gb * NBK + nl].w);
 #pragma unroll
             for (int ai = 0; ai < APW; ++ai) {
-                const int a = (int)s_mult[r * na + min(a_beg + ai, na - 1)];
-                aw[ai] = a * ks + lkc;
-                fa[ai] = frow[a];
+                fa[ai] = frow[(int)s_mult[r * na + min(a_beg + ai, na - 1)]];
             }
         }
     };
     auto nothing = [] {};
     // mid() / end() run after the first / second half of the step's MFMAs (the DMA path requests
     // the next chunk's rows there, a few at a time, so the memory pipe never backs up into a wave)
-    auto step_g = [&](const float4 g, const float (&fa)[APW], const int (&aw)[APW], auto mid, auto end) {
+    auto step_g = [&](const float4 g, const float (&fa)[APW], auto mid, auto end) {
         const float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
-        if (!HAS_MULT) {
-            // all weights of the step first (independent chains), then the MFMAs back to back: a
-            // per-anchor guard between them would fence every weight chain behind the previous MFMA
-            float wv[APW];
+        // all weights of the step first (independent chains), then the MFMAs back to back
+        f32x2 wv[APW / 2];
 #pragma unroll
-            for (int ai = 0; ai < APW; ++ai) {
-                float t = fmaf(g.x, kx[ai], kc[ai]);
-                t = fmaf(g.y, ky[ai], t);
-                t = fmaf(g.z, kz[ai], t);
-                wv[ai] = fmaxf(t + base, 0.0f);
-            }
-            // no per-anchor guard: a wave with fewer than APW anchors repeats its last one into
-            // accumulators the epilogue never stores (its SIMD partner owns a full set anyway)
-#pragma unroll
-            for (int ai = 0; ai < APW / 2; ++ai)
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
-            mid();
-#pragma unroll
-            for (int ai = APW / 2; ai < APW; ++ai)
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai], acc[ai], 0, 0, 0);
-            end();
-        } else {
-#pragma unroll
-            for (int h = 0; h < APW; h += 4) {
-                float4 k4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) k4[j] = s_rk[aw[h + j]];
-                float wv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = fmaf(g.x, k4[j].x, k4[j].w + kdead);
-                    t = fmaf(g.y, k4[j].y, t);
-                    t = fmaf(g.z, k4[j].z, t);
-                    wv[j] = fmaxf(t + base, 0.0f);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[h + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h + j], wv[j], acc[h + j], 0, 0, 0);
-                if (h == 0) mid(); else end();
-            }
+        for (int j = 0; j < APW / 2; ++j) {
+            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], kcp[j] + (f32x2){base, base});
+            x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
         }
+        // no per-anchor guard: a wave with fewer than APW anchors repeats its last one into
+        // accumulators the epilogue never stores (its SIMD partner owns a full set anyway)
+#pragma unroll
+        for (int ai = 0; ai < APW / 2; ++ai)
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
+        mid();
+#pragma unroll
+        for (int ai = APW / 2; ai < APW; ++ai)
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
+        end();
     };
 
-    auto step = [&](int gb, int s, const float (&fa)[APW], const int (&aw)[APW], auto mid, auto end) {
-        step_g(s_g[gb * NBK + 2 * s + lh], fa, aw, mid, end);
+    auto step = [&](int gb, int s, const float (&fa)[APW], auto mid, auto end) {
+        step_g(s_g[gb * NBK + 2 * s + lh], fa, mid, end);
     };
 
 #ifdef EAP_INV_TRACE
@@ -345,23 +335,22 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
             float fa[4][APW];
             float4 gv[4];
-            int aw[APW];
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 gv[st] = s_g[g0 * NBK + 2 * st + lh];
-                gather(fbuf, g0, st, fa[st], aw);
+                gather(fbuf, g0, st, fa[st]);
             }
             prep_rows(g1);
             load_idx((ch + 2) * NBK);
             __builtin_amdgcn_sched_barrier(0);
             TR(1);
-            step_g(gv[0], fa[0], aw, [&] { issue(0, nb); }, [&] { issue(1, nb); });
+            step_g(gv[0], fa[0], [&] { issue(0, nb); }, [&] { issue(1, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            step_g(gv[1], fa[1], aw, [&] { issue(2, nb); }, [&] { issue(3, nb); });
+            step_g(gv[1], fa[1], [&] { issue(2, nb); }, [&] { issue(3, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            step_g(gv[2], fa[2], aw, [&] { issue(4, nb); }, [&] { issue(5, nb); });
+            step_g(gv[2], fa[2], [&] { issue(4, nb); }, [&] { issue(5, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            step_g(gv[3], fa[3], aw, [&] { issue(6, nb); }, [&] { issue(7, nb); });
+            step_g(gv[3], fa[3], [&] { issue(6, nb); }, [&] { issue(7, nb); });
             TR(2);
             store_idx(g2);
             dma_wait();
@@ -377,30 +366,29 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             TR(0);
             const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
             float fa0[APW], fa1[APW];
-            int aw0[APW], aw1[APW];
             // operands of the first two steps before anything else, so the matrix pipe restarts
             // right after the barrier; the next chunk's row addresses follow in their shadow.
             // The rows themselves are requested unconditionally (past the end of the list the
             // ring repeats the last entry: a harmless reload into the idle buffer).
-            gather(fbuf, g0, 0, fa0, aw0);
+            gather(fbuf, g0, 0, fa0);
             __builtin_amdgcn_sched_barrier(0);
             load_idx((ch + 2) * NBK);
-            gather(fbuf, g0, 1, fa1, aw1);
+            gather(fbuf, g0, 1, fa1);
             __builtin_amdgcn_sched_barrier(0);
             prep_rows(g1);
             __builtin_amdgcn_sched_barrier(0);
             TR(1);
-            step(g0, 0, fa0, aw0, [&] { issue(0, nb); }, [&] { issue(1, nb); issue(2, nb); });
+            step(g0, 0, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); issue(2, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            gather(fbuf, g0, 2, fa0, aw0);
+            gather(fbuf, g0, 2, fa0);
             __builtin_amdgcn_sched_barrier(0);
-            step(g0, 1, fa1, aw1, [&] { issue(3, nb); }, [&] { issue(4, nb); issue(5, nb); });
+            step(g0, 1, fa1, [&] { issue(3, nb); }, [&] { issue(4, nb); issue(5, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            gather(fbuf, g0, 3, fa1, aw1);
+            gather(fbuf, g0, 3, fa1);
             __builtin_amdgcn_sched_barrier(0);
-            step(g0, 2, fa0, aw0, [&] { issue(6, nb); }, [&] { issue(7, nb); });
+            step(g0, 2, fa0, [&] { issue(6, nb); }, [&] { issue(7, nb); });
             __builtin_amdgcn_sched_barrier(0);
-            step(g0, 3, fa1, aw1, nothing, nothing);
+            step(g0, 3, fa1, nothing, nothing);
             TR(2);
             store_idx(g2);
             dma_wait();
@@ -420,22 +408,21 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         TR(1);
         const float *fbuf = s_f + (size_t)buf * NBK * CB * FP;
         float fa0[APW], fa1[APW];
-        int aw0[APW], aw1[APW];
-        gather(fbuf, buf, 0, fa0, aw0);
+        gather(fbuf, buf, 0, fa0);
         __builtin_amdgcn_sched_barrier(0);
-        gather(fbuf, buf, 1, fa1, aw1);
+        gather(fbuf, buf, 1, fa1);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 0, fa0, aw0, nothing, nothing);
+        step(buf, 0, fa0, nothing, nothing);
         __builtin_amdgcn_sched_barrier(0);
-        gather(fbuf, buf, 2, fa0, aw0);
+        gather(fbuf, buf, 2, fa0);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 1, fa1, aw1, nothing, nothing);
+        step(buf, 1, fa1, nothing, nothing);
         __builtin_amdgcn_sched_barrier(0);
-        gather(fbuf, buf, 3, fa1, aw1);
+        gather(fbuf, buf, 3, fa1);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 2, fa0, aw0, nothing, nothing);
+        step(buf, 2, fa0, nothing, nothing);
         __builtin_amdgcn_sched_barrier(0);
-        step(buf, 3, fa1, aw1, nothing, nothing);
+        step(buf, 3, fa1, nothing, nothing);
         TR(2);
         if (ch + 1 < nchunk) stash(buf ^ 1);
         TR(3);
@@ -502,11 +489,12 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
                                            float sigma, const float *gy, const int32_t *rows,
                                            const int32_t *off, const int32_t *cnt,
                                            const int32_t *ent_p, const float *ent_gx, const float *rk,
-                                           const uint8_t *multinv, int identity_anchor, float *z,
+                                           const uint8_t *multinv, const float *anchors, int identity_anchor, float *z,
                                            eap_stream_t stream) {
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64 || (na & 3) != 0) return eap::bad_arg("so3_inter_group_inv: the anchor count must be a multiple of 4, at most 64");
     if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
+    if (multinv && !anchors) return eap::bad_arg("so3_inter_group_inv: the anchor rotations are needed with a permutation table");
     if ((long long)o * p * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_inv: one cloud's gradient exceeds 2^31 elements");
     hipStream_t s = eap::S(stream);
     // no anchor permutation: the two-workgroups-per-CU kernel of csrc/so3_inter_lists.hip
@@ -519,14 +507,14 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     const int FP_ = dma ? na : (na <= 60 ? 60 : FPMAX);
     const size_t stage_b = sizeof(float) * 2 * NBK * CB * FP_;
     if (sizeof(float) * 8 * (size_t)ks * na > stage_b) return eap::bad_arg("so3_inter_group_inv: epilogue tile too large");
-    size_t shmem = stage_b + 16 * 3 * NBK + 16 * NBK + (multinv ? 16 * (size_t)na * ks + (size_t)na * na : 0);
+    size_t shmem = stage_b + 16 * 3 * NBK + 16 * NBK + (multinv ? 16 * 3 * (size_t)na + (size_t)na * na : 0);
     if (shmem > 160 * 1024) return eap::bad_arg("so3_inter_group_inv: LDS budget exceeded");
     dim3 grid(rcap, (o + CB - 1) / CB, b);
     const float4 *g4 = reinterpret_cast<const float4 *>(ent_gx);
     auto launch = [&](auto kern) {
         int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
         if (e) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, z);
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, anchors, z);
         return 0;
     };
     int e;

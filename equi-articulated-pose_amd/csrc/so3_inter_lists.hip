@@ -234,7 +234,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         for (int j = 0; j < APW / 2; ++j) {
             f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], kcp[j] + (f32x2){bk, bk});
             x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
         }
         // unguarded: a wave whose last anchors fall off the group repeats its last one into
         // accumulators the epilogue never stores

@@ -25,6 +25,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CB = 32;        // channels per block (one MFMA M tile)
 constexpr int NBK = 8;        // neighbours per LDS stage (4 MFMA k-steps; the pipeline below is written for 4)
@@ -85,14 +86,15 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     // kernel weight  w = relu(1 - |g - k|^2 / sigma) = relu(base_n + kc + g . k'),
     //   base_n = 1 - |g|^2/sigma (once per neighbour),  k' = 2k/sigma,  kc = -|k|^2/sigma:
     // 3 FMAs + add + max per weight; unused kernel-point columns carry kc = -1e30 (weight 0)
-    float kx[APW], ky[APW], kz[APW], kc[APW];
+    // packed pairs: the weights are evaluated two anchors per VALU instruction (csrc/so3_inter_lists.hip has the why)
+    f32x2 kxp[APW / 2], kyp[APW / 2], kzp[APW / 2], kcp[APW / 2];
 #pragma unroll
     for (int ai = 0; ai < APW; ++ai) {
         const bool ok = ai < a_cnt && lk < ks;
         const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + min(lk, ks - 1)) * 3;   // clamped, always valid
         const float x = r3[0], y = r3[1], z = r3[2];
-        kx[ai] = 2.f * inv_sigma * x; ky[ai] = 2.f * inv_sigma * y; kz[ai] = 2.f * inv_sigma * z;
-        kc[ai] = ok ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
+        kxp[ai >> 1][ai & 1] = 2.f * inv_sigma * x; kyp[ai >> 1][ai & 1] = 2.f * inv_sigma * y; kzp[ai >> 1][ai & 1] = 2.f * inv_sigma * z;
+        kcp[ai >> 1][ai & 1] = ok ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
     }
     // identity relative rotations everywhere in this cloud (flag from so3_prep): no table lookups
     const bool plain = !HAS_MULT || (nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) == 0);
@@ -183,15 +185,17 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     auto step = [&](int n0, int s, const float (&fa)[APW]) {
         const float4 g = s_g[n0 + 2 * s + lh];
         const float base = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
+        f32x2 wv[APW / 2];
 #pragma unroll
-        for (int ai = 0; ai < APW; ++ai) {
-            float tt = fmaf(g.x, kx[ai], kc[ai]);
-            tt = fmaf(g.y, ky[ai], tt);
-            tt = fmaf(g.z, kz[ai], tt);
-            const float wv = fmaxf(tt + base, 0.0f);
-            if (ai < a_cnt)                              // wave-uniform
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv, acc[ai], 0, 0, 0);
+        for (int j = 0; j < APW / 2; ++j) {
+            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], kcp[j] + (f32x2){base, base});
+            x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
         }
+#pragma unroll
+        for (int ai = 0; ai < APW; ++ai)
+            if (ai < a_cnt)                              // wave-uniform
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
     };
 
     for (int ch = 0; ch < nchunk; ++ch) {

@@ -380,9 +380,10 @@ class _InterConv(torch.autograd.Function):
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident, nonident=None):
+    def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None):
         feats = feats.contiguous()
         W = W.contiguous()
+        ctx.anchors = anchors.detach().contiguous() if anchors is not None else None   # the rotations `mult` was built from
         # X is internal to this Function: where the kernels allow it, it is kept blocked by anchor
         # quads ([b,p,a/4,c,k,4]) -- coalesced row-end stores in the grouping kernel -- and the GEMMs
         # read it as a blocked B operand (include/eap_hip.h, "blocked intermediate")
@@ -443,7 +444,7 @@ class _InterConv(torch.autograd.Function):
             ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
             multinv = _group_tables_inverse(mult) if (mult is not None and any_nonident) else None
             z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
-                                         ctx.ident)                                  # [b,o,ks,rcap,na]
+                                         ctx.ident, ctx.anchors)                     # [b,o,ks,rcap,na]
             ra = rcap * na
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
@@ -472,7 +473,7 @@ class _InterConv(torch.autograd.Function):
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
-        return gF, gW, None, None, None, None, None, None, None
+        return gF, gW, None, None, None, None, None, None, None, None
 
 
 INTRA_DW_SLICE = 64      # channels whose 12-tap gather is materialised at a time for the intra weight gradient
@@ -601,7 +602,8 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
     gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
-    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident)
+    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident,
+                         anchors if mult is not None else None)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 

@@ -195,12 +195,14 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
  * rows [b,rcap] (support index or -1), off/cnt [b,rcap] (range of the row's entries in the
  * per-item sorted entry list), ent_p [b,p*nn] (query point of each entry), ent_gx float4
  * [b,p*nn] (its so3_prep word), rk [na,ks,3], multinv [na,na] (multinv[r][a'] = a, NULL = no
- * permutation)  ->  z [b,o,ks,rcap,na].  The caller finishes with eap_gemm_f32. */
+ * permutation), anchors [na,3,3] (the rotations the table was built from; needed with multinv: an
+ * entry's offset vector is rotated by A_r once so that its weights are those of the accumulator's own
+ * anchor)  ->  z [b,o,ks,rcap,na].  The caller finishes with eap_gemm_dma_f32. */
 int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma,
                                 const float *gy, const int32_t *rows, const int32_t *off,
                                 const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
-                                const float *rk, const uint8_t *multinv, int identity_anchor,
-                                float *z, eap_stream_t stream);
+                                const float *rk, const uint8_t *multinv, const float *anchors,
+                                int identity_anchor, float *z, eap_stream_t stream);
 
 /* so3_inter_group_inv without anchor permutation, gy stored with a row pitch: gy [b,o,p,gy_pitch], gy_pitch a
  * multiple of 4 and >= na (64 makes every 60-anchor row start on a 256-byte boundary). */
