@@ -6,7 +6,8 @@ import collections, csv, glob, json, os, sys
 
 out_dir, run = sys.argv[1], sys.argv[2]
 ENTRY = [('so3_group_lists_kernel<true', 'eap_so3_inter_group_inv_f32'), ('so3_group_lists_kernel<false, 2', 'eap_so3_inter_group_fwd_t_f32'),
-         ('gemm_dma_f32_kernel', 'eap_gemm_dma_f32'), ('inter_zpconv_rows_kernel', 'eap_inter_zpconv_fwd_f32'),
+         ('gemm_dma_f32_kernel', 'eap_gemm_dma_f32'), ('zpconv_mfma_kernel', 'eap_inter_zpconv_fwd_ws_f32 (matrix kernel)'), ('zpconv_index_check_kernel', 'eap_inter_zpconv_*_ws_f32 (index check)'),
+         ('zpconv_bwd_t_kernel', 'eap_inter_zpconv_bwd_ws_f32 (products)'), ('zpconv_bwd_sum_kernel', 'eap_inter_zpconv_bwd_ws_f32 (sums)'),
          ('bn_act_bwd_apply', 'eap_bn_act_bwd_apply_f32'), ('bn_act_fwd', 'eap_bn_act_fwd_f32')]
 
 
