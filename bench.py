@@ -348,10 +348,16 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # (EAP_DIST_BACKEND=gloo + several ranks on one device: a functional check of the N > 1 path on a 1-GPU box only)
+    backend = os.environ.get('EAP_DIST_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import synth_clouds
     from vgtk import _hip, sharding
