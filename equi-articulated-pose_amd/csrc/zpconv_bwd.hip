@@ -142,43 +142,48 @@ __global__ __launch_bounds__(TM, 2) void zpconv_bwd_t_kernel(int C, int na, int 
     }
 }
 
-// gfeats[b, c, q, 4 aq .. +3] = sum over q's entries e = (p, n) of T[b, p, a, n, c]
+// gfeats[b, c, q, 16 ag .. +15] = sum over q's entries e = (p, n) of T[b, p, a, n, c]: thread (anchor al = t >> 4,
+// channel quad c4 = t & 15) reads 16 bytes per entry (a wave = 4 anchors x 256 contiguous bytes), four entries in flight,
+// summed in entry order; the [16 anchors][64 channels] result goes through LDS to 16-byte stores along the anchors
 __global__ __launch_bounds__(256) void zpconv_bwd_sum_kernel(int C, int na, int nq, int P, int nn, const int32_t *__restrict__ rows,
                                                              const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
                                                              const float4 *__restrict__ ent_e, const int32_t *__restrict__ skip,
                                                              const float *__restrict__ T, float *__restrict__ gf) {
-    __shared__ float s_x[4][65];
-    const int aq = blockIdx.x, r = blockIdx.y, bi = blockIdx.z, t = threadIdx.x;
+    __shared__ float s_x[16][65];
+    const int ag = blockIdx.x, r = blockIdx.y, bi = blockIdx.z, t = threadIdx.x;
     if (skip[bi] != 0) return;
     const int q = rows[(size_t)bi * nq + r];
     if (q < 0) return;
     const int n_ent = cnt[(size_t)bi * nq + r];
     const float4 *ent = ent_e + (size_t)bi * P * nn + off[(size_t)bi * nq + r];
-    const int al = t >> 6, cl = t & 63, a = 4 * aq + al;
+    const int al = t >> 4, c4 = (t & 15) * 4, a = min(16 * ag + al, na - 1);
     const size_t a_off = (size_t)a * nn * C, p_stride = (size_t)na * nn * C;
     const float *Tb = T + (size_t)bi * P * p_stride;
     for (int cb = 0; cb < C; cb += 64) {
-        const int c = min(cb + cl, C - 1);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const int c = min(cb + c4, C - 4);
+        auto row = [&](int j) {
+            const unsigned e = __float_as_uint(ent[j].x);
+            return *reinterpret_cast<const float4 *>(Tb + (size_t)(e / nn) * p_stride + a_off + (size_t)(e % nn) * C + c);
+        };
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        auto add = [](float4 &s, const float4 v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
         int j = 0;
-        for (; j + 4 <= n_ent; j += 4) {                            // four independent rows in flight, summed in entry order
-            const unsigned e0 = __float_as_uint(ent[j].x), e1 = __float_as_uint(ent[j + 1].x), e2 = __float_as_uint(ent[j + 2].x),
-                           e3 = __float_as_uint(ent[j + 3].x);
-            const float v0 = Tb[(size_t)(e0 / nn) * p_stride + a_off + (size_t)(e0 % nn) * C + c];
-            const float v1 = Tb[(size_t)(e1 / nn) * p_stride + a_off + (size_t)(e1 % nn) * C + c];
-            const float v2 = Tb[(size_t)(e2 / nn) * p_stride + a_off + (size_t)(e2 % nn) * C + c];
-            const float v3 = Tb[(size_t)(e3 / nn) * p_stride + a_off + (size_t)(e3 % nn) * C + c];
-            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        for (; j + 4 <= n_ent; j += 4) {
+            const float4 v0 = row(j), v1 = row(j + 1), v2 = row(j + 2), v3 = row(j + 3);
+            add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
         }
-        for (; j < n_ent; ++j) {
-            const unsigned e0 = __float_as_uint(ent[j].x);
-            s0 += Tb[(size_t)(e0 / nn) * p_stride + a_off + (size_t)(e0 % nn) * C + c];
-        }
-        s_x[al][cl] = (s0 + s1) + (s2 + s3);
+        for (; j < n_ent; ++j) add(s0, row(j));
+        s_x[al][c4] = (s0.x + s1.x) + (s2.x + s3.x);
+        s_x[al][c4 + 1] = (s0.y + s1.y) + (s2.y + s3.y);
+        s_x[al][c4 + 2] = (s0.z + s1.z) + (s2.z + s3.z);
+        s_x[al][c4 + 3] = (s0.w + s1.w) + (s2.w + s3.w);
         __syncthreads();
-        if (t < 64 && cb + t < C)
-            *reinterpret_cast<float4 *>(gf + (((size_t)bi * C + cb + t) * nq + q) * na + 4 * aq) =
-                make_float4(s_x[0][t], s_x[1][t], s_x[2][t], s_x[3][t]);
+        {
+            const int cc = t >> 2, aq = t & 3;                       // 64 channels x 4 anchor quads
+            if (cb + cc < C && 16 * ag + 4 * aq < na)
+                *reinterpret_cast<float4 *>(gf + (((size_t)bi * C + cb + cc) * nq + q) * na + 16 * ag + 4 * aq) =
+                    make_float4(s_x[4 * aq][cc], s_x[4 * aq + 1][cc], s_x[4 * aq + 2][cc], s_x[4 * aq + 3][cc]);
+        }
         __syncthreads();
     }
 }
@@ -257,7 +262,7 @@ extern "C" int eap_inter_zpconv_bwd_ws_f32(int b, int np, int nq, int na, int ks
     if (e) return e;
     e = eap_inv_lists_fill(b, np, nq, ann, nq, idx0, eid, rows, off, ent_p, ent_e, stream);
     if (e) return e;
-    hipLaunchKernelGGL(zpconv_bwd_sum_kernel, dim3(na >> 2, nq, b), dim3(256), 0, s, c, na, nq, np, ann, rows, off, cnt,
+    hipLaunchKernelGGL(zpconv_bwd_sum_kernel, dim3((na + 15) / 16, nq, b), dim3(256), 0, s, c, na, nq, np, ann, rows, off, cnt,
                        reinterpret_cast<const float4 *>(ent_e), flag, T, gfeats);
     e = eap::check_launch("inter_zpconv_backward (sums)");
     if (e) return e;
