@@ -3,4 +3,4 @@ from .functional import *  # noqa: F401,F403
 from .modules import *  # noqa: F401,F403
 from .blocks import BatchNormLeakyReLU, InstanceNormLeakyReLU  # noqa: F401
 from .heads import (InvPPOutBlockOurs, SO3OutBlockRTWithMaskSep, anchor_attention_pool, orbit_selection, slot_masked_mean,  # noqa: F401
-                    rotation_from_angle_axis)
+                    rotation_from_angle_axis, pose_head_over_subsets)

@@ -14,6 +14,8 @@ and 3), mirroring the reference classes so a maintainer can swap the import:
                            the path's own kernels (contraction GEMM + fused BatchNorm/ReLU epilogue); the small
                            regressors and the masked translation average stay torch ops.
 
+  pose_head_over_subsets   the model's per-cloud loop around that head (...pn_38_multi_stage.py:L706-830) as one call per slot
+
 InvPPOutBlockOurs' 1x1 convolutions / BatchNorms are dense torch layers (rocBLAS / MIOpen plumbing)."""
 import ctypes
 
@@ -341,3 +343,94 @@ class SO3OutBlockRTWithMaskSep(nn.Module):
                 if value is not None:
                     output[key] = value.squeeze(1)
         return output
+
+
+def _masked_unary_stack(x, m, cnt, linears, norms):
+    """_unary_stack for B independent batch-1 calls on point SUBSETS at once: x [B,C,P,A] full clouds, m [B,1,P,1] the
+    0/1 membership, cnt [B,1] = points in the subset x anchors.  Training-mode BatchNorm statistics are those of each
+    cloud's subset alone (what a batch-1 call on the gathered subset computes), and the running statistics receive the
+    B momentum updates in cloud order, as the loop would apply them."""
+    for lid, linear in enumerate(linears):
+        b, c, n, a = x.shape
+        y = L.so3_contract(linear.weight.view(linear.out_channels, c), x.reshape(b, c, n * a)).view(b, linear.out_channels, n, a)
+        if linear.bias is not None:
+            y = y + linear.bias.view(1, -1, 1, 1)
+        if norms is not None:
+            y = _subset_batchnorm(y, m, cnt, norms[lid])
+        x = F.relu(y)
+    return x
+
+
+def _subset_batchnorm(y, m, cnt, bn):
+    """nn.BatchNorm2d applied to every cloud's subset as its own batch-1 call (see _masked_unary_stack)."""
+    if bn.training:
+        ym = y * m
+        mean = ym.sum((2, 3)) / cnt                                        # [B, C]
+        var = ((ym * ym).sum((2, 3)) / cnt - mean * mean).clamp_min(0.0)   # biased, as BatchNorm normalises with
+        with torch.no_grad():
+            unb = var * (cnt / (cnt - 1.0).clamp_min(1.0))
+            for i in range(y.shape[0]):                                    # B tiny [C]-vector updates, in loop order
+                bn.running_mean.mul_(1.0 - bn.momentum).add_(mean[i], alpha=bn.momentum)
+                bn.running_var.mul_(1.0 - bn.momentum).add_(unb[i], alpha=bn.momentum)
+            bn.num_batches_tracked.add_(y.shape[0])
+        mean, var = mean[:, :, None, None], var[:, :, None, None]
+    else:
+        mean, var = bn.running_mean.view(1, -1, 1, 1), bn.running_var.view(1, -1, 1, 1)
+    return (y - mean) * torch.rsqrt(var + bn.eps) * bn.weight.view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
+
+
+def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
+    """SO3OutBlockRTWithMaskSep on one point subset per cloud, all clouds at once -- the batched form of the model's
+    inner loop `for i_bz in range(bz): head(SphericalPointCloud(xyz[i_bz, subset], feats[i_bz, :, subset]), mask=None,
+    trans_feats=..., trans_xyz=..., anchors=...)` (...pn_38_multi_stage.py:L706-830; one call of this function per
+    slot replaces the loop over the batch; every slot has its own head module, as in the reference).
+    feats [B,C,P,A], xyz [B,3,P], member [B,P] in {0,1} (at least one point per cloud), anchors [A,3,3] or [B,A,3,3]
+    -> the head's output dictionary with batch dimension B; identical (to rounding) to B separate batch-1 calls on the
+    gathered subsets, BatchNorm statistics and running-statistic updates included (tests/test_gpu_lists_and_modules.py).
+    Supported configuration: pooling 'mean' or 'max', no global_scalar."""
+    if head.pooling_method not in ('mean', 'max') or head.global_scalar:
+        raise NotImplementedError('pose_head_over_subsets: mean / max pooling without the global scalar only')
+    import math
+    b, _, n, na = feats.shape
+    m = member.to(feats.dtype).view(b, 1, n, 1)
+    npts = m.sum((2, 3))                                                    # [B, 1]
+    cnt = npts * na
+
+    def pool(f):
+        return (f * m).max(2)[0] if head.pooling_method == 'max' else (f * m).sum(2) / npts.view(b, 1, 1)
+
+    x_out = pool(_masked_unary_stack(feats, m, cnt, head.linear, head.norm))                     # [B, c, A]
+    shared = _masked_unary_stack(feats, m, cnt, head.trans_linear, head.trans_norm)            # [B, c, P, A]
+    trans_x_out = pool(shared)
+    d0, dbn, dact, d1 = head.regressor_dense_layer
+    cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, n, -1), shared], dim=1).contiguous()
+    y = L.so3_contract(d0.weight.view(d0.out_channels, cat.shape[1]), cat.reshape(b, cat.shape[1], n * na)).view(b, d0.out_channels, n, na)
+    y = F.leaky_relu(_subset_batchnorm(y + d0.bias.view(1, -1, 1, 1), m, cnt, dbn), dact.negative_slope)
+    t_out = F.conv2d(y, d1.weight, d1.bias).reshape(b, head.num_heads, 3, n, na)
+    A = anchors if anchors.dim() == 4 else anchors.unsqueeze(0)
+    y_t = torch.matmul(A.unsqueeze(1), t_out.permute(0, 1, 4, 2, 3).contiguous())                # [B, h, A, 3, P]
+    if use_offset:
+        y_t = y_t + xyz.unsqueeze(1).unsqueeze(1)
+    w = m.view(b, 1, 1, 1, n)
+    y_t = ((y_t * w).sum(-1) / npts.view(b, 1, 1, 1)).permute(0, 1, 3, 2).contiguous()            # [B, h, 3, A]
+    output = {'R': head.regressor_layer(x_out) if head.pred_R else None, 'T': y_t}
+    if head.pred_axis:
+        y_axis = head.axis_regressor_layer(x_out)
+        if head.mtx_based_axis_regression:
+            e = torch.sigmoid(y_axis.contiguous().view(b, head.num_heads, 4, na))
+            alpha, beta = e[:, :, 0, :].unsqueeze(-2), e[:, :, 1, :].unsqueeze(-2)
+            y_angle = (45.0 / 180.) * beta * math.pi + (45.0 / 180.0) * math.pi
+            xz_len = torch.cos(y_angle)
+            y_axis = torch.cat([torch.cos(alpha * 2.0 * math.pi) * xz_len, torch.sin(y_angle), torch.sin(alpha * 2.0 * math.pi) * xz_len], dim=-2)
+        else:
+            y_axis = y_axis / torch.clamp(torch.norm(y_axis, dim=1, keepdim=True, p=2), min=1e-6)
+        output['axis'] = y_axis
+    else:
+        output['axis'] = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float32, device=feats.device).view(1, 3, 1).repeat(b, 1, na)
+    if head.pred_pv_points:
+        output['pv_points'] = head.pvp_regressor_layer(x_out)
+    if head.pred_central_points:
+        output['central_points'] = head.central_point_regressor_layer(x_out)
+    if head.num_heads == 1:
+        output = {k: (v.squeeze(1) if v is not None else None) for k, v in output.items()}
+    return output

@@ -434,3 +434,40 @@ def test_pose_head_matches_reference_golden(dev, golden):
             for k, v in head.state_dict().items():
                 if 'running' in k:
                     assert rel_err(v.cpu().numpy(), np.asarray(G[f'after_{k}'])) < 1e-5, k
+
+
+@pytest.mark.parametrize('pooling', ['max', 'mean'])
+def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling):
+    """vgtk.so3conv.pose_head_over_subsets (one call per slot) against the model's inner loop: the head called once per
+    cloud, batch 1, on the gathered point subset with mask=None (...pn_38_multi_stage.py:L706-830) -- outputs and
+    the BatchNorm running statistics after the pass, training and eval mode."""
+    import copy
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    torch.manual_seed(3)
+    B, C, N, A = 3, 16, 40, 60
+    head = sptk.SO3OutBlockRTWithMaskSep({'dim_in': C, 'mlp': [32, 32], 'kanchor': A, 'temperature': 3.0}, norm=1, pooling_method=pooling,
+                                         pred_axis=True, pred_pv_points=True, pred_central_points=True).to(dev)
+    feats = torch.randn(B, C, N, A, device=dev)
+    xyz = torch.randn(B, 3, N, device=dev) * 0.3
+    member = torch.rand(B, N, device=dev) > 0.5
+    member[:, 0] = True
+    member[1, 4:] = False; member[1, :4] = True                    # a 4-point subset
+    anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors(A))).to(dev)
+    for training in (True, False):
+        ref_head, fast_head = copy.deepcopy(head).train(training), copy.deepcopy(head).train(training)
+        outs = []
+        with torch.no_grad():
+            for b in range(B):
+                sel = member[b].nonzero().squeeze(1)
+                fx, px = feats[b:b + 1, :, sel].contiguous(), xyz[b:b + 1, :, sel].contiguous()
+                outs.append(ref_head(zptk.SphericalPointCloud(px, fx, None), None, fx, trans_xyz=px, anchors=anchors.unsqueeze(0)))
+            got = sptk.pose_head_over_subsets(fast_head, feats, xyz, member, anchors)
+        for k in ('R', 'T', 'axis', 'pv_points', 'central_points'):
+            ref = torch.cat([o[k] for o in outs], 0)
+            assert got[k].shape == ref.shape, k
+            assert rel_err(got[k].cpu().numpy(), ref.cpu().numpy()) < 2e-5, (training, k)
+        for (k, v), (_, w) in zip(ref_head.state_dict().items(), fast_head.state_dict().items()):
+            if 'running' in k:
+                assert rel_err(w.cpu().numpy(), v.cpu().numpy()) < 1e-5, k
