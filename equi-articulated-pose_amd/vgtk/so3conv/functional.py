@@ -364,14 +364,14 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
             ent_p, ent_gx, rcap, not any_nonident)
 
 
-# Layout of the fused conv's intermediate X and who contracts it (where the kernels allow it, else the
-# reference layout + own GEMM):
-#   'transposed'  X as the plain [P*A, C*K] matrix, contraction = library GEMM (hipBLASLt via torch.matmul:
-#                 149 TFLOP/s on the deepest layer against 127 for csrc/gemm_f32.hip)
+# Layout of the fused conv's intermediate X (where the kernels allow it, else the reference layout); the contraction
+# is always a hand-written GEMM:
+#   'transposed'  X as the plain [P*A, C*K] matrix, both GEMM operands k-contiguous: csrc/gemm_dma_f32.hip
+#                 (141 TFLOP/s on the deepest layer; hipBLASLt, reachable with EAP_LIBRARY_GEMMS=1 for A/B timing only: 150)
 #   'blocked'     X blocked by anchor quads, contraction = csrc/gemm_f32.hip (eap_gemm_f32_xb)
-#   'reference'   X [C*K, P*A] as the reference's einsum writes it, contraction = csrc/gemm_f32.hip
+#   'reference'   X [C*K, P*A] as the reference's einsum writes it
 X_LAYOUT = os.environ.get('EAP_X_LAYOUT', 'transposed')
-LIBRARY_SMALL_GEMMS = os.environ.get('EAP_LIBRARY_GEMMS', '0') != '0'   # the two Z-based gradient GEMMs (plain row-major operands) through the library as well; False: csrc/gemm_f32.hip
+LIBRARY_SMALL_GEMMS = os.environ.get('EAP_LIBRARY_GEMMS', '0') != '0'   # A/B knob: the plain GEMMs through the vendor library instead of the own kernels (never the default)
 BLOCKED_X = True     # test knob: False forces the reference layout
 
 
