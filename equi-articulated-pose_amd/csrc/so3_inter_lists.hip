@@ -271,19 +271,33 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     auto store_row = [&](int row) {
         if (active && lk < ks) {
             if (LAYOUT == 2) {
-                // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix a library
-                // GEMM reads as B^T): for one register r and one anchor the 24 kernel-point lanes of a
-                // channel write 96 contiguous bytes, consecutive channels follow -- dword stores
+                // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix the contraction GEMM reads
+                // as B^T): for one register r and one anchor the 24 kernel-point lanes of a channel write 96 contiguous
+                // bytes, consecutive channels follow -- dword stores.  Wave-uniform base (SALU arithmetic) + one 32-bit
+                // byte offset per lane: the 64 stores of a row end cost no vector address arithmetic (they did: ~150
+                // VALU instructions per row end, i.e. matrix time)
                 const size_t CK = (size_t)C * ks;
                 float *rb = obb + ((size_t)row * na + a0 + al_beg) * CK + (size_t)c0 * ks;      // uniform
-                const unsigned lo = (unsigned)((4 * lh) * ks + lk);
+                const unsigned lo_b = (unsigned)((4 * lh) * ks + lk) * 4u;
+                if (full_c) {
+                    // (inline asm: hipcc does not pick the SGPR-base form here; the accumulators were last written by MFMAs
+                    // the asm cannot declare a dependency on, hence the wait states first)
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (full_c || c0 + (r & 3) + 8 * (r >> 2) + 4 * lh < C) {
+                    for (int r = 0; r < 16; ++r)
 #pragma unroll
                         for (int ai = 0; ai < APW; ++ai)
-                            rb[(size_t)ai * CK + (size_t)((r & 3) + 8 * (r >> 2)) * ks + lo] = acc[ai][r];
-                    }
+                            asm volatile("global_store_dword %0, %1, %2" : : "v"(lo_b), "v"(acc[ai][r]),
+                                         "s"(rb + (size_t)ai * CK + (size_t)((r & 3) + 8 * (r >> 2)) * ks) : "memory");
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (c0 + (r & 3) + 8 * (r >> 2) + 4 * lh < C) {
+#pragma unroll
+                            for (int ai = 0; ai < APW; ++ai)
+                                *reinterpret_cast<float *>(reinterpret_cast<char *>(rb + (size_t)ai * CK + (size_t)((r & 3) + 8 * (r >> 2)) * ks) + lo_b) = acc[ai][r];
+                        }
+                }
             } else if (LAYOUT == 1) {
                 float *rb = obb + (((size_t)row * npq + aq0) * C + c0) * ks * 4;     // uniform
 #pragma unroll
