@@ -196,7 +196,7 @@ def cpu_baseline(points, slab=64):
 def zpconv_roofline(dev, points, clouds=8, channels=64):
     """The standalone native zpconv ops (vgtk.cuda.zpconv.inter_zpconv_forward / _backward, the op the north
     star puts an HBM-roofline target on): algorithmic bytes = idx + w read once, feats / grad
-    read once, out / gfeats written once; time = HIP events around 3 launches after a warm-up.  Separate from
+    read once, out / gfeats written once; time = HIP events around 5 launches after 2 warm-up launches.  Separate from
     the timed steps (the shipped models never call this op: they use the fused grouping)."""
     import synth_clouds
     import vgtk.cuda.zpconv as Z
@@ -209,16 +209,17 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
     feats = torch.randn(clouds, channels, points, NA, device=dev)
     byts = 4.0 * clouds * (2.0 * points * NA * KS * NN + channels * points * NA + channels * KS * points * NA)
 
-    def timed(fn):
-        fn()
+    def timed(fn, warm=2, reps=5):
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(3):
+        for _ in range(reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / 3
+        return e0.elapsed_time(e1) / reps
 
     ms = timed(lambda: Z.inter_zpconv_forward(idx, w, feats))
     grad = torch.randn(clouds, channels, KS, points, NA, device=dev)

@@ -231,13 +231,9 @@ __global__ __launch_bounds__(TM, 2) void zpconv_mfma_kernel(
     // (piece + row) mod 8: the 32 channel lanes of a read spread over the banks
     const float4 *fa_lane = reinterpret_cast<const float4 *>(s_f + (size_t)(4 * lh * CB + lk) * PITCH + 4 * ((wave_u + lk) & 7));
 
+    // never zeroed: the first MFMA k-step of every point takes the constant 0 as its C operand (128 v_mov per point and
+    // wave would be matrix time)
     f32x16 acc[2][APW];
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int ai = 0; ai < APW; ++ai)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ti][ai][r] = 0.f;
 
     // streamed weights: lane (k, h) reads w[b, p, a, k, 16 blk + 8 h .. + 7] as two 16-byte words per anchor, by inline
     // asm like the DMA (hipcc cannot see the DMA requests and would otherwise wait for everything in flight)
@@ -276,28 +272,28 @@ __global__ __launch_bounds__(TM, 2) void zpconv_mfma_kernel(
         flush_round(std::integral_constant<int, 1>{}, tile0, row);
         flush_round(std::integral_constant<int, 2>{}, tile0, row);
         flush_round(std::integral_constant<int, 3>{}, tile0, row);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int ai = 0; ai < APW; ++ai)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ti][ai][r] = 0.f;
     };
 
     auto nothing = [] {};
     // MFMA k-step S of a stage with weight half H: 8 MFMAs (2 channel tiles x 4 anchors)
-#define ZP_STEP(S, H, FA0, FA1, WS, MID, END)                                                                        \
+#define ZP_MFMA(TI, AI, FA, COMP, H, S, WS, C) acc[TI][AI] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.COMP, wref<AI, H>(WS)[S], C, 0, 0, 0)
+#define ZP_STEP(S, H, FA0, FA1, WS, MID, END, FIRST)                                                                 \
     do {                                                                                                             \
         __builtin_amdgcn_s_setprio(3);                                                                               \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA0.x, wref<0, H>(WS)[S], acc[0][0], 0, 0, 0);              \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA1.x, wref<0, H>(WS)[S], acc[1][0], 0, 0, 0);              \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA0.y, wref<1, H>(WS)[S], acc[0][1], 0, 0, 0);              \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA1.y, wref<1, H>(WS)[S], acc[1][1], 0, 0, 0);              \
-        MID();                                                                                                       \
-        acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA0.z, wref<2, H>(WS)[S], acc[0][2], 0, 0, 0);              \
-        acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA1.z, wref<2, H>(WS)[S], acc[1][2], 0, 0, 0);              \
-        acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA0.w, wref<3, H>(WS)[S], acc[0][3], 0, 0, 0);              \
-        acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA1.w, wref<3, H>(WS)[S], acc[1][3], 0, 0, 0);              \
+        if (FIRST) {              /* block-uniform: the first k-step of a point starts from C = 0 */                  \
+            const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      \
+            ZP_MFMA(0, 0, FA0, x, H, S, WS, zc); ZP_MFMA(1, 0, FA1, x, H, S, WS, zc);                                \
+            ZP_MFMA(0, 1, FA0, y, H, S, WS, zc); ZP_MFMA(1, 1, FA1, y, H, S, WS, zc);                                \
+            MID();                                                                                                   \
+            ZP_MFMA(0, 2, FA0, z, H, S, WS, zc); ZP_MFMA(1, 2, FA1, z, H, S, WS, zc);                                \
+            ZP_MFMA(0, 3, FA0, w, H, S, WS, zc); ZP_MFMA(1, 3, FA1, w, H, S, WS, zc);                                \
+        } else {                                                                                                     \
+            ZP_MFMA(0, 0, FA0, x, H, S, WS, acc[0][0]); ZP_MFMA(1, 0, FA1, x, H, S, WS, acc[1][0]);                  \
+            ZP_MFMA(0, 1, FA0, y, H, S, WS, acc[0][1]); ZP_MFMA(1, 1, FA1, y, H, S, WS, acc[1][1]);                  \
+            MID();                                                                                                   \
+            ZP_MFMA(0, 2, FA0, z, H, S, WS, acc[0][2]); ZP_MFMA(1, 2, FA1, z, H, S, WS, acc[1][2]);                  \
+            ZP_MFMA(0, 3, FA0, w, H, S, WS, acc[0][3]); ZP_MFMA(1, 3, FA1, w, H, S, WS, acc[1][3]);                  \
+        }                                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                                               \
         END();                                                                                                       \
     } while (0)
@@ -320,17 +316,17 @@ __global__ __launch_bounds__(TM, 2) void zpconv_mfma_kernel(
         }                                                                                                            \
         prep_rows((PAR) ? g1 : g0, (PAR) ^ 1);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        ZP_STEP(0, PAR, fa00, fa01, WS, [&] { issue(0, nbuf); issue(1, nbuf); }, [&] { issue(2, nbuf); issue(3, nbuf); }); \
+        ZP_STEP(0, PAR, fa00, fa01, WS, [&] { issue(0, nbuf); issue(1, nbuf); }, [&] { issue(2, nbuf); issue(3, nbuf); }, ((PAR) == 0 && blk_row == 0)); \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         fa00 = fbuf[2 * (CB * PITCH / 4)]; fa01 = fbuf[2 * (CB * PITCH / 4) + 32 * PITCH / 4];                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        ZP_STEP(1, PAR, fa10, fa11, WS, [&] { issue(4, nbuf); issue(5, nbuf); }, [&] { issue(6, nbuf); issue(7, nbuf); }); \
+        ZP_STEP(1, PAR, fa10, fa11, WS, [&] { issue(4, nbuf); issue(5, nbuf); }, [&] { issue(6, nbuf); issue(7, nbuf); }, false); \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         fa10 = fbuf[3 * (CB * PITCH / 4)]; fa11 = fbuf[3 * (CB * PITCH / 4) + 32 * PITCH / 4];                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        ZP_STEP(2, PAR, fa00, fa01, WS, nothing, nothing);                                                           \
+        ZP_STEP(2, PAR, fa00, fa01, WS, nothing, nothing, false);                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        ZP_STEP(3, PAR, fa10, fa11, WS, nothing, nothing);                                                           \
+        ZP_STEP(3, PAR, fa10, fa11, WS, nothing, nothing, false);                                                    \
         dma_wait();                                                                                                  \
         if ((PAR) == 1) {                                                                                            \
             if (++blk_row == spr) {                       /* block-uniform */                                        \
@@ -360,6 +356,7 @@ __global__ __launch_bounds__(TM, 2) void zpconv_mfma_kernel(
     }
 #undef ZP_STAGE
 #undef ZP_STEP
+#undef ZP_MFMA
 }
 
 }  // namespace
