@@ -153,10 +153,6 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     const float4 *fa_lane = reinterpret_cast<const float4 *>(s_f + (size_t)(lh * CB + lk) * PITCH + 4 * ((wave_u + lk) & 7));
 
     f32x16 acc[APW];
-#pragma unroll
-    for (int ai = 0; ai < APW; ++ai)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
 
     // ---- DMA: thread -> NSTD 16-byte pieces of a chunk's LDS image ---------------------------------
     // A DMA instruction writes its 64 lanes' pieces to consecutive LDS addresses, so the image is
@@ -227,7 +223,9 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         bk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (2 * s + lh), bases));
     };
     auto nothing = [] {};
-    auto step = [&](const float4 g, float bk, const float4 fv, auto mid, auto end) {
+    // first (block-uniform): the k-step that opens a row starts from the constant C = 0 -- the accumulators are never
+    // zeroed by vector instructions (64 per row and wave, i.e. matrix time)
+    auto step = [&](const float4 g, float bk, const float4 fv, auto mid, auto end, bool first = false) {
         const float fa[APW] = {fv.x, fv.y, fv.z, fv.w};
         f32x2 wv[APW / 2];
 #pragma unroll
@@ -239,13 +237,24 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         // unguarded: a wave whose last anchors fall off the group repeats its last one into
         // accumulators the epilogue never stores
         __builtin_amdgcn_s_setprio(3);                      // a wave with MFMAs ready goes first (-2.5 % on one box, A/B)
+        if (first) {
+            const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ai = 0; ai < APW / 2; ++ai)
-            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
-        mid();
+            for (int ai = 0; ai < APW / 2; ++ai)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], zc, 0, 0, 0);
+            mid();
 #pragma unroll
-        for (int ai = APW / 2; ai < APW; ++ai)
-            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
+            for (int ai = APW / 2; ai < APW; ++ai)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], zc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ai = 0; ai < APW / 2; ++ai)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
+            mid();
+#pragma unroll
+            for (int ai = APW / 2; ai < APW; ++ai)
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ai], wv[ai >> 1][ai & 1], acc[ai], 0, 0, 0);
+        }
         if (wave_u >= NWV / 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
         end();
     };
@@ -321,10 +330,6 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
             }
             }
         }
-#pragma unroll
-        for (int ai = 0; ai < APW; ++ai)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
     };
 
     // the hardware favours the older waves of a SIMD; the younger half would otherwise reach every chunk
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
             prep_rows(g1);
             issue_idx((ch + 2) * NBK, g2);
             __builtin_amdgcn_sched_barrier(0);
-            step(ga, ba, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); });
+            step(ga, ba, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); }, ch_row == 0);
             __builtin_amdgcn_sched_barrier(0);
             gather(fbuf, g0, bases, 2, fa0, ga, ba);
             __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +374,13 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
             __syncthreads();
             const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
         }
-        if (nchunk == 0) store_row(r_begin);              // unreferenced row: zeros
+        if (nchunk == 0) {                                // unreferenced row: zeros
+#pragma unroll
+            for (int ai = 0; ai < APW; ++ai)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
+            store_row(r_begin);
+        }
     } else {
         for (int ch = 0; ch < nchunk; ++ch) {
             prep_rows(g1);
