@@ -747,3 +747,27 @@ def test_three_block_backbone_end_to_end_vs_oracle(dev, vg):
     gW = torch.autograd.grad(outs[-1], [convs[0].basic_conv.W, convs[1].basic_conv.W], g_out.to(dev))
     for got, want in zip(gW, gW_ref):
         assert rel_err(got.cpu().numpy(), want.numpy()) < 2e-4
+
+
+@pytest.mark.gpu
+def test_inter_zpconv_matrix_path_edges(dev):
+    """csrc/zpconv_mfma.hip / zpconv_bwd.hip at the edges of their shape range: a single point, fewer points than a
+    run of 8, a channel count that is not a multiple of 64, every neighbour the same support point (one inverse list
+    holding every entry), and an empty batch."""
+    import vgtk.cuda.zpconv as Z
+    rng = np.random.default_rng(11)
+    for (b, p, q, a, k, ann, c) in ((1, 1, 5, 60, 24, 64, 64), (2, 5, 9, 60, 24, 16, 80), (1, 11, 3, 28, 24, 32, 16)):
+        idx = np.broadcast_to(rng.integers(0, q, (b, p, 1, 1, ann)), (b, p, a, k, ann)).astype(np.int32).copy()
+        if p == 5:
+            idx[:] = 2                                          # all entries reference support point 2
+        w = rng.random((b, p, a, k, ann)).astype(np.float32)
+        feats = rng.standard_normal((b, c, q, a)).astype(np.float32)
+        out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
+        ref = native.inter_zpconv_forward(idx, w, feats)
+        assert rel_err(out, ref) < 2e-6, (b, p, q, a, k, ann, c)
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        got = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q).cpu().numpy()
+        assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 1e-5, (b, p, q, a, k, ann, c)
+    e = Z.inter_zpconv_forward(torch.zeros(0, 4, 60, 24, 64, dtype=torch.int32, device=dev), torch.zeros(0, 4, 60, 24, 64, device=dev),
+                               torch.zeros(0, 16, 4, 60, device=dev))
+    assert tuple(e.shape) == (0, 16, 24, 4, 60)
