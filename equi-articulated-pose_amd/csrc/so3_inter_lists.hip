@@ -35,6 +35,7 @@
 //   * Row end: accumulators straight to global (16-byte stores, no LDS transposition, no barrier);
 //     in the forward a workgroup streams through 8 consecutive rows without draining its pipeline.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -148,6 +149,13 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
         kzp[ai >> 1][ai & 1] = 2.f * inv_sigma * z;
         kcp[ai >> 1][ai & 1] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
     }
+    // Kernel points rotated by the anchors all have the norm of the unrotated point, so -|kappa|^2/s is normally the same
+    // for the wave's four anchors (to rounding): it then joins the per-entry term with ONE plain add per k-step instead
+    // of two packed ones (a packed instruction costs the matrix pipe twice a plain one, tools/microbench/mfma_riders.hip).
+    // Arbitrary rk tables (norms that differ) keep the general form; the choice is wave-uniform.
+    const float kcl = kcp[0][0];
+    const bool kc_uniform = __all(fabsf(kcp[0][1] - kcl) <= 1e-6f * fabsf(kcl) && fabsf(kcp[1][0] - kcl) <= 1e-6f * fabsf(kcl) &&
+                                  fabsf(kcp[1][1] - kcl) <= 1e-6f * fabsf(kcl)) != 0;
     // operand read: the wave's four anchors are ONE 16-byte piece (piece wave_u) of channel row lk, stored at slot
     // (piece + row) mod 8 so that the 32 channel lanes of a read spread over the banks
     const float4 *fa_lane = reinterpret_cast<const float4 *>(s_f + (size_t)(lh * CB + lk) * PITCH + 4 * ((wave_u + lk) & 7));
@@ -225,12 +233,13 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     auto nothing = [] {};
     // first (block-uniform): the k-step that opens a row starts from the constant C = 0 -- the accumulators are never
     // zeroed by vector instructions (64 per row and wave, i.e. matrix time)
-    auto step = [&](const float4 g, float bk, const float4 fv, auto mid, auto end, bool first = false) {
+    auto step = [&](auto kcu, const float4 g, float bk, const float4 fv, auto mid, auto end, bool first = false) {
         const float fa[APW] = {fv.x, fv.y, fv.z, fv.w};
         f32x2 wv[APW / 2];
+        const float bkc = bk + kcl;
 #pragma unroll
         for (int j = 0; j < APW / 2; ++j) {
-            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], kcp[j] + (f32x2){bk, bk});
+            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], decltype(kcu)::value ? (f32x2){bkc, bkc} : kcp[j] + (f32x2){bk, bk});
             x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
         }
@@ -340,47 +349,48 @@ __global__ __launch_bounds__(TM, 4) void so3_group_lists_kernel(
     // two loops, one per kind of wave (a wave without anchors only feeds the DMA): the accumulators of the working
     // waves then never meet a control-flow join, which the register allocator answered with a second copy of them
     if (active) {
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int buf = ch & 1, nb = buf ^ 1;
-            const float4 *fbuf = fa_lane + buf * (NBK * CB * PITCH / 4);
-            // Operands run two k-steps ahead of the MFMAs; the next chunk's rows are requested one
-            // wave-instruction per step, from the middle of the step's MFMAs.  Past the end of the
-            // list the ring repeats the last entry (a harmless reload of the idle buffer).
-            float4 fa0, fa1, ga, gb;
-            float ba, bb;
-            const int bases = chunk_bases(ch, g0);
-            gather(fbuf, g0, bases, 0, fa0, ga, ba);
-            gather(fbuf, g0, bases, 1, fa1, gb, bb);
-            prep_rows(g1);
-            issue_idx((ch + 2) * NBK, g2);
-            __builtin_amdgcn_sched_barrier(0);
-            step(ga, ba, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); }, ch_row == 0);
-            __builtin_amdgcn_sched_barrier(0);
-            gather(fbuf, g0, bases, 2, fa0, ga, ba);
-            __builtin_amdgcn_sched_barrier(0);
-            step(gb, bb, fa1, [&] { issue(2, nb); }, [&] { issue(3, nb); });
-            __builtin_amdgcn_sched_barrier(0);
-            gather(fbuf, g0, bases, 3, fa1, gb, bb);
-            __builtin_amdgcn_sched_barrier(0);
-            step(ga, ba, fa0, nothing, nothing);
-            __builtin_amdgcn_sched_barrier(0);
-            step(gb, bb, fa1, nothing, nothing);
-            dma_wait();
-            if (++ch_row == nchunk_row) {                 // block-uniform
-                store_row(row);
-                ch_row = 0;
-                ++row;
-            }
-            __syncthreads();
-            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
-        }
-        if (nchunk == 0) {                                // unreferenced row: zeros
-#pragma unroll
-            for (int ai = 0; ai < APW; ++ai)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;
-            store_row(r_begin);
-        }
+        // (the whole loop, row ends included, once per form of the weight evaluation -- a macro: behind a generic lambda the
+        // accumulators of one instantiation went to scratch; each copy is self-contained, so they meet no control-flow join)
+#define EAP_LISTS_LOOP(kcu)                                                            \
+        for (int ch = 0; ch < nchunk; ++ch) {                                                                         \
+            const int buf = ch & 1, nb = buf ^ 1;                                                                     \
+            const float4 *fbuf = fa_lane + buf * (NBK * CB * PITCH / 4);                                              \
+            float4 fa0, fa1, ga, gb;                                                                                  \
+            float ba, bb;                                                                                             \
+            const int bases = chunk_bases(ch, g0);                                                                    \
+            gather(fbuf, g0, bases, 0, fa0, ga, ba);                                                                  \
+            gather(fbuf, g0, bases, 1, fa1, gb, bb);                                                                  \
+            prep_rows(g1);                                                                                            \
+            issue_idx((ch + 2) * NBK, g2);                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, ga, ba, fa0, [&] { issue(0, nb); }, [&] { issue(1, nb); }, ch_row == 0);                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            gather(fbuf, g0, bases, 2, fa0, ga, ba);                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, gb, bb, fa1, [&] { issue(2, nb); }, [&] { issue(3, nb); });                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            gather(fbuf, g0, bases, 3, fa1, gb, bb);                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, ga, ba, fa0, nothing, nothing);                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, gb, bb, fa1, nothing, nothing);                                                                 \
+            dma_wait();                                                                                               \
+            if (++ch_row == nchunk_row) {                                                                             \
+                store_row(row);                                                                                       \
+                ch_row = 0;                                                                                           \
+                ++row;                                                                                                \
+            }                                                                                                         \
+            __syncthreads();                                                                                          \
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;                                                             \
+        }                                                                                                             \
+        if (nchunk == 0) {                                                                                            \
+            _Pragma("unroll") for (int ai = 0; ai < APW; ++ai)                                                        \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[ai][r] = 0.f;                                      \
+            store_row(r_begin);                                                                                       \
+        }                                                                                                             \
+
+        if (kc_uniform) { EAP_LISTS_LOOP(std::true_type{}); } else { EAP_LISTS_LOOP(std::false_type{}); }
+#undef EAP_LISTS_LOOP
     } else {
         for (int ch = 0; ch < nchunk; ++ch) {
             prep_rows(g1);
