@@ -364,12 +364,15 @@ int launch_shape(const DmaArgs &g, int zcount, hipStream_t s) {
 
 int launch(bool akm, bool bkn, const DmaArgs &g, int zcount, hipStream_t s) {
     if (zcount > 65535) return eap::bad_arg("gemm_dma_f32: batch * splits exceeds 65535");
+#ifdef EAP_ABLATION
+    // Timing ablations (WRONG RESULTS), only in a library built with `make ABLATION=1`: EAP_GEMM_DEBUG=1,2
+    // (tools/gemm_only.py, profiles/r02_gemm_ablation.txt).  A production build never reads the variable.
     if (!akm && !bkn && g.M > 128 && g.N > 128) {
-        // EAP_GEMM_DEBUG=1,2: ablation variants for timing (tools/gemm_only.py, profiles/r02_gemm_ablation.txt)
         static const int dbg = getenv("EAP_GEMM_DEBUG") ? atoi(getenv("EAP_GEMM_DEBUG")) : 0;
         if (dbg == 1) return launch_debug<1>(g, zcount, s);
         if (dbg == 2) return launch_debug<2>(g, zcount, s);
     }
+#endif
     if (akm) return bkn ? launch_shape<true, true>(g, zcount, s) : launch_shape<true, false>(g, zcount, s);
     return bkn ? launch_shape<false, true>(g, zcount, s) : launch_shape<false, false>(g, zcount, s);
 }

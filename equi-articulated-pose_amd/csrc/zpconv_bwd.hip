@@ -197,12 +197,35 @@ bool inter_zpconv_bwd_matrix_supported(int np, int nq, int na, int ks, int nn, i
 }
 }  // namespace eap
 
-// bytes: flags | idx0 [b,np,ann] | entry ids float4 [b,np,ann] | counts, rows, off, cnt [b,nq] | n_rows [b] | ent_p [b,np*ann] |
-//        ent_e float4 [b,np*ann] | T float [b,np,na,ann,c]
+// Workspace layout, shared by the size query and the launcher: every chunk starts on a 256-byte boundary.
+//   flags [b] | idx0 [b,np,ann] | entry ids float4 [b,np,ann] | counts, rows, off, cnt [b,nq] | n_rows [b] | ent_p [b,np*ann] |
+//   ent_e float4 [b,np*ann] | T float [b,np,na,ann,c]
+namespace {
+struct BwdWorkspace {
+    int64_t flag, idx0, eid, counts, rows, off, cnt, n_rows, ent_p, ent_e, T, total;
+    BwdWorkspace(int b, int np, int nq, int na, int ann, int c) {
+        const int64_t ent = (int64_t)b * np * ann, fl = 64 * (((int64_t)b + 63) / 64);
+        int64_t at = 0;
+        auto take = [&](int64_t bytes) { const int64_t r = at; at += (bytes + 255) / 256 * 256; return r; };
+        flag = take(4 * fl);
+        idx0 = take(4 * ent);
+        eid = take(16 * ent);
+        counts = take(4ll * b * nq);
+        rows = take(4ll * b * nq);
+        off = take(4ll * b * nq);
+        cnt = take(4ll * b * nq);
+        n_rows = take(4 * fl);
+        ent_p = take(4 * ent);
+        ent_e = take(16 * ent);
+        T = take(4 * ent * na * c);
+        total = at;
+    }
+};
+}  // namespace
+
 extern "C" int64_t eap_inter_zpconv_bwd_workspace(int b, int np, int nq, int na, int ann, int c) {
-    const int64_t ent = (int64_t)b * np * ann;
-    return 256 + 4ll * 64 * ((b + 63) / 64) + 4 * ent + 16 * ent + 4 * 4ll * b * nq + 256 + 4ll * 64 * ((b + 63) / 64) + 4 * ent + 256 +
-           16 * ent + 4 * ent * na * c;
+    if (b <= 0 || np <= 0 || nq < 0 || na <= 0 || ann <= 0 || c <= 0) return 256;
+    return BwdWorkspace(b, np, nq, na, ann, c).total;
 }
 
 extern "C" int eap_inter_zpconv_bwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx,
@@ -215,21 +238,19 @@ extern "C" int eap_inter_zpconv_bwd_ws_f32(int b, int np, int nq, int na, int ks
                         ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(gfeats) |
                           reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
     if (!matrix) return eap_inter_zpconv_bwd_f32(b, np, nq, na, ks, ann, c, idx, w, grad, gfeats, stream);
-    const int64_t ent = (int64_t)b * np * ann;
-    const int fl = 64 * ((b + 63) / 64);
+    const BwdWorkspace L(b, np, nq, na, ann, c);
     char *wsb = reinterpret_cast<char *>(workspace);
-    auto take = [&](int64_t bytes) { char *r = wsb; wsb += (bytes + 255) / 256 * 256; return r; };
-    int32_t *flag = reinterpret_cast<int32_t *>(take(4ll * fl));
-    int32_t *idx0 = reinterpret_cast<int32_t *>(take(4 * ent));
-    float *eid = reinterpret_cast<float *>(take(16 * ent));
-    int32_t *counts = reinterpret_cast<int32_t *>(take(4ll * b * nq));
-    int32_t *rows = reinterpret_cast<int32_t *>(take(4ll * b * nq));
-    int32_t *off = reinterpret_cast<int32_t *>(take(4ll * b * nq));
-    int32_t *cnt = reinterpret_cast<int32_t *>(take(4ll * b * nq));
-    int32_t *n_rows = reinterpret_cast<int32_t *>(take(4ll * fl));
-    int32_t *ent_p = reinterpret_cast<int32_t *>(take(4 * ent));
-    float *ent_e = reinterpret_cast<float *>(take(16 * ent));
-    float *T = reinterpret_cast<float *>(take(4 * ent * na * c));
+    int32_t *flag = reinterpret_cast<int32_t *>(wsb + L.flag);
+    int32_t *idx0 = reinterpret_cast<int32_t *>(wsb + L.idx0);
+    float *eid = reinterpret_cast<float *>(wsb + L.eid);
+    int32_t *counts = reinterpret_cast<int32_t *>(wsb + L.counts);
+    int32_t *rows = reinterpret_cast<int32_t *>(wsb + L.rows);
+    int32_t *off = reinterpret_cast<int32_t *>(wsb + L.off);
+    int32_t *cnt = reinterpret_cast<int32_t *>(wsb + L.cnt);
+    int32_t *n_rows = reinterpret_cast<int32_t *>(wsb + L.n_rows);
+    int32_t *ent_p = reinterpret_cast<int32_t *>(wsb + L.ent_p);
+    float *ent_e = reinterpret_cast<float *>(wsb + L.ent_e);
+    float *T = reinterpret_cast<float *>(wsb + L.T);
 
     int e = eap::hip_fail(hipMemsetAsync(flag, 0, sizeof(int32_t) * b, s), "inter_zpconv_backward flags");
     if (e) return e;

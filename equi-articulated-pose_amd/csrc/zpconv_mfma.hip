@@ -388,7 +388,11 @@ int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, 
     if (blocks >= (1ll << 31)) return eap::bad_arg("inter_zpconv_forward (matrix path): too many workgroups");
     // EAP_ZP_DEBUG (timing ablations only: wrong results): 1 = no output stores, 2 = every weight load hits the same
     // lines, 4 = no feature DMA
+#ifdef EAP_ABLATION      // only in a library built with `make ABLATION=1`; a production build never reads the variable
     static const int dbg = getenv("EAP_ZP_DEBUG") ? atoi(getenv("EAP_ZP_DEBUG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     hipLaunchKernelGGL(zpconv_mfma_kernel, dim3((unsigned)blocks), dim3(TM), shmem, s, c, nq, na, ks, np, nn, AG, gsz, ny, b, feats, idx0, w,
                        skip, out, dbg);
     return eap::check_launch("inter_zpconv_forward (matrix path)");

@@ -4,8 +4,10 @@ import torch
 from .. import _hip
 
 
-# upper bound of the backward's scratch buffer (the batch is processed in slices that fit)
-BWD_WORKSPACE_BYTES = 16 << 30
+# upper bound of the backward's scratch buffer (the batch is processed in slices that fit).  The reference op needs no
+# scratch at all, so the bound is modest (two 4096-point clouds at 64 channels) and a cloud that does not fit (or an allocation that fails) takes the
+# scratch-free scatter kernel instead of raising
+BWD_WORKSPACE_BYTES = 8 << 30
 
 
 def _check(idx, w, x):
@@ -44,9 +46,18 @@ def inter_zpconv_backward(idx, w, grad, npoint):
     if grad.dtype == torch.float32 and b > 0:
         # atomics-free path (csrc/zpconv_bwd.hip): scratch for the per-(point, neighbour) products, a few clouds at a time
         per_cloud = int(_hip.lib.eap_inter_zpconv_bwd_workspace(1, np_, int(npoint), na, ann, c))
-        step = max(1, min(b, BWD_WORKSPACE_BYTES // max(per_cloud, 1)))
-        ws = torch.empty((int(_hip.lib.eap_inter_zpconv_bwd_workspace(step, np_, int(npoint), na, ann, c)) + 3) // 4,
-                         dtype=torch.int32, device=grad.device)
+        step = min(b, BWD_WORKSPACE_BYTES // max(per_cloud, 1))
+        ws = None
+        if step >= 1:
+            try:
+                ws = torch.empty((int(_hip.lib.eap_inter_zpconv_bwd_workspace(step, np_, int(npoint), na, ann, c)) + 3) // 4,
+                                 dtype=torch.int32, device=grad.device)
+            except torch.cuda.OutOfMemoryError:
+                ws = None
+        if ws is None:
+            _hip.call('eap_inter_zpconv_bwd_f32', out, b, np_, int(npoint), na, ks, ann, c,
+                      _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
+            return out
         for b0 in range(0, b, step):
             nb = min(step, b - b0)
             _hip.call('eap_inter_zpconv_bwd_ws_f32', out, nb, np_, int(npoint), na, ks, ann, c, _hip._ptr(idx[b0:b0 + nb]),

@@ -655,7 +655,7 @@ def inter_so3poseconv_grouping_strided(xyz, pose, feats, stride, n_neighbor, anc
         sample_idx, new_xyz, sampled_pose = _strided_centres(xyz, pose, stride, lazy_sample)
         _, w, new_feats = _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius * radius_expansion, sigma,
                                        permute_modes != 0, q_xyz=new_xyz, q_pose=sampled_pose)
-        return None, w, new_xyz, new_feats, sample_idx, sampled_pose
+        return None, w, new_xyz, new_feats, sample_idx.long(), sampled_pose          # spconv/functional.py:L476 `idx.long()`
     _, w, new_feats = _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma,
                                    permute_modes != 0)
     return inter_idx, w, xyz, new_feats, None, pose

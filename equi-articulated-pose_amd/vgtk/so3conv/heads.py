@@ -51,19 +51,25 @@ class _AnchorAttnPool(torch.autograd.Function):
         b, c, n, na = x.shape
         dx = torch.empty_like(x)
         dl = torch.empty_like(logits)
+        g = g.contiguous()            # bound to a local: the buffer must outlive the enqueue
         _hip.call('eap_anchor_attn_pool_bwd_f32', x, b, c, n, na, _F32(ctx.temperature), _hip._ptr(x), _hip._ptr(logits),
-                  _hip._ptr(g.contiguous()), _hip._ptr(dx), _hip._ptr(dl))
+                  _hip._ptr(g), _hip._ptr(dx), _hip._ptr(dl))
         return dx, dl, None
 
 
 def anchor_attention_pool(x, logits, temperature):
     """x [b,c,n,a], logits [b,n,a] (or [b,1,n,a]) -> pooled [b,c,n], confidence [b,n,a].
-    The confidence is returned as data (the reference's callers use it for selection, not for a loss)."""
+    The fused pass hands the confidence out as data; when the logits carry a gradient the returned confidence is the
+    (small, [b,n,a]) torch softmax instead, so a caller that feeds it to a loss (the reference's `orbit_attn == 1`
+    concatenation, ...pn_38_multi_stage.py:L612-613) gets the gradient the reference's softmax gives."""
     if x.dtype != torch.float32 or not x.is_cuda:
         raise RuntimeError('anchor_attention_pool: float32 device tensors only')
     if logits.dim() == 4:
         logits = logits.squeeze(1)
-    return _AnchorAttnPool.apply(x, logits, float(temperature))
+    out, conf = _AnchorAttnPool.apply(x, logits, float(temperature))
+    if logits.requires_grad and torch.is_grad_enabled():
+        conf = torch.softmax(logits * float(temperature), dim=-1)
+    return out, conf
 
 
 class InvPPOutBlockOurs(nn.Module):
@@ -118,6 +124,24 @@ def orbit_selection(minn_dist_ori_to_recon, minn_dist_recon_to_ori, slot_single_
     return torch.min(d, dim=-1)
 
 
+def orbit_slot_distances(minn_dist_ori_to_recon_all_pts, minn_dist_ori_to_recon, hard_one_hot_labels, attn_ori):
+    """Point-to-reconstruction distances [B,S,A,N] (the first and last outputs of
+    extensions.chamfer_dist.orbit_reconstruction_distances) -> per-(slot, orbit) scalars [B,S,A], weighted over the
+    points as ...pn_38_multi_stage.py:L1363-1380 does:
+      hard    weights = the slot's 0/1 membership                 (minn_dist_ori_to_recon_hard)
+      soft    weights = membership * attention                    (minn_dist_ori_to_recon, what orbit selection reads)
+      all     weights = attention, on the unmasked distances      (minn_dist_ori_to_recon_all_pts)
+    each a weighted sum over N divided by max(sum of weights, 1e-8).  hard_one_hot_labels [B,N,S], attn_ori [B,S,N]."""
+    hard = hard_one_hot_labels.transpose(1, 2).to(minn_dist_ori_to_recon.dtype)         # [B,S,N]
+
+    def wmean(d, w):
+        w = w.unsqueeze(2)                                                              # [B,S,1,N]
+        return (d * w).sum(-1) / w.sum(-1).clamp(min=1e-8)
+
+    return (wmean(minn_dist_ori_to_recon, hard), wmean(minn_dist_ori_to_recon, hard * attn_ori),
+            wmean(minn_dist_ori_to_recon_all_pts, attn_ori))
+
+
 class _SlotMaskedMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask):
@@ -136,7 +160,8 @@ class _SlotMaskedMean(torch.autograd.Function):
         mask, inv_den = ctx.saved_tensors
         b, c, n, na, ns = ctx.dims
         dx = torch.empty(b, c, n, na, dtype=torch.float32, device=g.device)
-        _hip.call('eap_slot_masked_mean_bwd_f32', g, b, ns, c, n, na, _hip._ptr(g.contiguous()), _hip._ptr(mask), _hip._ptr(inv_den), _hip._ptr(dx))
+        g = g.contiguous()            # bound to a local: the buffer must outlive the enqueue
+        _hip.call('eap_slot_masked_mean_bwd_f32', g, b, ns, c, n, na, _hip._ptr(g), _hip._ptr(mask), _hip._ptr(inv_den), _hip._ptr(dx))
         return dx, None
 
 
@@ -147,6 +172,9 @@ def slot_masked_mean(x, mask):
     slots (at most 8) in one pass over x."""
     if x.dtype != torch.float32 or not x.is_cuda:
         raise RuntimeError('slot_masked_mean: float32 device tensors only')
+    if mask.requires_grad:
+        raise RuntimeError('slot_masked_mean: the slot weights are treated as data (no gradient reaches them); detach the mask or '
+                           'use torch ops for a differentiable soft mask')
     return _SlotMaskedMean.apply(x, mask.to(torch.float32))
 
 
@@ -162,6 +190,52 @@ def rotation_from_angle_axis(angle, axis):
     return R.view(*angle.shape, 3, 3)
 
 
+def rotation_axes(rots):
+    """Unit rotation axis of every matrix of rots [..., 3, 3] -> [..., 3], batched; the three regimes of the reference's
+    per-matrix Python loop (model_utils.py:L954-997): angle 0 -> e_x; angle pi -> from the symmetric part
+    (R + R^T entries over 4 times the first axis component that is non-zero); otherwise the skew part over 2 sin(angle)."""
+    R = rots.reshape(-1, 3, 3)
+    t = ((R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2] - 1.0) * 0.5).clamp(-1.0, 1.0)
+    sine = torch.sin(torch.acos(t))
+    skew = torch.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], -1)
+    generic = skew / (2.0 * sine).clamp_min(1e-30).unsqueeze(-1)
+    # half-turns: the diagonal gives the squared components
+    ax = torch.sqrt(((R[:, 0, 0] + 1.0) * 0.5).clamp_min(0.0))
+    ay = torch.sqrt(((R[:, 1, 1] + 1.0) * 0.5).clamp_min(0.0))
+    az = torch.sqrt(((R[:, 2, 2] + 1.0) * 0.5).clamp_min(0.0))
+    zero = torch.zeros_like(ax)
+    from_x = torch.stack([ax, (R[:, 0, 1] + R[:, 1, 0]) / (4.0 * ax).clamp_min(1e-30), (R[:, 0, 2] + R[:, 2, 0]) / (4.0 * ax).clamp_min(1e-30)], -1)
+    from_y = torch.stack([zero, ay, (R[:, 1, 2] + R[:, 2, 1]) / (4.0 * ay).clamp_min(1e-30)], -1)
+    from_z = torch.stack([zero, zero, az], -1)
+    half = torch.where((ax > 1e-8).unsqueeze(-1), from_x, torch.where((ay > 1e-8).unsqueeze(-1), from_y, from_z))
+    e_x = torch.tensor([1.0, 0.0, 0.0], dtype=R.dtype, device=R.device).expand_as(generic)
+    out = torch.where(((t - 1.0).abs() < 1e-8).unsqueeze(-1), e_x, torch.where(((t + 1.0).abs() < 1e-8).unsqueeze(-1), half, generic))
+    return out.reshape(*rots.shape[:-2], 3)
+
+
+def compute_rotation_matrix_from_angle(anchors, angles, defined_axis=None):
+    """anchors [na,3,3], angles [n,na,1] (or [n,na]) -> [n,na,3,3]: rotation by `angles` about `defined_axis` ([1,3] /
+    [3] shared, or [n,na,3]) or, by default, about every anchor's own rotation axis.  Same signature and values as
+    the reference's function (SPConvNets/models/model_utils.py:L1000-1043), which keeps the axis-norm-dependent form
+    m_00 = u^2 + (v^2 + w^2) cos: equal to Rodrigues' formula for a unit axis, and followed term by term here so that a
+    predicted axis that is unit only to rounding gives the reference's matrix."""
+    ang = angles.squeeze(-1) if angles.dim() == 3 else angles
+    axes = rotation_axes(anchors) if defined_axis is None else defined_axis
+    if axes.dim() == 1:
+        axes = axes.unsqueeze(0)
+    if axes.dim() == 2:
+        u, v, w = (axes[:, i].unsqueeze(0) for i in range(3))
+    else:
+        u, v, w = axes.unbind(-1)
+    c, s = torch.cos(ang), torch.sin(ang)
+    k = 1.0 - c
+    rows = [u * u + (v * v + w * w) * c, u * v * k - w * s, u * w * k + v * s,
+            u * v * k + w * s, v * v + (u * u + w * w) * c, v * w * k - u * s,
+            u * w * k - v * s, v * w * k + u * s, w * w + (u * u + v * v) * c]
+    rows = [r.expand_as(ang) if r.shape != ang.shape else r for r in rows]
+    return torch.stack(rows, -1).reshape(*ang.shape, 3, 3)
+
+
 def _unary_stack(x, linears, norms):
     """relu(norm_i(conv1x1_i(x))) for every layer of a ModuleList pair (model_utils.py:L478-485): the 1x1 convolution
     is the path's contraction GEMM (csrc/gemm_dma_f32.hip through so3_contract), BatchNorm + ReLU the fused block
@@ -173,6 +247,9 @@ def _unary_stack(x, linears, norms):
             y = y + linear.bias.view(1, -1, 1, 1)
         if norms is not None:
             bn = norms[lid]
+            if (n * a) % 4 != 0:          # the fused epilogue moves 16-byte words; odd row lengths take the torch modules
+                x = F.relu(bn(y))
+                continue
             if bn.training:
                 bn.num_batches_tracked.add_(1)
             x = _BNAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, 0.0, False)

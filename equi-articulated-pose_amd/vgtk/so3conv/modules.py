@@ -140,7 +140,7 @@ class InterSO3PoseConv(nn.Module):
             _, w, feats = L.inter_so3conv_fused(x.xyz, x.pose, x.feats, self.basic_conv.W, self.n_neighbor,
                                                 self.anchors, self.kernels, self.radius, self.sigma,
                                                 self.permute_modes != 0, q_xyz=q_xyz, q_pose=q_pose)
-            return None, w, sample_idx, SphericalPointCloudPose(q_xyz, feats, self.anchors, q_pose)
+            return None, w, sample_idx.long(), SphericalPointCloudPose(q_xyz, feats, self.anchors, q_pose)      # spconv/functional.py:L476
         # stride-1 branch of the reference (functional.py:L1025-1286): the neighbourhood is recomputed
         # on every call and the passed-in inter_idx is handed back unchanged; grouping + contraction
         # run as one autograd node (csrc/so3_inter_*.hip + gemm_dma_f32.hip)

@@ -52,3 +52,20 @@ def test_host_tensors_are_rejected():
     conv = sptk.InterSO3PoseConv(1, 4, 1, 1, 0.1, 0.01, 4)
     with pytest.raises(RuntimeError):
         conv(zptk.SphericalPointCloudPose(torch.zeros(1, 3, 8), torch.ones(1, 1, 8, 60), None, None))
+
+
+def test_zpconv_backward_workspace_covers_every_aligned_chunk():
+    """The scratch size the backward asks for (host-only entry, no GPU) is what its launcher carves: eleven chunks,
+    each rounded up to 256 bytes (round-2 advisor finding: the old closed form fell short by up to ~2 KB for small or
+    odd shapes, e.g. b=1, np=1, ann=4, nq=1)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, 'equi-articulated-pose_amd', 'libeap_hip.so'))
+    lib.eap_inter_zpconv_bwd_workspace.restype = ctypes.c_int64
+
+    def up(x):
+        return (x + 255) // 256 * 256
+
+    for (b, np_, nq, na, ann, c) in ((1, 1, 1, 4, 4, 16), (1, 11, 3, 28, 32, 16), (3, 5, 7, 60, 12, 16), (2, 4096, 4096, 60, 64, 64),
+                                     (65, 3, 9, 60, 4, 32)):
+        ent, fl = b * np_ * ann, 64 * ((b + 63) // 64)
+        need = (up(4 * fl) + up(4 * ent) + up(16 * ent) + 4 * up(4 * b * nq) + up(4 * fl) + up(4 * ent) + up(16 * ent) + up(4 * ent * na * c))
+        assert lib.eap_inter_zpconv_bwd_workspace(b, np_, nq, na, ann, c) == need, (b, np_, nq, na, ann, c)

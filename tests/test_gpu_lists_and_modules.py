@@ -471,3 +471,89 @@ def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling):
         for (k, v), (_, w) in zip(ref_head.state_dict().items(), fast_head.state_dict().items()):
             if 'running' in k:
                 assert rel_err(w.cpu().numpy(), v.cpu().numpy()) < 1e-5, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8(f) rows 2 and 4 against fixtures produced by RUNNING THE REFERENCE (tests/golden/make_golden_extra.py)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,lazy', [('lazy', True), ('fps', False)])
+def test_strided_pose_conv_matches_reference_golden(dev, golden, tag, lazy):
+    """InterSO3PoseConv(stride=2), random per-point poses, anchor permutation on: sample indices / centres / gathered
+    poses exact, materialised kernel weights, outputs, dF, dW against the reference's own forward + autograd."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    g = golden('strided_pose.npz')
+    conv = sptk.InterSO3PoseConv(6, 8, 1, int(g['stride']), float(g['radius']), float(g['sigma']), int(g['nn']), lazy_sample=lazy,
+                                 kanchor=60, permute_modes=1)
+    np.testing.assert_array_equal(conv.anchors.numpy(), g['anchors'])
+    np.testing.assert_array_equal(conv.kernels.numpy(), g['kernels'])
+    with torch.no_grad():
+        conv.basic_conv.W.copy_(T(g[f'{tag}_W']))
+    conv = conv.to(dev)
+    fd = T(g[f'{tag}_feats']).to(dev).requires_grad_(True)
+    inter_idx, w, sample_idx, out = conv(zptk.SphericalPointCloudPose(T(g['xyz']).to(dev), fd, None, T(g[f'{tag}_pose']).to(dev)))
+    assert inter_idx is None
+    assert sample_idx.dtype == torch.int64                                      # spconv/functional.py:L476 `idx.long()`
+    np.testing.assert_array_equal(sample_idx.cpu().numpy(), g[f'{tag}_sample_idx'])
+    np.testing.assert_array_equal(out.xyz.cpu().numpy(), g[f'{tag}_new_xyz'])
+    np.testing.assert_array_equal(out.pose.cpu().numpy(), g[f'{tag}_new_pose'])
+    assert rel_err(w.materialize()[:, :4].cpu().numpy(), g[f'{tag}_inter_w_head']) < 5e-6
+    assert rel_err(out.feats.detach().cpu().numpy(), g[f'{tag}_out']) < 1e-5
+    gF, gW = torch.autograd.grad(out.feats, [fd, conv.basic_conv.W], T(g[f'{tag}_grad_out']).to(dev))
+    assert rel_err(gF.cpu().numpy(), g[f'{tag}_grad_feats']) < 1e-5
+    assert rel_err(gW.cpu().numpy(), g[f'{tag}_grad_W']) < 2e-5
+
+
+@pytest.mark.parametrize('mode', ['attention', 'max', 'mean'])
+def test_invariant_head_matches_reference_golden(dev, golden, mode):
+    """InvPPOutBlockOurs against the reference class (base_so3conv.py:L842-917) run on CPU: outputs in training and
+    eval mode, anchor confidences, running-statistic updates, and for attention pooling every gradient."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    g = golden('inv_head.npz')
+    params = {'dim_in': 24, 'mlp': [16, 12], 'fc': [12], 'k': 12, 'kanchor': 60, 'temperature': 3.0}
+    head = sptk.InvPPOutBlockOurs(params, norm=1, pooling_method=mode)
+    pre = f'{mode}_state_'
+    state = {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+    assert set(state) == set(head.state_dict()), 'state_dict names differ from the reference class'
+    head = head.to(dev)
+    for phase in ('train', 'eval'):
+        head.load_state_dict(state)
+        head.train(phase == 'train')
+        x = T(g['x']).to(dev).requires_grad_(True)
+        res = head(zptk.SphericalPointCloud(None, x, None))
+        y = res[0] if mode == 'attention' else res
+        assert rel_err(y.detach().cpu().numpy(), g[f'{mode}_{phase}_out']) < 5e-6
+        if mode == 'attention':
+            assert rel_err(res[1].cpu().numpy(), g[f'{mode}_{phase}_conf']) < 5e-6
+            names = [n for n, _ in head.named_parameters()]
+            grads = torch.autograd.grad(y, [x] + list(head.parameters()), T(g[f'{mode}_{phase}_grad_out']).to(dev))
+            top = max(float(np.abs(g[f'{mode}_{phase}_grad_{n}']).max()) for n in names)
+            for n, got in zip(['x'] + names, grads):
+                want = g[f'{mode}_{phase}_grad_{n}']
+                # a conv bias in front of a training-mode BatchNorm has an exactly-zero gradient (rounding noise on both sides)
+                scale = max(float(np.abs(want).max()), 1e-2 * top)
+                assert float(np.abs(got.cpu().numpy() - want).max()) < 5e-5 * scale, (phase, n)
+        if phase == 'train':
+            for k, v in head.state_dict().items():
+                if 'running' in k:
+                    assert rel_err(v.cpu().numpy(), g[f'{mode}_after_{k}']) < 1e-5, k
+
+
+@pytest.mark.parametrize('tag,cd,single', [('cd0_multi', 0, 0), ('cd1_single', 1, 1)])
+def test_orbit_selection_matches_reference_statements(dev, golden, tag, cd, single):
+    """The 60-way batched chamfer (extensions.chamfer_dist.orbit_reconstruction_distances) + the point-weighted
+    aggregation (vgtk.so3conv.orbit_slot_distances) + the arg-min (orbit_selection) against the values the reference's
+    own lines ...pn_38_multi_stage.py:L1341-1399 produced on the same inputs (an empty slot included)."""
+    import vgtk.so3conv as sptk
+    from extensions.chamfer_dist import orbit_reconstruction_distances
+    g = golden('orbit.npz')
+    hard, attn = T(g[f'{tag}_hard_one_hot_labels']).to(dev), T(g[f'{tag}_attn_ori']).to(dev)
+    o2r_all, r2o_all, r2o, o2r = orbit_reconstruction_distances(T(g[f'{tag}_transformed_pts']).to(dev), T(g[f'{tag}_ori_pts']).to(dev), hard)
+    d_hard, d_soft, d_all = sptk.orbit_slot_distances(o2r_all, o2r, hard, attn)
+    for got, key in ((r2o_all, 'minn_dist_recon_to_ori_all_pts'), (r2o, 'minn_dist_recon_to_ori'), (d_hard, 'minn_dist_ori_to_recon_hard'),
+                     (d_soft, 'minn_dist_ori_to_recon'), (d_all, 'minn_dist_ori_to_recon_all_pts')):
+        np.testing.assert_allclose(got.cpu().numpy(), g[f'{tag}_{key}'], rtol=2e-5, atol=1e-7, err_msg=key)
+    dist, orbit = sptk.orbit_selection(d_soft, r2o, slot_single_cd=cd, slot_single_mode=single)
+    np.testing.assert_array_equal(orbit.cpu().numpy(), g[f'{tag}_slot_orbits'])
+    np.testing.assert_allclose(dist.cpu().numpy(), g[f'{tag}_slot_dist'], rtol=2e-5)

@@ -756,7 +756,8 @@ def test_inter_zpconv_matrix_path_edges(dev):
     holding every entry), and an empty batch."""
     import vgtk.cuda.zpconv as Z
     rng = np.random.default_rng(11)
-    for (b, p, q, a, k, ann, c) in ((1, 1, 5, 60, 24, 64, 64), (2, 5, 9, 60, 24, 16, 80), (1, 11, 3, 28, 24, 32, 16)):
+    for (b, p, q, a, k, ann, c) in ((1, 1, 5, 60, 24, 64, 64), (2, 5, 9, 60, 24, 16, 80), (1, 11, 3, 28, 24, 32, 16),
+                                  (1, 1, 1, 4, 24, 4, 16), (3, 3, 5, 60, 24, 12, 16)):      # scratch chunks far from 256-byte multiples
         idx = np.broadcast_to(rng.integers(0, q, (b, p, 1, 1, ann)), (b, p, a, k, ann)).astype(np.int32).copy()
         if p == 5:
             idx[:] = 2                                          # all entries reference support point 2
