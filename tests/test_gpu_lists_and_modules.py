@@ -332,7 +332,7 @@ def test_anchor_attention_pool_and_invariant_head(dev):
     oref = (h * cref).sum(-1)
     assert out.shape == (2, 12, 37) and conf.shape == (2, 37, 60)
     assert rel_err(out.detach().cpu().numpy(), oref.detach().cpu().numpy()) < 2e-6
-    assert rel_err(conf.cpu().numpy(), cref.squeeze(1).detach().cpu().numpy()) < 2e-6
+    assert rel_err(conf.detach().cpu().numpy(), cref.squeeze(1).detach().cpu().numpy()) < 2e-6
     g = torch.randn_like(out)
     names = [n for n, _ in head.named_parameters()]
     grads = torch.autograd.grad(out, [x] + list(head.parameters()), g, retain_graph=True)
@@ -525,7 +525,7 @@ def test_invariant_head_matches_reference_golden(dev, golden, mode):
         y = res[0] if mode == 'attention' else res
         assert rel_err(y.detach().cpu().numpy(), g[f'{mode}_{phase}_out']) < 5e-6
         if mode == 'attention':
-            assert rel_err(res[1].cpu().numpy(), g[f'{mode}_{phase}_conf']) < 5e-6
+            assert rel_err(res[1].detach().cpu().numpy(), g[f'{mode}_{phase}_conf']) < 5e-6
             names = [n for n, _ in head.named_parameters()]
             grads = torch.autograd.grad(y, [x] + list(head.parameters()), T(g[f'{mode}_{phase}_grad_out']).to(dev))
             top = max(float(np.abs(g[f'{mode}_{phase}_grad_{n}']).max()) for n in names)

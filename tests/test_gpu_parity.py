@@ -772,3 +772,28 @@ def test_inter_zpconv_matrix_path_edges(dev):
     e = Z.inter_zpconv_forward(torch.zeros(0, 4, 60, 24, 64, dtype=torch.int32, device=dev), torch.zeros(0, 4, 60, 24, 64, device=dev),
                                torch.zeros(0, 16, 4, 60, device=dev))
     assert tuple(e.shape) == (0, 16, 24, 4, 60)
+
+
+@pytest.mark.gpu
+def test_native_known_answers(dev):
+    """The hand-derived known-answer cases of tests/test_oracle_native.py (ball query padding rules and strict radius,
+    gather with repeated indices, furthest-point-sampling tie / skip rules, zpconv with per-(a,k) indices, chamfer
+    first-minimum ties within and across the reference's 512-point tiles) asserted on the HIP kernels themselves."""
+    import chamfer
+    import vgtk.cuda.gathering as GA
+    import vgtk.cuda.grouping as G
+    import vgtk.cuda.zpconv as Z
+    import test_oracle_native as K
+
+    def on_gpu(fn):
+        def run(*args):
+            conv = [T(np.ascontiguousarray(a)).to(dev) if isinstance(a, np.ndarray) else a for a in args]
+            out = fn(*conv)
+            return [o.cpu().numpy() for o in out] if isinstance(out, (list, tuple)) else out.cpu().numpy()
+        return run
+
+    K.known_ball_query(on_gpu(G.ball_query))
+    K.known_gather(on_gpu(GA.gather_points_forward), on_gpu(GA.gather_points_backward))
+    K.known_fps(on_gpu(G.furthest_point_sampling))
+    K.known_zpconv(on_gpu(Z.inter_zpconv_forward), on_gpu(Z.inter_zpconv_backward), on_gpu(Z.intra_zpconv_forward), on_gpu(Z.intra_zpconv_backward))
+    K.known_chamfer(on_gpu(chamfer.forward), on_gpu(chamfer.backward))
