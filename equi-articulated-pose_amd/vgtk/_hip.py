@@ -295,38 +295,3 @@ def so3_intra_conv(feats, W, intra_idx32):
     call('eap_so3_intra_conv_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats), _ptr(intra_idx32), _ptr(out),
          tag={'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)})
     return out
-
-
-def library_contract(W, xt, y):
-    """y[b] = W @ xt[b]^T  with W [o, ck], xt [b, pa, ck] (the transposed intermediate), y [b, o, pa]:
-    the PLAIN fp32 GEMM of the contraction handed to the vendor library through torch.matmul
-    (hipBLASLt / rocBLAS), exactly what the reference's BasicSO3Conv.forward does
-    (so3conv/modules.py:L48-55).  Timed like the C-ABI launches when bench.py asks for it."""
-    b, pa, ck = xt.shape
-    o = W.shape[0]
-    if KERNEL_TIMES is not None:
-        stream = torch.cuda.current_stream(xt.device)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        torch.matmul(W, xt.transpose(1, 2), out=y)
-        e1.record(stream)
-        KERNEL_TIMES.append(('library_gemm_f32', {'flops': 2.0 * o * pa * ck * b, 'shape': ('gemm_nt', o, pa, ck, b)}, e0, e1))
-    else:
-        torch.matmul(W, xt.transpose(1, 2), out=y)
-    return y
-
-
-def library_matmul(a, bmat, out):
-    """torch.matmul(a, bmat, out=out) with the bench's timing hook (plain GEMMs only)."""
-    if KERNEL_TIMES is not None:
-        stream = torch.cuda.current_stream(bmat.device)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        r = torch.matmul(a, bmat, out=out) if out is not None else torch.matmul(a, bmat)
-        e1.record(stream)
-        fl = 2.0 * r.numel() * a.shape[-1]
-        KERNEL_TIMES.append(('library_gemm_f32', {'flops': fl, 'shape': ('matmul',) + tuple(a.shape) + tuple(bmat.shape)}, e0, e1))
-        return r
-    return torch.matmul(a, bmat, out=out) if out is not None else torch.matmul(a, bmat)

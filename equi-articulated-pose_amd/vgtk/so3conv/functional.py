@@ -367,12 +367,41 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
 # Layout of the fused conv's intermediate X (where the kernels allow it, else the reference layout); the contraction
 # is always a hand-written GEMM:
 #   'transposed'  X as the plain [P*A, C*K] matrix, both GEMM operands k-contiguous: csrc/gemm_dma_f32.hip
-#                 (141 TFLOP/s on the deepest layer; hipBLASLt, reachable with EAP_LIBRARY_GEMMS=1 for A/B timing only: 150)
+#                 (141 TFLOP/s on the deepest layer; hipBLASLt on the same operands: 150 -- tools/gemm_only.py times both)
 #   'blocked'     X blocked by anchor quads, contraction = csrc/gemm_f32.hip (eap_gemm_f32_xb)
 #   'reference'   X [C*K, P*A] as the reference's einsum writes it
 X_LAYOUT = os.environ.get('EAP_X_LAYOUT', 'transposed')
-LIBRARY_SMALL_GEMMS = os.environ.get('EAP_LIBRARY_GEMMS', '0') != '0'   # A/B knob: the plain GEMMs through the vendor library instead of the own kernels (never the default)
 BLOCKED_X = True     # test knob: False forces the reference layout
+
+
+# The intermediate X [B, C*K, P*A] of the fused conv (24 GB at C = 128, B = 8) is scratch, not state: the re-associated
+# backward never reads it, so it is produced and consumed X_CHUNK_CLOUDS clouds at a time and never saved.  Only the
+# textbook backward (many referenced rows) needs it for dW = dY X^T; which regime a layer is in is known on the host
+# only when its backward runs, so the layer's previous decision is the hint: after a 'dx' backward the next forward of
+# the same weights keeps X, and a wrong guess costs one re-run of the grouping kernel in the backward.
+X_CHUNK_CLOUDS = int(os.environ.get('EAP_X_CHUNK_CLOUDS', '8'))   # measured: 2 / 4 / 8 clouds per slab = 146.8 / 146.9 / 145.6 ms per step
+_KEEP_X_HINT = {}           # id(W) -> (weakref(W), bool)
+
+
+def _keep_x_hint(W):
+    hit = _KEEP_X_HINT.get(id(W))
+    return bool(hit is not None and hit[0]() is W and hit[1])
+
+
+def _set_keep_x_hint(W, keep):
+    if len(_KEEP_X_HINT) > 1024:
+        _KEEP_X_HINT.clear()
+    _KEEP_X_HINT[id(W)] = (weakref.ref(W), bool(keep))
+
+
+def _contract_into(W, x, y, layout):
+    """y[b,o,pa] = W . x for the intermediate in one of its three layouts."""
+    b, c, ks, p, na = x.shape
+    o = W.shape[0]
+    if layout == 2:                              # Y = W . (X^T)^T, both operands k-contiguous (csrc/gemm_dma_f32.hip)
+        _hip.gemm(0, 1, o, p * na, c * ks, W, c * ks, 0, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b)
+    else:
+        _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
 
 
 class _InterConv(torch.autograd.Function):
@@ -380,9 +409,9 @@ class _InterConv(torch.autograd.Function):
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None):
+    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None):
         feats = feats.contiguous()
-        W = W.contiguous()
+        W = W_param.contiguous()
         ctx.anchors = anchors.detach().contiguous() if anchors is not None else None   # the rotations `mult` was built from
         # X is internal to this Function: where the kernels allow it, it is kept blocked by anchor
         # quads ([b,p,a/4,c,k,4]) -- coalesced row-end stores in the grouping kernel -- and the GEMMs
@@ -390,28 +419,37 @@ class _InterConv(torch.autograd.Function):
         can = BLOCKED_X and X_LAYOUT != 'reference' and _hip.so3_inter_group_fwd_can_block(
             feats.shape[1], feats.shape[2], feats.shape[3], rk.shape[1], mult is not None, nonident is not None)
         layout = 0 if not can else (2 if X_LAYOUT == 'transposed' else 1)
-        x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=layout)   # [b,c,k,p,a] (nominal shape)
-        b, c, ks, p, na = x.shape
-        o = W.shape[0]
-        y = torch.empty(b, o, p, na, dtype=torch.float32, device=x.device)
-        if layout == 2 and LIBRARY_SMALL_GEMMS:      # A/B knob only: the same contraction through hipBLASLt
-            _hip.library_contract(W, x.view(b, p * na, c * ks), y.view(b, o, p * na))
-        elif layout == 2:                            # Y = W . (X^T)^T, both operands k-contiguous (csrc/gemm_dma_f32.hip)
-            _hip.gemm(0, 1, o, p * na, c * ks, W, c * ks, 0, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b)
+        b, c, n, na = feats.shape
+        p, ks, o = idx.shape[1], rk.shape[1], W.shape[0]
+        needs_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)
+        keep = needs_grad and (not lists_ok or _keep_x_hint(W_param))
+        y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
+        if keep:
+            x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=layout)   # [b,c,k,p,a] (nominal shape)
+            _contract_into(W, x, y.view(b, o, p * na), layout)
         else:
-            _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
+            x = None
+            step = max(1, X_CHUNK_CLOUDS)
+            for b0 in range(0, b, step):
+                b1 = min(b, b0 + step)
+                xs = _hip.so3_inter_group_fwd(feats[b0:b1], idx[b0:b1], gx[b0:b1], rk, mult, sigma,
+                                              None if nonident is None else nonident[b0:b1], blocked=layout)
+                _contract_into(W, xs, y[b0:b1].view(b1 - b0, o, p * na), layout)
+                del xs
         ctx.layout = layout
+        ctx.kept_x = x is not None
+        ctx.W_param = weakref.ref(W_param)
         # feats: needed by the re-associated weight gradient (saved, not copied: autograd's version check
         # then catches an in-place update of the previous block's output)
-        ctx.save_for_backward(W, x, idx, gx, rk, mult if mult is not None else torch.empty(0),
+        ctx.save_for_backward(W, x if x is not None else torch.empty(0), idx, gx, rk, mult if mult is not None else torch.empty(0),
                               nonident if nonident is not None else torch.empty(0), feats)
         ctx.has_mult = mult is not None
         ctx.has_flag = nonident is not None
         ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
         # inverse neighbour lists, first half (device only; the host-side numbers arrive asynchronously)
         ctx.head = None
-        if BACKWARD_MODE != 'dx' and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and \
-                _inv_lists_supported(idx, feats.shape[2], na, ks):
+        if lists_ok and needs_grad:
             ctx.head = _ListHead(idx, feats.shape[2], nonident)
         return y
 
@@ -421,10 +459,10 @@ class _InterConv(torch.autograd.Function):
         mult = mult if ctx.has_mult else None
         nonident = nonident if ctx.has_flag else None
         gy = gy.contiguous()
-        b, c, ks, p, na = x.shape
+        b, c, n, na = feats.shape
+        p, ks = idx.shape[1], rk.shape[1]
         o, ck, pa = W.shape[0], c * ks, p * na
         gW = gF = None
-        n = ctx.n
         # Strategy: when few support rows are referenced (the reference's first-nsample-in-index-
         # order ball query with large radii), BOTH gradients follow from
         #     Z[o,k,q,a'] = sum_{(p,n)->q} dY[o,p,a] w(p,a,k,n)          (csrc/so3_inter_inv.hip)
@@ -436,6 +474,11 @@ class _InterConv(torch.autograd.Function):
             rcap, any_nonident = head.decide()
             if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
                 head = None
+        Wp = ctx.W_param()
+        if Wp is not None:
+            _set_keep_x_hint(Wp, head is None)            # the next forward of this layer keeps X iff this backward needed it
+        if head is None and not ctx.kept_x:               # wrong guess (or the first step): one more run of the grouping kernel
+            x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, ctx.sigma, nonident, blocked=ctx.layout)
             rcap = min((rcap + 3) & ~3, n)       # slots past a cloud's last referenced row are empty (rows = -1): K = rcap * na
                                                  # of the gradient GEMMs becomes a multiple of 16
         if head is not None:
@@ -449,18 +492,12 @@ class _InterConv(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
-                if LIBRARY_SMALL_GEMMS:
-                    _hip.library_matmul(W2, z.view(b, o * ks, ra), gFc)
-                else:
-                    _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
+                _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
                 gF = _hip.rows_scatter(gFc.view(b, c, rcap, na), rows, n)           # unreferenced rows: zero gradient
             if ctx.needs_input_grad[1]:
                 fc = _hip.rows_gather(feats, rows, rcap).view(b, c, ra)              # [b,c,rcap*na]; unused slots: zeros
-                if LIBRARY_SMALL_GEMMS:
-                    d = _hip.library_matmul(z.view(b, o * ks, ra), fc.transpose(1, 2), None).sum(0)
-                else:
-                    d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
-                    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
+                d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
+                _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
                 gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
         else:
             if ctx.needs_input_grad[1]:

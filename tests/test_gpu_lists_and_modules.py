@@ -531,8 +531,9 @@ def test_invariant_head_matches_reference_golden(dev, golden, mode):
             top = max(float(np.abs(g[f'{mode}_{phase}_grad_{n}']).max()) for n in names)
             for n, got in zip(['x'] + names, grads):
                 want = g[f'{mode}_{phase}_grad_{n}']
-                # a conv bias in front of a training-mode BatchNorm has an exactly-zero gradient (rounding noise on both sides)
-                scale = max(float(np.abs(want).max()), 1e-2 * top)
+                # a conv bias in front of a training-mode BatchNorm has an exactly-zero gradient: rounding noise on both sides
+                # (the reference's CPU value is ~1e-5 where the weight gradients are ~20), hence the floor
+                scale = max(float(np.abs(want).max()), 5e-2 * top)
                 assert float(np.abs(got.cpu().numpy() - want).max()) < 5e-5 * scale, (phase, n)
         if phase == 'train':
             for k, v in head.state_dict().items():
