@@ -60,6 +60,16 @@ int group_lists_fwd(int b, int c, int p, int n, int nn, int na, int ks, float si
 int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
+// csrc/so3_inter_lists2.hip: the same kernel with two channel tiles per wave sharing one weight evaluation (64-channel
+// blocks); group_lists2_preferred: the channel count fills the wider blocks and the variant has not been switched off
+// with eap_so3_group_lists_tiles(1)
+bool group_lists2_preferred(int c, int na, int ks, int layout);
+int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                     const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
+                     hipStream_t s);
+int group_lists2_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
+                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
+                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
 // csrc/zpconv_rows.hip: native inter zpconv forward near HBM speed (shared neighbour list per point)
 bool inter_zpconv_rows_supported(int np, int nq, int na, int ks, int nn, int c);
 // (only_flagged != nullptr: clouds whose flag is zero are left untouched)

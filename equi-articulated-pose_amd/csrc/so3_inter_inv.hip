@@ -482,6 +482,8 @@ extern "C" int eap_so3_inter_group_inv_pitch_f32(int b, int o, int p, int nn, in
                                                  float *z, eap_stream_t stream) {
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (!eap::group_lists_supported(na, ks)) return eap::bad_arg("so3_inter_group_inv_pitch: unsupported anchor / kernel-point count");
+    if (eap::group_lists2_preferred(o, na, ks, 0))
+        return eap::group_lists2_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
     return eap::group_lists_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
 }
 
@@ -498,8 +500,11 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     if ((long long)o * p * na >= (1ll << 31)) return eap::bad_arg("so3_inter_group_inv: one cloud's gradient exceeds 2^31 elements");
     hipStream_t s = eap::S(stream);
     // no anchor permutation: the two-workgroups-per-CU kernel of csrc/so3_inter_lists.hip
-    if (!multinv && eap::group_lists_supported(na, ks))
+    if (!multinv && eap::group_lists_supported(na, ks)) {
+        if (eap::group_lists2_preferred(o, na, ks, 0))
+            return eap::group_lists2_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
         return eap::group_lists_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
+    }
     // row pitch = na (direct global -> LDS rows) when that pitch spreads the 32 channel lanes of
     // an operand read over 16 bank pairs (na = 4 mod 8, e.g. the 60 icosahedral anchors);
     // other anchor counts take the register-staged variant with a padded pitch

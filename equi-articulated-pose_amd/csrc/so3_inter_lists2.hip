@@ -1,0 +1,412 @@
+// csrc/so3_inter_lists2.hip -- the entry-list grouping kernel of csrc/so3_inter_lists.hip with TWO channel tiles per
+// wave sharing ONE weight evaluation (round 3).
+//
+//   forward   X[b,c,k,p,a]  = sum_n  F[b,c,idx[b,p,n],a]  * w(p,a,k,n)
+//             (vgtk/vgtk/so3conv/functional.py:L1112-1261, einsum 'bcpna,bpakn->bckpa' at L1261)
+//   backward  Z[b,o,k,r,a]  = sum_{(p,n)->q_r} dY[b,o,p,a] * w(p,a,k,n)      (its autograd transpose over inverse lists)
+//   w(p,a,k,n) = relu(1 - |g(p,n) - A_a kappa_k|^2 / sigma)
+//
+// Why: on this part every vector-ALU instruction between two fp32 MFMAs costs its issue cycles of matrix time
+// (tools/microbench/mfma_waves.hip, mfma_riders.hip), and the weights -- the MFMA's B operand --
+// are evaluated in registers, ~3 plain-instruction equivalents each.  A weight depends on (entry, anchor, kernel point)
+// but NOT on the channel, so the one lever left is channels per weight: a wave now feeds each weight register to two
+// v_mfma_f32_32x32x2_f32 (channel rows 0-31 and 32-63 of a 64-channel block) instead of one, halving the vector work per
+// matrix instruction; per-entry terms, ring reads and chunk barriers are shared the same way.
+//
+// Geometry: workgroup = 4 waves (one per SIMD) = (row run, 64 channels, 16 anchors); wave = 4 anchors x 2 channel
+// tiles = 128 accumulator registers; 64 KB of LDS -> two workgroups per CU (two waves per SIMD: the measured matrix-pipe
+// utilisation is the same for 2 and 4 resident waves, mfma_waves.hip).  na = 60 -> anchor groups 16+16+16+12.
+// LDS image of a chunk: [8 entries][64 channel rows][4 slots of 16 bytes]; the piece of anchors 4w..4w+3 of row r sits in
+// slot (w + (r >> 2)) & 3: the four 16-lane groups a ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...,
+// MI355X_MICROARCH.md section LDS) then touch 16 different 16-byte slots of the 256-byte bank row -- conflict-free at a
+// 64-byte row pitch, and still one contiguous 1 KB destination per global->LDS DMA instruction.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CT = 2;         // channel tiles (MFMA M tiles) per wave
+constexpr int CB = 32 * CT;   // channels per block
+constexpr int NBK = 8;        // entries per LDS stage (4 MFMA k-steps)
+constexpr int APW = 4;        // anchors per wave
+constexpr int NWV = 4;
+constexpr int TM = 64 * NWV;
+constexpr int SL = 4;         // 16-byte slots per LDS row (= pieces of a 16-anchor group)
+constexpr int GSZ = 4 * SL;   // anchors per workgroup
+constexpr int PITCH = 4 * SL; // floats per LDS row
+constexpr int NSTD = NBK * CB * SL / TM;   // DMA instructions per thread and chunk (8): instruction u carries entry u
+constexpr unsigned BUF_BYTES = NBK * CB * PITCH * 4;
+static_assert(CB * SL == TM, "one DMA instruction per entry: thread t <-> (row t >> 2, slot t & 3)");
+
+__device__ inline unsigned lds_addr(const void *ptr) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
+}
+// wave-wide 16-byte-per-lane global -> LDS DMA, invisible to hipcc's waitcnt bookkeeping on purpose (the kernel waits
+// with dma_wait() before the chunk barrier); same idiom as csrc/so3_inter_lists.hip
+__device__ inline void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void glds16s(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ inline void glds4(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LISTS = true : rows / off / cnt describe variable-length entry lists (backward);
+// LISTS = false: row r of cloud b owns entries [ (b*R + r)*nn, +nn ) (forward: its neighbours).
+// LAYOUT of the output: 0 = [b,c,k,row,a] (reference), 2 = transposed [row*na+a][c*ks+k]
+template <bool LISTS, int LAYOUT>
+__global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
+    int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, int AG, int RPB, float inv_sigma,
+    const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
+    const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
+    const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- block -> (row run, anchor group, channel slice, cloud); an XCD gets whole (slice, cloud) pairs when their
+    //      number allows it, else a contiguous range of rows (whole output lines in one L2) ----
+    const int nrun = (R + RPB - 1) / RPB;
+    const int ny = gridDim.y, nsl = ny * gridDim.z, per_slice = nrun * AG;
+    int qd = blockIdx.x, sl = blockIdx.y + ny * blockIdx.z;
+    if ((nsl & 7) == 0) {
+        const unsigned lin = blockIdx.x + (unsigned)per_slice * (blockIdx.y + (unsigned)ny * blockIdx.z);
+        const unsigned j = lin >> 3;
+        sl = (int)((lin & 7u) + 8u * (j / (unsigned)per_slice));
+        qd = (int)(j % (unsigned)per_slice);
+    } else {
+        qd = xcd_point(blockIdx.x, per_slice);
+    }
+    const int run = qd / AG, ag = qd - run * AG;
+    const int r_begin = run * RPB, rows_blk = min(RPB, R - r_begin);
+    const int cy = sl % ny, bi = sl / ny, c0 = cy * CB;
+    if (nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) != 0) return;   // permuted cloud: not ours
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lk = lane & 31, lh = lane >> 5;
+    const int a0 = ag * GSZ, gcount = min(GSZ, na - a0);      // anchors [a0, a0 + gcount) of this block
+    const int npg = gcount >> 2;                               // 16-byte pieces per feature row that exist
+    const int al_beg = wave_u * APW;                           // first local anchor of this wave = piece wave_u
+    const bool active = al_beg < gcount;                       // wave-uniform
+
+    float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][PITCH]
+    float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * PITCH);   // [3][NBK] ring
+    int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] ring
+
+    int n_ent, nchunk_row;
+    size_t e0;
+    if (LISTS) {
+        const int q = rows[(size_t)bi * R + r_begin];
+        n_ent = q >= 0 ? cnt[(size_t)bi * R + r_begin] : 0;
+        e0 = (size_t)bi * ent_stride + (q >= 0 ? off[(size_t)bi * R + r_begin] : 0);
+        nchunk_row = (n_ent + NBK - 1) / NBK;
+    } else {
+        n_ent = rows_blk * nn;
+        e0 = ((size_t)bi * R + r_begin) * nn;
+        nchunk_row = (nn + NBK - 1) / NBK;
+    }
+    const int nchunk = LISTS ? nchunk_row : rows_blk * nchunk_row;
+
+    // ---- per-lane weight constants of this wave's anchors (k = lane & 31): see csrc/so3_inter_lists.hip ----
+    f32x2 kxp[APW / 2], kyp[APW / 2], kzp[APW / 2], kcp[APW / 2];
+#pragma unroll
+    for (int ai = 0; ai < APW; ++ai) {
+        const int a = a0 + min(al_beg + ai, gcount - 1);
+        const float *r3 = rk + ((size_t)a * ks + min(lk, ks - 1)) * 3;
+        const float x = r3[0], y = r3[1], z = r3[2];
+        kxp[ai >> 1][ai & 1] = 2.f * inv_sigma * x;
+        kyp[ai >> 1][ai & 1] = 2.f * inv_sigma * y;
+        kzp[ai >> 1][ai & 1] = 2.f * inv_sigma * z;
+        kcp[ai >> 1][ai & 1] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
+    }
+    const float kcl = kcp[0][0];
+    const bool kc_uniform = __all(fabsf(kcp[0][1] - kcl) <= 1e-6f * fabsf(kcl) && fabsf(kcp[1][0] - kcl) <= 1e-6f * fabsf(kcl) &&
+                                  fabsf(kcp[1][1] - kcl) <= 1e-6f * fabsf(kcl)) != 0;
+    // operand read: the wave's four anchors are ONE 16-byte piece (piece wave_u) of a channel row; tile 1 = rows + 32
+    // (same slot: (32 >> 2) & 3 == 0)
+    const float4 *fa_lane = reinterpret_cast<const float4 *>(s_f + (size_t)(lh * CB + lk) * PITCH + 4 * ((wave_u + (lk >> 2)) & 3));
+    constexpr int TILE_F4 = 32 * PITCH / 4;            // float4s between the two channel tiles of an entry
+    constexpr int STEP_F4 = 2 * CB * PITCH / 4;        // float4s per MFMA k-step (2 entries)
+    constexpr int BUF_F4 = NBK * CB * PITCH / 4;
+
+    f32x16 acc[CT][APW];
+
+    // ---- DMA: instruction u of a chunk carries entry u; thread t <-> channel row t >> 2, slot t & 3 ----
+    const float *fb = F + ((size_t)bi * C + c0) * PF * fpitch;   // fpitch: floats between consecutive feature rows (>= na)
+    const unsigned lds_f = lds_addr(s_f);
+    const unsigned row_bytes = (unsigned)fpitch * 4u;
+    const int d_row = t >> 2, d_piece = ((t & 3) - (d_row >> 2)) & 3;
+    const bool d_valid = d_piece < npg;
+    const unsigned dma_off = ((unsigned)(min(c0 + d_row, C - 1) - c0) * (unsigned)PF * (unsigned)fpitch + (unsigned)(a0 + 4 * min(d_piece, npg - 1))) * 4u;
+    const unsigned lds_g = lds_addr(s_g), lds_p = lds_addr(s_p);
+    auto issue_idx = [&](int j0, int slot) {
+        if (wave_u == 0 && lane < NBK) {
+            const size_t e = e0 + min(j0 + lane, max(n_ent - 1, 0));
+            glds4(ent_p + e, __builtin_amdgcn_readfirstlane(lds_p + (unsigned)slot * NBK * 4u));
+            glds16(ent_gx + e, __builtin_amdgcn_readfirstlane(lds_g + (unsigned)slot * NBK * 16u));
+        }
+    };
+    unsigned src_off[NSTD];
+    auto prep_rows = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < NSTD; ++u) {
+            int pe = s_p[slot * NBK + u];
+            if (!LISTS) pe = (unsigned)pe < (unsigned)PF ? pe : 0;     // shadow row: any valid row, weight 0
+            src_off[u] = dma_off + __umul24((unsigned)pe, row_bytes);
+        }
+    };
+    auto issue = [&](int u, int buf) {
+        if (d_valid)
+            glds16s(fb, src_off[u], __builtin_amdgcn_readfirstlane(lds_f + (unsigned)buf * BUF_BYTES + (unsigned)(u * TM + wave_u * 64) * 16u));
+    };
+
+    if (nchunk > 0) {
+        issue_idx(0, 0);
+        issue_idx(NBK, 1);
+        dma_wait();
+        __syncthreads();
+        prep_rows(0);
+#pragma unroll
+        for (int u = 0; u < NSTD; ++u) issue(u, 0);
+        dma_wait();
+    }
+    __syncthreads();
+
+    auto chunk_bases = [&](int ch, int gslot) {
+        const int e = lane & (NBK - 1);
+        const float4 g = s_g[gslot * NBK + e];
+        float b = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
+        bool dead = ch * NBK + e >= n_ent;
+        if (!LISTS) dead = dead || (unsigned)s_p[gslot * NBK + e] >= (unsigned)PF;
+        return __float_as_int(dead ? -1e30f : b);
+    };
+    auto gather = [&](const float4 *fab, int gslot, int bases, int s, float4 &fa, float4 &fb1, float4 &g, float &bk) {
+        fa = fab[s * STEP_F4];
+        fb1 = fab[s * STEP_F4 + TILE_F4];
+        g = s_g[gslot * NBK + 2 * s + lh];
+        bk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (2 * s + lh), bases));
+    };
+    auto nothing = [] {};
+    // one MFMA k-step (2 entries): 4 weights per lane, 8 matrix instructions; q0..q3 run after MFMA pairs 1..4
+    auto step = [&](auto kcu, const float4 g, float bk, const float4 fv0, const float4 fv1, auto q0, auto q1, auto q2, auto q3,
+                    bool first = false) {
+        const float fa0[APW] = {fv0.x, fv0.y, fv0.z, fv0.w};
+        const float fa1[APW] = {fv1.x, fv1.y, fv1.z, fv1.w};
+        f32x2 wv[APW / 2];
+        const float bkc = bk + kcl;
+#pragma unroll
+        for (int j = 0; j < APW / 2; ++j) {
+            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], decltype(kcu)::value ? (f32x2){bkc, bkc} : kcp[j] + (f32x2){bk, bk});
+            x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
+        }
+        __builtin_amdgcn_s_setprio(3);
+        if (first) {
+            const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[0], wv[0][0], zc, 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[1], wv[0][1], zc, 0, 0, 0);
+            q0();
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[2], wv[1][0], zc, 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[3], wv[1][1], zc, 0, 0, 0);
+            q1();
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[0], wv[0][0], zc, 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[1], wv[0][1], zc, 0, 0, 0);
+            q2();
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[2], wv[1][0], zc, 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[3], wv[1][1], zc, 0, 0, 0);
+        } else {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[0], wv[0][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[1], wv[0][1], acc[0][1], 0, 0, 0);
+            q0();
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[2], wv[1][0], acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[3], wv[1][1], acc[0][3], 0, 0, 0);
+            q1();
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[0], wv[0][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[1], wv[0][1], acc[1][1], 0, 0, 0);
+            q2();
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[2], wv[1][0], acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[3], wv[1][1], acc[1][3], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        q3();
+    };
+
+    // Row end: accumulators straight to global memory.  D[i = channel][j = kernel point] sits as col = lane&31,
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Wave-uniform 64-bit base per store + ONE 32-bit per-lane offset.
+    const size_t o_ks = (size_t)R * na, o_cs = (size_t)ks * R * na;
+    float *ob = out + (size_t)bi * C * o_cs + (size_t)c0 * o_cs + a0;
+    const unsigned lane_off = (unsigned)((size_t)(4 * lh) * o_cs + (size_t)min(lk, ks - 1) * o_ks) + (unsigned)al_beg;
+    float *obb = out + (size_t)bi * C * o_cs;
+    auto store_row = [&](int row) {
+        if (active && lk < ks) {
+            if (LAYOUT == 2) {
+                // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix the contraction GEMM reads)
+                const size_t CK = (size_t)C * ks;
+                float *rb = obb + ((size_t)row * na + a0 + al_beg) * CK + (size_t)c0 * ks;      // uniform
+                const unsigned lo_b = (unsigned)((4 * lh) * ks + lk) * 4u;
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // the accumulators were last written by MFMAs the asm cannot see
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (c0 + 32 * ct + 32 <= C) {            // block-uniform
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+#pragma unroll
+                            for (int ai = 0; ai < APW; ++ai)
+                                asm volatile("global_store_dword %0, %1, %2" : : "v"(lo_b), "v"(acc[ct][ai][r]),
+                                             "s"(rb + (size_t)ai * CK + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * ks) : "memory");
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (c0 + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh < C) {
+#pragma unroll
+                                for (int ai = 0; ai < APW; ++ai)
+                                    *reinterpret_cast<float *>(reinterpret_cast<char *>(rb + (size_t)ai * CK + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * ks) + lo_b) = acc[ct][ai][r];
+                            }
+                    }
+                }
+            } else {
+                float *rb = ob + (size_t)row * na;             // uniform
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (c0 + 32 * ct + 32 <= C) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            *reinterpret_cast<float4 *>(rb + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * o_cs + lane_off) =
+                                make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (c0 + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh < C)
+                                *reinterpret_cast<float4 *>(rb + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * o_cs + lane_off) =
+                                    make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
+                    }
+                }
+            }
+        }
+    };
+
+    int g0 = 0, g1 = 1, g2 = 2;                           // ring slots of chunks ch, ch+1, ch+2
+    int ch_row = 0, row = r_begin;
+    if (active) {
+#define EAP_LISTS2_LOOP(kcu)                                                                                          \
+        for (int ch = 0; ch < nchunk; ++ch) {                                                                         \
+            const int buf = ch & 1, nb = buf ^ 1;                                                                     \
+            const float4 *fbuf = fa_lane + buf * BUF_F4;                                                              \
+            float4 fa0, fb0, fa1, fb1, ga, gb;                                                                        \
+            float ba, bb;                                                                                             \
+            const int bases = chunk_bases(ch, g0);                                                                    \
+            gather(fbuf, g0, bases, 0, fa0, fb0, ga, ba);                                                             \
+            gather(fbuf, g0, bases, 1, fa1, fb1, gb, bb);                                                             \
+            prep_rows(g1);                                                                                            \
+            issue_idx((ch + 2) * NBK, g2);                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, ga, ba, fa0, fb0, [&] { issue(0, nb); }, [&] { issue(1, nb); }, [&] { issue(2, nb); }, nothing, ch_row == 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            gather(fbuf, g0, bases, 2, fa0, fb0, ga, ba);                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, gb, bb, fa1, fb1, [&] { issue(3, nb); }, [&] { issue(4, nb); }, [&] { issue(5, nb); }, nothing); \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            gather(fbuf, g0, bases, 3, fa1, fb1, gb, bb);                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, ga, ba, fa0, fb0, [&] { issue(6, nb); }, [&] { issue(7, nb); }, nothing, nothing);              \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            step(kcu, gb, bb, fa1, fb1, nothing, nothing, nothing, nothing);                                          \
+            dma_wait();                                                                                               \
+            if (++ch_row == nchunk_row) {                                                                             \
+                store_row(row);                                                                                       \
+                ch_row = 0;                                                                                           \
+                ++row;                                                                                                \
+            }                                                                                                         \
+            __syncthreads();                                                                                          \
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;                                                             \
+        }                                                                                                             \
+        if (nchunk == 0) {                                                                                            \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                         \
+                _Pragma("unroll") for (int ai = 0; ai < APW; ++ai)                                                    \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[ct][ai][r] = 0.f;                              \
+            store_row(r_begin);                                                                                       \
+        }
+
+        if (kc_uniform) { EAP_LISTS2_LOOP(std::true_type{}); } else { EAP_LISTS2_LOOP(std::false_type{}); }
+#undef EAP_LISTS2_LOOP
+    } else {
+        for (int ch = 0; ch < nchunk; ++ch) {
+            prep_rows(g1);
+#pragma unroll
+            for (int u = 0; u < NSTD; ++u) issue(u, (ch & 1) ^ 1);
+            dma_wait();
+            __syncthreads();
+            const int gt = g0; g0 = g1; g1 = g2; g2 = gt;
+        }
+    }
+}
+
+constexpr size_t SHMEM = 2 * BUF_BYTES + 16 * 3 * NBK + 16 * NBK;
+
+template <bool LISTS>
+int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
+            const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
+            const float *rk, const int32_t *nonident, float *out, hipStream_t s, const char *what) {
+    if (fpitch < na || (fpitch & 3) != 0) return eap::bad_arg("so3_group_lists2: the feature row pitch must be a multiple of 4, at least the anchor count");
+    if ((long long)CB * PF * fpitch * 4 >= (1ll << 32) || PF >= (1 << 24) || fpitch * 4 >= (1 << 24))
+        return eap::bad_arg("so3_group_lists2: 64 feature rows of a cloud exceed the 32-bit request offsets");
+    if (((long long)ks * R * na * 4 + 64ll * R * na + 64) * 4 >= (1ll << 31) || (long long)CB * ks * 4 >= (1ll << 31))
+        return eap::bad_arg("so3_group_lists2: output rows too far apart for 32-bit store offsets");
+    auto kern = layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>;
+    int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM), what);
+    if (e) return e;
+    const int AG = (na + GSZ - 1) / GSZ;
+    const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
+    dim3 grid((R + RPB - 1) / RPB * AG, (C + CB - 1) / CB, b);
+    hipLaunchKernelGGL(kern, grid, dim3(TM), SHMEM, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, 1.0f / sigma, F,
+                       rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
+    return eap::check_launch(what);
+}
+
+}  // namespace
+
+static int g_tiles = 2;       // eap_so3_group_lists_tiles
+
+// A/B and test switch: 1 = always the one-tile kernel of csrc/so3_inter_lists.hip, 2 = two tiles where they pay (default);
+// 0 = query.  Returns the value in force.  Process-wide, not thread-safe (set it before launching).
+extern "C" int eap_so3_group_lists_tiles(int tiles) {
+    if (tiles == 1 || tiles == 2) g_tiles = tiles;
+    return g_tiles;
+}
+
+namespace eap {
+
+// two channel tiles per wave pay when the channel count fills (most of) the 64-channel blocks; layout 1 (blocked by
+// anchor quads) stays with the one-tile kernel
+bool group_lists2_preferred(int c, int na, int ks, int layout) {
+    if (g_tiles != 2 || na <= 0 || (na & 3) != 0 || na > 64 || ks <= 0 || ks > 32 || layout == 1) return false;
+    const int rem = c % CB;
+    return c >= CB && (rem == 0 || rem > 32);
+}
+
+int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                     const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
+                     hipStream_t s) {
+    return launch2<false>(layout, b, c, n, na, na, ks, p, nn, 0, sigma, feats, nullptr, nullptr, nullptr, idx, gx, rk, nonident, out, s,
+                          "so3_inter_group_fwd (lists, two channel tiles)");
+}
+
+int group_lists2_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
+                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
+                     const float *ent_gx, const float *rk, float *z, hipStream_t s) {
+    return launch2<true>(0, b, o, p, na, gy_pitch, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, nullptr, z, s,
+                         "so3_inter_group_inv (lists, two channel tiles)");
+}
+
+}  // namespace eap

@@ -186,6 +186,12 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
                                      const float *rk, const uint8_t *mult, int identity_anchor,
                                      float *gfeats, float *workspace, eap_stream_t stream);
 
+/* Which entry-list grouping kernel serves eap_so3_inter_group_fwd*_f32 / eap_so3_inter_group_inv*_f32 when no anchor
+ * permutation is in play: 2 (default) = two channel tiles per wave sharing one weight evaluation where the channel
+ * count fills 64-channel blocks (csrc/so3_inter_lists2.hip), 1 = always the one-tile kernel (csrc/so3_inter_lists.hip);
+ * 0 = query.  Returns the value in force.  Same results either way (tests compare them); A/B timing and tests only. */
+int eap_so3_group_lists_tiles(int tiles);
+
 /* so3_inter_group_inv: the feature gradient of the whole inter convolution by re-association,
  *   dF[c,q,a'] = sum_{o,k} W[o,(c,k)] Z[o,k,q,a'],
  *   Z[o,k,q,a'] = sum_{(p,n): idx[p,n]=q} dY[o,p,a] w(p,a,k,n),  a = perm_n^-1(a')

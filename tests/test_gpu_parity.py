@@ -797,3 +797,49 @@ def test_native_known_answers(dev):
     K.known_fps(on_gpu(G.furthest_point_sampling))
     K.known_zpconv(on_gpu(Z.inter_zpconv_forward), on_gpu(Z.inter_zpconv_backward), on_gpu(Z.intra_zpconv_forward), on_gpu(Z.intra_zpconv_backward))
     K.known_chamfer(on_gpu(chamfer.forward), on_gpu(chamfer.backward))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [
+    (2, 64, 37, 37, 64, 60, 24),      # the shipped geometry: 64 channels = one full block, anchor groups 16+16+16+12
+    (1, 128, 70, 50, 24, 60, 24),     # two blocks, 3 chunks per row, rows streamed 8 at a time, shadow rows
+    (1, 112, 19, 19, 20, 28, 17),     # 112 = 64 + 48: a partial second tile; 28 anchors (16 + 12); nn not a multiple of 8; 17 kernel points
+    (1, 192, 9, 40, 16, 64, 32),      # 64 anchors (4 full groups), 32 kernel points, fewer rows than a run
+    (3, 64, 33, 33, 8, 16, 24),       # 16 anchors: one group; batch 3 (slice count not a multiple of 8)
+])
+def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
+    """csrc/so3_inter_lists2.hip (two channel tiles per wave, 64-channel blocks) against csrc/so3_inter_lists.hip and the
+    VALU kernel: forward in the reference and the transposed layout, and the backward's Z over inverse lists.  Every output
+    element accumulates the same products in the same order in both matrix kernels, so they must agree BIT FOR BIT."""
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    b, c, p, n, nn, na, ks = shape
+    torch.manual_seed(7)
+    feats = torch.randn(b, c, n, na, device=dev)
+    idx = torch.randint(0, n + 1, (b, p, nn), device=dev, dtype=torch.int32)      # n = shadow row
+    gx = torch.zeros(b, p, nn, 4, device=dev)
+    gx[..., :3] = torch.randn(b, p, nn, 3, device=dev) * 0.05
+    rk = torch.randn(na, ks, 3, device=dev) * 0.05
+    sigma = 0.01
+    gy = torch.randn(b, c, p, na, device=dev)
+    idx_v = idx.clamp(max=n - 1)
+    rows, off, cnt, ent_p, ent_gx, rcap, _ = L._inverse_lists(idx_v, gx, n, 0, None)
+    out = {}
+    assert _hip.lib.eap_so3_group_lists_tiles(0) == 2
+    try:
+        for tiles in (1, 2):
+            assert _hip.lib.eap_so3_group_lists_tiles(tiles) == tiles
+            out[tiles] = (_hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma),
+                          _hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma, blocked=2),
+                          _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, None, sigma, nn))
+    finally:
+        _hip.lib.eap_so3_group_lists_tiles(2)
+    for a, bb, what in zip(out[1], out[2], ('forward', 'forward, transposed', 'backward Z')):
+        assert torch.equal(a, bb), what
+    ref = torch.empty_like(out[2][0])
+    _hip.call('eap_so3_inter_group_fwd_valu_f32', ref, b, c, p, n, nn, na, ks, _hip._F32(sigma), _hip._ptr(feats),
+              _hip._ptr(idx), _hip._ptr(gx), _hip._ptr(rk), _hip._ptr(None), _hip._ptr(ref))
+    assert rel_err(out[2][0].cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    # transposed layout holds the same numbers: [b, p*na + a, c*ks + k]
+    xt = out[2][1].view(b, p * na, c * ks)
+    assert torch.equal(xt.view(b, p, na, c, ks).permute(0, 3, 4, 1, 2), out[2][0])

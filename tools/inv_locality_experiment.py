@@ -34,18 +34,21 @@ for layer in (2, 1):
     def run(ep):
         _hip.call('eap_so3_inter_group_inv_pitch_f32', z, B, o, P, NN, NA, NA, KS, rcap, _hip._F32(s), _hip._ptr(gy), _hip._ptr(rows),
                   _hip._ptr(off), _hip._ptr(cnt), _hip._ptr(ep), _hip._ptr(ent_gx), _hip._ptr(rk), _hip._ptr(z))
-    for ep in variants.values():
-        run(ep)
-    torch.cuda.synchronize()
-    res = {k: [] for k in variants}
-    for _ in range(5):
-        for k, ep in variants.items():
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); run(ep); e1.record(); torch.cuda.synchronize()
-            res[k].append(e0.elapsed_time(e1))
     fl = 2.0 * B * o * KS * P * NN * NA
     cn = cnt.flatten().float()
     print(f'layer {layer} O={o} rcap={rcap}: list lengths mean {cn[cn > 0].mean().item():.0f} max {cn.max().item():.0f} min {cn[cn > 0].min().item():.0f}', flush=True)
-    for k, v in res.items():
-        v.sort()
-        print(f'layer {layer} O={o}: rows {k:9s}: median {v[2]:.2f} ms  min {v[0]:.2f} ms  {fl / v[2] / 1e9:.1f} TFLOP/s algorithmic = {fl / v[2] / 1e9 / 157.3:.3f} of peak', flush=True)
+    for tiles in (1, 2):        # csrc/so3_inter_lists.hip (one channel tile per wave) / so3_inter_lists2.hip (two)
+        _hip.lib.eap_so3_group_lists_tiles(tiles)
+        for ep in variants.values():
+            run(ep)
+        torch.cuda.synchronize()
+        res = {k: [] for k in variants}
+        for _ in range(5):
+            for k, ep in variants.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(ep); e1.record(); torch.cuda.synchronize()
+                res[k].append(e0.elapsed_time(e1))
+        for k, v in res.items():
+            v.sort()
+            print(f'layer {layer} O={o} tiles/wave {tiles}: rows {k:9s}: median {v[2]:.2f} ms  min {v[0]:.2f} ms  {fl / v[2] / 1e9:.1f} TFLOP/s algorithmic = {fl / v[2] / 1e9 / 157.3:.3f} of peak', flush=True)
+    _hip.lib.eap_so3_group_lists_tiles(2)
