@@ -86,36 +86,6 @@ def get_2D_res_anchors():
 RES_ROT_2D = get_2D_res_anchors()
 
 
-def get_kernel_points_np(radius, aperature, kernel_size, multiplier=1):
-    """(x,y,z) kernel points from the conic parameterisation (functional.py:L73-89)."""
-    assert isinstance(kernel_size, int)
-    rrange = np.linspace(0, radius, kernel_size, dtype=np.float32)
-    kps = []
-    for ridx, ri in enumerate(rrange):
-        alpharange = zpconv.get_angular_kernel_points_np(aperature, ridx * multiplier + 1)
-        for aidx, alpha in enumerate(alpharange):
-            r_r = ri * np.tan(alpha)
-            thetarange = np.linspace(0, 2 * np.pi, aidx * 2 + 1, endpoint=False, dtype=np.float32)
-            kps.append(np.vstack([r_r * np.cos(thetarange), r_r * np.sin(thetarange), np.repeat(ri, aidx * 2 + 1)]).T)
-    return np.vstack(kps)
-
-
-def get_spherical_kernel_points_np(radius, kernel_size, multiplier=3):
-    """Kernel points on concentric spheres (functional.py:L91-109)."""
-    assert isinstance(kernel_size, int)
-    rrange = np.linspace(0, radius, kernel_size, dtype=np.float32)
-    kps = []
-    for ridx, r_i in enumerate(rrange):
-        asize = bsize = ridx * multiplier + 1
-        alpharange = np.linspace(0, 2 * np.pi, asize, endpoint=False, dtype=np.float32)
-        betarange = np.linspace(0, np.pi, bsize, endpoint=True, dtype=np.float32)
-        xs = r_i * np.cos(alpharange[:, None]) * np.sin(betarange[None])
-        ys = r_i * np.sin(alpharange[:, None]) * np.sin(betarange[None])
-        zs = r_i * np.cos(betarange)[None].repeat(asize, axis=0)
-        kps.append(np.vstack([xs.reshape(-1), ys.reshape(-1), zs.reshape(-1)]).T)
-    return np.vstack(kps)
-
-
 def initial_anchor_query(frag, centers, kernels, r, sigma):
     """frag [m,3], centers [b,3,nc], kernels [ks,na,3] -> (w, cnt) [b,ks,nc,na] (functional.py:L129-130)."""
     return cuda_nn.initial_anchor_query(centers, frag, kernels, r, sigma)

@@ -102,33 +102,19 @@ class InterSO3Conv(nn.Module):
         return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, feats, self.anchors)
 
 
-class InterSO3PoseConv(nn.Module):
+class InterSO3PoseConv(InterSO3Conv):
     """Pose-aware inter conv (modules.py:L177-322); forward returns
-    (inter_idx, inter_w, sample_idx, SphericalPointCloudPose)."""
+    (inter_idx, inter_w, sample_idx, SphericalPointCloudPose).  Same parameters / buffers as InterSO3Conv
+    (`basic_conv.W`, `anchors`, `kernels`) plus the pose-handling switches."""
 
     def __init__(self, dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
                  lazy_sample=True, pooling=None, kanchor=60, permute_modes=0, use_2d=False,
                  use_art_mode=False):
-        super(InterSO3PoseConv, self).__init__()
         if use_2d or use_art_mode:
             raise NotImplementedError('use_2d / use_art_mode grouping variants are outside the accelerated path')
-        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
-        anchors = L.get_anchors(kanchor)
-        self.dim_in = dim_in
-        self.dim_out = dim_out
-        self.kernel_size = kernels.shape[0]
-        self.stride = stride
-        self.radius = radius
-        self.sigma = sigma
-        self.n_neighbor = n_neighbor
-        self.lazy_sample = lazy_sample
-        self.pooling = pooling
-        self.permute_modes = permute_modes
-        self.use_2d = use_2d
-        self.use_art_mode = use_art_mode
-        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
-        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
-        self.register_buffer('kernels', torch.from_numpy(kernels))
+        super(InterSO3PoseConv, self).__init__(dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
+                                               lazy_sample=lazy_sample, pooling=pooling, kanchor=kanchor)
+        self.permute_modes, self.use_2d, self.use_art_mode = permute_modes, use_2d, use_art_mode
 
     def forward(self, x, inter_idx=None, inter_w=None, seg=None):
         if self.pooling is not None and self.stride > 1 and x.feats.shape[1] > 1:
@@ -176,19 +162,9 @@ class IntraSO3Conv(nn.Module):
         return SphericalPointCloud(x.xyz, out, self.anchors)
 
 
-class IntraSO3Conv2D(nn.Module):
-    """IntraSO3Conv on an anchor axis of (60, 4) in-plane residual rotations (modules.py:L350-373)."""
-
-    def __init__(self, dim_in, dim_out):
-        super(IntraSO3Conv2D, self).__init__()
-        anchors = L.get_anchors()
-        intra_idx = L.get_intra_idx()
-        self.dim_in = dim_in
-        self.dim_out = dim_out
-        self.kernel_size = intra_idx.shape[1]
-        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
-        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
-        self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
+class IntraSO3Conv2D(IntraSO3Conv):
+    """IntraSO3Conv on an anchor axis of (60, 4) in-plane residual rotations (modules.py:L350-373): same parameters and
+    buffers, the 12-tap gather acts on the 60-axis."""
 
     def forward(self, x):
         feats = L.intra_so3conv_grouping_2D(self.intra_idx, x.feats)
@@ -210,19 +186,16 @@ class PointnetSO3Conv(nn.Module):
         self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
 
     def forward(self, x):
-        xyz = x.xyz
-        feats = x.feats
-        na = feats.shape[3]
-        xyz = xyz - xyz.mean(2, keepdim=True)
-        if na == 1:
-            feats = torch.cat([x.feats, xyz[..., None]], 1)
+        """x.xyz [b,3,n], x.feats [b,c,n,na] -> [b,dim_out,na] (or the per-point map with return_raw): every anchor sees
+        the centred coordinates in ITS frame, A_a^T (x - mean), stacked under the features; a shared 1x1 layer; max over
+        the points."""
+        centred = x.xyz - x.xyz.mean(dim=2, keepdim=True)                               # [b,3,n]
+        if x.feats.shape[3] == 1:
+            coords = centred.unsqueeze(-1)                                              # one frame: the identity
         else:
-            xyzr = torch.einsum('aji,bjn->bina', self.anchors, xyz)
-            feats = torch.cat([x.feats, xyzr], 1)
-        feats = self.embed(feats)
-        if self.return_raw:
-            return feats
-        return torch.max(feats, 2)[0]
+            coords = torch.matmul(self.anchors.transpose(1, 2).unsqueeze(0), centred.unsqueeze(1)).permute(0, 2, 3, 1)   # [b,3,n,na]
+        embedded = self.embed(torch.cat([x.feats, coords], dim=1))
+        return embedded if self.return_raw else embedded.max(dim=2)[0]
 
 
 class PointnetSO3PoseConv(PointnetSO3Conv):

@@ -1,4 +1,3 @@
 from .base import SphericalPointCloud, SphericalPointCloudPose  # noqa: F401
 from .functional import *  # noqa: F401,F403
 from . import functional  # noqa: F401
-from .modules import *  # noqa: F401,F403

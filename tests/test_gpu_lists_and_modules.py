@@ -1,5 +1,5 @@
 """GPU: the device-side inverse neighbour lists (csrc/inv_lists.hip) and the B1 modules added in round 2
-(KernelPropagation, IntraSO3Conv2D, vgtk.spconv.modules) against plain torch / the CPU oracle."""
+(KernelPropagation, IntraSO3Conv2D, the zpconv wrappers) against plain torch / the CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -139,42 +139,53 @@ def test_intra_so3conv_2d(dev):
     assert rel_err(out.detach().cpu().numpy(), ref.numpy()) < 1e-5
 
 
-def test_zpconv_modules(dev):
-    """vgtk.spconv.modules (spconv/modules.py:L17-146) on the HIP zpconv kernels vs the reference's einsum
-    formulation in plain torch on the CPU."""
-    import synth_clouds
+def test_zpconv_wrappers_pooling_and_index_helpers(dev):
+    """the autograd wrappers around the native zpconv ops (spconv/functional.py:L102-129,
+    L211-238) through the "naive" shared-index entry points, values and gradients against the reference's einsum
+    formulation on the CPU (oracle/so3_ref.py, pinned by zpconv_naive.npz); the pooling / blurring blends and the two
+    index helpers the SO(3) layer shares with it."""
     import vgtk.spconv as zptk
-    torch.manual_seed(4)
-    xyz = T(synth_clouds.laptop_batch(4, 2, 128)[0])
-    # intra: [b,c,p,a_in] -> [b,c2,p,a_out]
-    intra = zptk.IntraZPConv(6, 9, 3, 1.2, 0.1, 4, 12)
-    f = torch.randn(2, 6, 128, 12)
-    g = so3_ref.intra_zpconv_grouping_naive(intra.intra_idx, intra.intra_w, f)
-    ref = torch.matmul(intra.basic_conv.W.detach(), g.reshape(2, 6 * 3, 128 * 12)) + intra.basic_conv.bias.detach()
-    out = intra.to(dev)(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None)).feats
-    assert rel_err(out.detach().cpu().numpy(), ref.view(2, 9, 128, 12).numpy()) < 1e-5
-    # anchor propagation 12 -> 42 directions
-    prop = zptk.AnchorProp(12, 42, 0.1)
-    want = (f[:, :, :, prop.idx] * prop.w).sum(-1)
-    got = prop.to(dev)(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None)).feats
-    assert got.shape == (2, 6, 128, 42) and rel_err(got.cpu().numpy(), want.numpy()) < 1e-6
-    # inter: ball query + S^2 kernel weights + grouping + dense layer sized by the anchor count
-    inter = zptk.InterZPConv(6, 5, 1, 1, 0.2, 1.2, 0.05, 12, 16, 4)     # kernel_size 1 -> ks = 1 (as the reference's example shapes)
-    idx = T(native.ball_query(xyz.numpy(), xyz.numpy(), 0.2, 16))
-    gxyz = so3_ref.group_nd(so3_ref.add_shadow_point(xyz), idx) - xyz.unsqueeze(3)
-    norm = gxyz.pow(2).sum(1).sqrt() + 1e-6
-    cos_t = (gxyz.unsqueeze(3) * inter.anchors.t()[:, None, :, None]).sum(1) / norm.unsqueeze(2)
-    sign = torch.sign(cos_t); eps = 1e-4; slope = np.arccos(1 - eps) / eps
-    theta = torch.where(cos_t.abs() <= 1 - eps, torch.acos(cos_t), torch.acos(sign * (1 - eps)) - slope * sign * (cos_t.abs() - 1 + eps)).unsqueeze(3)
-    dist1 = (norm[:, :, None, None, :] - inter.kernels[:, :1]).abs() + (norm[:, :, None, None, :] * (theta - inter.kernels[:, 1:])).abs() / 3.0
-    w = torch.relu(1.0 - dist1 / 0.05 ** 0.5).permute(0, 1, 3, 2, 4).contiguous()          # [b,p,ks=1,a,nn] read as [b,p,a'=1,k'=12,nn]
-    gf = so3_ref.inter_zpconv_grouping_naive(idx, w, so3_ref.add_shadow_feature(f))          # einsum broadcasts a' = 1 over the 12 anchors
-    ref = torch.matmul(inter.basic_conv.W.detach(), gf.reshape(2, 6 * 12, 128 * 12)) + inter.basic_conv.bias.detach()
-    inter = inter.to(dev)
-    i2, w2, y = inter(zptk.SphericalPointCloud(xyz.to(dev), f.to(dev), None))
-    np.testing.assert_array_equal(i2.cpu().numpy(), idx.numpy())
-    assert rel_err(w2.cpu().numpy(), w.numpy()) < 1e-5
-    assert rel_err(y.feats.detach().cpu().numpy(), ref.view(2, 5, 128, 12).numpy()) < 1e-5
+    gen = torch.Generator().manual_seed(4)
+    b, p, a, k, nn, c, q = 2, 20, 12, 5, 8, 3, 21
+    idx = torch.randint(0, q, (b, p, nn), generator=gen)
+    w = torch.rand(b, p, a, k, nn, generator=gen)
+    f = torch.randn(b, c, q, a, generator=gen)
+    fr = f.clone().requires_grad_(True)
+    ref = so3_ref.inter_zpconv_grouping_naive(idx, w, fr)
+    g = torch.randn(ref.shape, generator=gen)
+    fd = f.to(dev).requires_grad_(True)
+    out = zptk.inter_zpconv_grouping_naive(idx.to(dev), w.to(dev), fd)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    assert rel_err(torch.autograd.grad(out, fd, g.to(dev))[0].cpu().numpy(), torch.autograd.grad(ref, fr, g)[0].numpy()) < 2e-6
+    iidx = torch.randint(0, a, (a, 4), generator=gen)
+    iw = torch.rand(a, k, 4, generator=gen)
+    f2 = torch.randn(b, c, p, a, generator=gen)
+    f2r = f2.clone().requires_grad_(True)
+    ref = so3_ref.intra_zpconv_grouping_naive(iidx, iw, f2r)
+    g = torch.randn(ref.shape, generator=gen)
+    f2d = f2.to(dev).requires_grad_(True)
+    out = zptk.intra_zpconv_grouping_naive(iidx.to(dev), iw.to(dev), f2d)
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    assert rel_err(torch.autograd.grad(out, f2d, g.to(dev))[0].cpu().numpy(), torch.autograd.grad(ref, f2r, g)[0].numpy()) < 2e-6
+    # pooling / blurring (spconv/functional.py:L274-311): alpha * centre + (1 - alpha) * neighbourhood mean, shadow index = zeros
+    idx_s = torch.randint(0, q + 1, (b, q, nn), generator=gen)                     # q = shadow row
+    pad = torch.cat([f, torch.zeros(b, c, 1, a)], 2)
+    mean = torch.stack([pad[i][:, idx_s[i]] for i in range(b)]).mean(3)            # [b,c,q,a]
+    assert rel_err(zptk.inter_blurring_naive(idx_s.to(dev), f.to(dev)).cpu().numpy(), (0.5 * f + 0.5 * mean).numpy()) < 1e-6
+    sample = torch.randint(0, q, (b, 7), generator=gen)
+    want = 0.25 * torch.stack([f[i][:, sample[i]] for i in range(b)]) + 0.75 * torch.stack([pad[i][:, idx_s[i, :7]] for i in range(b)]).mean(3)
+    assert rel_err(zptk.inter_pooling_naive(idx_s[:, :7].to(dev), sample.to(dev), f.to(dev), alpha=0.25).cpu().numpy(), want.numpy()) < 1e-6
+    # index helpers against the oracle's restatement of the reference's (pinned through the layer fixtures)
+    x = torch.randn(3, 5, 7, 4, generator=gen)
+    for dim, n in ((1, 5), (2, 7), (3, 4)):
+        i = torch.randint(0, n, (3, 9), generator=gen)
+        assert torch.equal(zptk.batched_index_select(x, dim, i), so3_ref.batched_index_select(x, dim, i))
+    v = torch.randn(2, 11, 3, 3, generator=gen)
+    ii = torch.randint(0, 11, (2, 4, 6), generator=gen)
+    assert torch.equal(zptk.batched_index_select_other(v, ii, 1), so3_ref.batched_index_select_other(v, ii, 1))
+    v2 = torch.randn(2, 4, 6, 60, 5, generator=gen)
+    i2 = torch.randint(0, 60, (2, 4, 6, 60), generator=gen)
+    assert torch.equal(zptk.batched_index_select_other(v2, i2, 3), so3_ref.batched_index_select_other(v2, i2, 3))
 
 
 @pytest.mark.parametrize('M,N,K,batch', [(512, 1920, 3072, 1), (128, 2040, 1536, 2), (256, 128, 32, 1), (130, 260, 48, 2),
