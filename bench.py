@@ -12,9 +12,12 @@ For N > 1 launch through torch.distributed.run (one rank per GPU, RCCL): every r
 its own B clouds (weak scaling, no data-path collective), then one pose-hypothesis all-gather
 and one bucketed gradient all-reduce per step.
 
-Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant kernel
-(the fp32-MFMA contraction; achieved = algorithmic flops / measured launch time from HIP events
-recorded on the launch stream inside the timed region) and a `cpu_baseline` object (the CPU
+Rank 0 prints ONE JSON line with the metric, a `roofline` object for the dominant HIP KERNEL (launch
+times are attributed to the kernel, template arguments included, that each C-ABI entry reports through
+eap_last_kernel() -- the same names rocprofv3 prints; achieved = algorithmic flops / measured launch
+time from HIP events recorded on the launch stream inside the timed region), `kernel_rooflines` for the
+grouping and contraction kernels, `whole_step` (algorithmic flops of the step / step time / peak),
+`config3_step` (BASELINE config 3 as one unit, config3_step.py) and a `cpu_baseline` object (the CPU
 oracle -- an op-for-op restatement of the reference's torch path -- timed on the host cores on a
 bounded sample; checker/baseline only, never part of the measured path).
 """
@@ -237,20 +240,55 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
                         f'broadcast over (a,k) as the Python layer builds it, radius {radius}'}
 
 
-KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it
-    'eap_gemm_dma_f32': 'gemm_dma_f32_kernel (v_mfma_f32_32x32x2_f32, DMA-fed 3-stage ring)',
-    'eap_gemm_dma_f32_reduce': 'gemm_dma_f32_kernel (v_mfma_f32_32x32x2_f32, DMA-fed 3-stage ring), split-K',
+KERNEL_OF_ENTRY = {   # C-ABI entry -> the HIP kernel that dominates it (fallback when the entry reports no kernel name)
+    'eap_gemm_dma_f32': 'gemm_dma_f32_kernel (v_mfma_f32_32x32x2_f32, operands staged global -> VGPR -> LDS, 3-stage ring)',
+    'eap_gemm_dma_f32_reduce': 'gemm_dma_f32_kernel (v_mfma_f32_32x32x2_f32, operands staged global -> VGPR -> LDS, 3-stage ring), split-K',
     'eap_gemm_f32': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)',
     'eap_gemm_f32_reduce': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K',
     'eap_so3_inter_group_fwd_f32': 'so3_group_lists_kernel<false, 0> (v_mfma_f32_32x32x2_f32)',
     'eap_so3_inter_group_fwd_xb_f32': 'so3_group_lists_kernel<false, 1> (v_mfma_f32_32x32x2_f32), blocked output',
     'eap_gemm_f32_xb': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), blocked B operand',
     'eap_gemm_f32_reduce_xb': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32), split-K, blocked B operand',
-    'library_gemm_f32': 'hipBLASLt fp32 GEMM through torch.matmul (plain [P*A, C*K] operand)',
     'eap_so3_inter_group_fwd_t_f32': 'so3_group_lists_kernel<false, 2> (v_mfma_f32_32x32x2_f32), transposed output',
     'eap_so3_intra_conv_f32': 'gemm_f32_kernel<GATHER> (v_mfma_f32_32x32x2_f32), implicit intra conv',
     'eap_so3_inter_group_inv_f32': 'so3_group_lists_kernel<true, 0> (v_mfma_f32_32x32x2_f32)',
 }
+
+
+def summarize_by_kernel(records):
+    """(entry, tag, e0, e1) records -> per HIP kernel (name with template arguments, as reported by the entry through
+    eap_last_kernel(); entries that report none are listed under their own name): total ms, launches, algorithmic flops."""
+    by_kernel = {}
+    for name, tag, e0, e1 in records:
+        kname = (tag or {}).get('kernel') or name
+        k = by_kernel.setdefault(kname, {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'entries': set()})
+        k['ms'] += e0.elapsed_time(e1)
+        k['launches'] += 1
+        k['flops'] += (tag or {}).get('flops', 0.0)
+        k['entries'].add(name)
+    return by_kernel
+
+
+def pmc_of_kernel(kname):
+    """Fabric-side bytes per launch + matrix-pipe utilisation of a kernel from the committed rocprofv3 --pmc passes
+    (profiles/r03_pmc_traffic.json, tools/pmc_traffic.py; collected at the default workload)."""
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path)).get('per_kernel', {})
+    for pat, v in d.items():
+        if kname.startswith(pat):
+            return v
+    return None
+
+
+def roofline_object(kname, k, default_cfg):
+    ach = k['flops'] / (k['ms'] * 1e-3) / 1e12 if k['ms'] > 0 else 0.0
+    pmc = pmc_of_kernel(kname) if default_cfg else None
+    return {'bound': 'mfma', 'kernel': kname, 'entries': sorted(k['entries']), 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+            'traffic': (pmc['fetch'] + pmc['write']) if pmc else None,
+            'traffic_detail': pmc, 'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1)}
 
 
 def summarize_kernels(records):
@@ -332,6 +370,52 @@ def other_configs(dev):
     ]
 
 
+def config3_step(dev, batch=16, points=4096, steps=2, warmup=1):
+    """BASELINE config 3 as one unit (config3_step.py): frozen separable glb_backbone forward + backbone and backbone_sec
+    forward/backward + invariant head + batched per-slot pose heads + one chamfer pair forward/backward + Adam."""
+    import synth_clouds
+    import config3_step as C3
+    from vgtk import _hip
+    torch.manual_seed(2913)
+    model = C3.Config3Model(points).to(dev)
+    opt = torch.optim.Adam(model.trained_parameters(), lr=1e-4)
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, batch, points)
+    xyz, pose = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(pose_np).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model(xyz, pose)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    _hip.KERNEL_TIMES = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
+    kern = summarize_by_kernel(records)
+    flops = C3.algorithmic_flops(batch, points, synth_clouds.backbone_layers(points))
+    top = sorted(kern.items(), key=lambda kv: -kv[1]['ms'])[:6]
+    out = {'workload': f'{batch} x {points}-pt clouds: 3 separable blocks forward (frozen, no_grad) + 2 x 3 inter blocks forward+backward + '
+                       f'InvPPOutBlockOurs + {C3.SLOTS} batched SO3OutBlockRTWithMaskSep heads + chamfer [{batch},{points},3] forward+backward + Adam',
+           'value': batch * steps / dt, 'unit': 'point-clouds/sec', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': warmup,
+           'loss': float(loss), 'peak_memory_GB': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+           'whole_step': {'algorithmic_flops': flops, 'achieved_TFLOPs': flops / (dt / steps) / 1e12,
+                          'frac_of_fp32_mfma_peak': flops / (dt / steps) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+           'kernel_time_share': sum(k['ms'] for k in kern.values()) / (dt * 1e3),
+           'top_kernels_ms_per_step': {n: round(k['ms'] / steps, 2) for n, k in top}}
+    del model, opt, xyz, pose
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -343,7 +427,7 @@ def main():
     ap.add_argument('--separable', action='store_true', help='the separable (inter + intra + skip) glb_backbone instead of the inter backbone; implies --fwd-only as in the reference')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plan-points', type=int, default=None, help='radii / sigmas of the backbone built for this input size (default: --points)')
-    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configurations')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configurations (config 3 composite included)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -372,6 +456,10 @@ def main():
             m.sync = world > 1
     conv_params = [p for p in model.parameters()]
     opt = torch.optim.Adam(conv_params, lr=1e-4)
+    # gradient all-reduce launched from autograd hooks: the deepest layer's bucket travels while the shallower layers'
+    # backward kernels still run (vgtk/sharding.py); a no-op on one GPU
+    reducer = sharding.GradientReducer(conv_params)
+    n_items = args.batch * world
     xyz_np, _, pose_np = synth_clouds.laptop_batch(rank * args.batch, args.batch, args.points)
     xyz = torch.from_numpy(xyz_np).to(dev)
     pose = torch.from_numpy(pose_np).to(dev)
@@ -381,16 +469,16 @@ def main():
             with torch.no_grad():
                 feats = model(xyz, pose)
                 R, T = model.hypotheses(feats)
-                sharding.all_gather_pose_hypotheses(R, T)
+                sharding.all_gather_pose_hypotheses(R, T, n_items=n_items)
             return
         opt.zero_grad(set_to_none=True)
         feats = model(xyz, pose)
         with torch.no_grad():
             R, T = model.hypotheses(feats)
-        allR, allT = sharding.all_gather_pose_hypotheses(R, T)
+        allR, allT = sharding.all_gather_pose_hypotheses(R, T, n_items=n_items)
         loss = StandInLoss.apply(feats, model.pose_head.weight, model.pose_head.bias)
         loss.backward()
-        sharding.all_reduce_gradients(conv_params)
+        reducer.finish()
         opt.step()
 
     def barrier():
@@ -415,17 +503,16 @@ def main():
 
     if rank == 0:
         kern, shapes = summarize_kernels(records)
-        dom_name = max(kern, key=lambda k: kern[k]['ms'])
-        dom = kern[dom_name]
-        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 and dom['flops'] > 0 else 0.0
-        # fabric-side bytes per launch of the dominant entry, from the rocprofv3 FETCH_SIZE /
-        # WRITE_SIZE passes committed under profiles/ (collected at the default workload only)
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) else 'r01_p_pmc_traffic.json')
-        if os.path.exists(pmc) and args.points == 4096 and args.batch == 8 and not args.fwd_only:
-            d = json.load(open(pmc))['per_launch_bytes'].get(dom_name)
-            if d:
-                traffic = d['fetch'] + d['write']
+        by_kernel = summarize_by_kernel(records)
+        default_cfg = args.points == 4096 and args.batch == 8 and not args.fwd_only and not args.separable and args.plan_points is None
+        # the dominant KERNEL (template instantiation, as rocprofv3 lists them) among those doing matrix work
+        dom_name = max((k for k in by_kernel if by_kernel[k]['flops'] > 0), key=lambda k: by_kernel[k]['ms'])
+        total_kernel_ms = max(sum(k['ms'] for k in by_kernel.values()), 1e-9)
+        roof = roofline_object(dom_name, by_kernel[dom_name], default_cfg)
+        roof['share_of_kernel_time'] = by_kernel[dom_name]['ms'] / total_kernel_ms
+        roof['flops_definition'] = ('algorithmic: 2*M*N*K*batch for GEMMs; 2*channels*K(24)*P*NN*A*B for the grouping kernels '
+                                    '(the MFMA tiles pad K 24->32 and the anchors 60->64, not counted)')
+        step_flops = sum(k['flops'] for k in by_kernel.values()) / args.steps
         clouds = args.batch * world * args.steps
         line = {
             'metric': 'point-clouds/sec (4096 pts, 60 anchors) ' + ('fwd' if args.fwd_only else 'fwd+bwd'),
@@ -437,39 +524,26 @@ def main():
                                    + f' 1->64->128->512 (NN=64,K=24,A=60), '
                                    + ('forward' if args.fwd_only else 'forward+backward+Adam'),
                        'clouds_per_gpu': args.batch, 'points': args.points, 'anchors': NA,
-                       'sharding': f'clouds x{world}, pose all-gather + 1 gradient all-reduce' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'kernel': KERNEL_OF_ENTRY.get(dom_name, dom_name), 'entry': dom_name,
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'flops_definition': 'algorithmic: 2*M*N*K*batch for GEMMs; 2*channels*K(24)*P*NN*A*B for '
-                                             'the grouping kernels (the MFMA tiles pad K 24->32, not counted)',
-                         'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
-                         'share_of_kernel_time': dom['ms'] / max(sum(k['ms'] for k in kern.values()), 1e-9)},
+                       'sharding': f'clouds x{world}, pose all-gather + gradient all-reduce overlapped with the backward' if world > 1 else 'single GPU'},
+            'roofline': roof,
+            # the same object for every kernel that takes more than 5 % of the kernel time and does matrix work
+            'kernel_rooflines': [dict(roofline_object(n, k, default_cfg), share_of_kernel_time=k['ms'] / total_kernel_ms)
+                                 for n, k in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms'])
+                                 if k['flops'] > 0 and k['ms'] / total_kernel_ms > 0.05],
+            'whole_step': {'algorithmic_flops_per_gpu': step_flops, 'achieved_TFLOPs_per_gpu': step_flops / (dt / args.steps) / 1e12,
+                           'frac_of_fp32_mfma_peak': step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                           'kernel_time_share_of_step': total_kernel_ms / (dt * 1e3)},
             'kernels': {n: {'ms_per_step': k['ms'] / args.steps, 'launches_per_step': k['launches'] / args.steps,
                             'tflops': (k['flops'] / (k['ms'] * 1e-3) / 1e12) if k['flops'] > 0 else None}
                         for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])},
             'dominant_kernel': dom_name,
             'launch_shapes': shapes[:8],
         }
-        # the contraction GEMM and the backward grouping are within a millisecond of each other: the same object for
-        # whichever of the two is NOT the dominant entry of this run
-        for other in ('eap_so3_inter_group_inv_f32', 'eap_gemm_dma_f32'):
-            if other != dom_name and other in kern and kern[other]['flops'] > 0:
-                k = kern[other]
-                ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
-                tr = None
-                if os.path.exists(pmc) and args.points == 4096 and args.batch == 8 and not args.fwd_only:
-                    d = json.load(open(pmc))['per_launch_bytes'].get(other)
-                    tr = d['fetch'] + d['write'] if d else None
-                line['roofline_second_kernel'] = {'bound': 'mfma', 'kernel': KERNEL_OF_ENTRY.get(other, other), 'entry': other, 'achieved': ach,
-                                                  'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': tr,
-                                                  'launches': k['launches'], 'avg_launch_ms': k['ms'] / max(k['launches'], 1)}
-                break
-        default_cfg = args.points == 4096 and args.batch == 8 and not args.fwd_only and not args.separable and args.plan_points is None
         if world == 1 and default_cfg and not args.no_other_configs:
             del model, opt, xyz, pose
             torch.cuda.empty_cache()
             line['other_configs'] = other_configs(dev)
+            line['config3_step'] = config3_step(dev)
         if world == 1 and not args.fwd_only:
             line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
         if world == 1 and not args.no_cpu_baseline:

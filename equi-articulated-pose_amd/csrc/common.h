@@ -9,6 +9,9 @@
 namespace eap {
 
 void set_error(const char *msg);
+// name (with template arguments, as rocprofv3 prints it) of the dominant kernel the calling thread launched last -- set by
+// the launchers of the hot kernels, read by bench.py through eap_last_kernel() to attribute time per KERNEL, not per entry
+void set_kernel(const char *name);
 
 static inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -337,6 +337,11 @@ int launch_one(DmaArgs g, int zcount, hipStream_t s) {
                           "gemm_dma_f32 shared memory");
     if (e) return e;
     hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, zcount), dim3(NT), shmem, s, g);
+    {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "gemm_dma_f32_kernel<%d, %d, %d, %d, %s, %s>", WM, WN, MI, NI, AKM ? "true" : "false", BKN ? "true" : "false");
+        eap::set_kernel(nm);
+    }
     return eap::check_launch("gemm_dma_f32");
 }
 

@@ -434,6 +434,7 @@ int launch(int blocked, int b, int C, int PF, int na, int fpitch, int ks, int R,
     dim3 grid((R + RPB - 1) / RPB * g.AG, (C + CB - 1) / CB, b);
     hipLaunchKernelGGL(kern, grid, dim3(TM), g.shmem, s, C, PF, na, fpitch, ks, R, nn, ent_stride, g.AG, g.gsz, RPB, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
+    eap::set_kernel(LISTS ? "so3_group_lists_kernel<true, 0>" : blocked == 2 ? "so3_group_lists_kernel<false, 2>" : blocked == 1 ? "so3_group_lists_kernel<false, 1>" : "so3_group_lists_kernel<false, 0>");
     return eap::check_launch(what);
 }
 

@@ -371,6 +371,7 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
     dim3 grid((R + RPB - 1) / RPB * AG, (C + CB - 1) / CB, b);
     hipLaunchKernelGGL(kern, grid, dim3(TM), SHMEM, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
+    eap::set_kernel(LISTS ? "so3_group_lists2_kernel<true, 0>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>");
     return eap::check_launch(what);
 }
 

@@ -25,6 +25,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH)
 lib.eap_last_error.restype = ctypes.c_char_p
+lib.eap_last_kernel.restype = ctypes.c_char_p
 lib.eap_gemm_f32_reduce_workspace.restype = ctypes.c_int64
 lib.eap_so3_inter_group_bwd_workspace.restype = ctypes.c_int64
 lib.eap_inter_zpconv_fwd_workspace.restype = ctypes.c_int64
@@ -67,9 +68,12 @@ def call(name, ref_tensor, *args, tag=None):
             stream = torch.cuda.current_stream(ref_tensor.device)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
+            lib.eap_last_kernel()        # (clear)
             e0.record(stream)
             rc = fn(*args, stream_of(ref_tensor))
             e1.record(stream)
+            if tag is not None:          # the HIP kernel (with its template arguments) this entry just launched
+                tag = dict(tag, kernel=lib.eap_last_kernel().decode() or name)
             KERNEL_TIMES.append((name, tag, e0, e1))
         else:
             rc = fn(*args, stream_of(ref_tensor))

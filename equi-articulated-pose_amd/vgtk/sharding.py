@@ -30,19 +30,46 @@ def shard_range(n_items, rank=None, world=None):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_pose_hypotheses(slot_R, slot_T, group=None):
-    """slot_R [B_loc,S,A,3,3], slot_T [B_loc,S,A,3] -> the same for all clouds of the job
-    ([B_loc*world, ...], rank-major).  Every rank must pass the same B_loc."""
+def shard_sizes(n_items, world=None):
+    """Number of clouds every rank holds under shard_range's contiguous split."""
+    if world is None:
+        world = dist.get_world_size() if is_distributed() else 1
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+def all_gather_pose_hypotheses(slot_R, slot_T, n_items=None, group=None):
+    """slot_R [B_loc,S,A,3,3], slot_T [B_loc,S,A,3] -> the same for all clouds of the job, rank-major
+    ([sum of B_loc, ...]).  Ranks may hold DIFFERENT numbers of clouds (shard_range hands out uneven shards when the
+    batch does not divide): every rank's block is padded to the largest shard for the one all_gather_into_tensor and the
+    padding is dropped afterwards.  The shard sizes follow from `n_items` (the job's cloud count) without communication;
+    without it they are exchanged first (one int per rank)."""
     if not is_distributed():
         return slot_R, slot_T
     world = dist.get_world_size(group)
     b = slot_R.shape[0]
-    flat = torch.cat([slot_R.reshape(b, -1), slot_T.reshape(b, -1)], dim=1).contiguous()
-    out = torch.empty(world * b, flat.shape[1], dtype=flat.dtype, device=flat.device)
+    if n_items is not None:
+        sizes = shard_sizes(n_items, world)
+        if sizes[dist.get_rank(group)] != b:
+            raise ValueError(f'all_gather_pose_hypotheses: this rank holds {b} clouds, shard_range({n_items}) says {sizes[dist.get_rank(group)]}')
+    else:
+        mine = torch.tensor([b], dtype=torch.int64, device=slot_R.device)
+        every = torch.empty(world, dtype=torch.int64, device=slot_R.device)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        sizes = every.tolist()
+    bmax = max(sizes)
+    flat = torch.cat([slot_R.reshape(b, -1), slot_T.reshape(b, -1)], dim=1)
+    if b < bmax:
+        flat = torch.cat([flat, flat.new_zeros(bmax - b, flat.shape[1])], dim=0)
+    flat = flat.contiguous()
+    out = torch.empty(world * bmax, flat.shape[1], dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)
-    nR = slot_R[0].numel()
-    R = out[:, :nR].reshape(world * b, *slot_R.shape[1:])
-    Tt = out[:, nR:].reshape(world * b, *slot_T.shape[1:])
+    if min(sizes) != bmax:
+        keep = torch.cat([torch.arange(r * bmax, r * bmax + n, device=out.device) for r, n in enumerate(sizes)])
+        out = out.index_select(0, keep)
+    nR = slot_R[0].numel() if b else slot_R.new_empty((1,) + tuple(slot_R.shape[1:]))[0].numel()
+    total = sum(sizes)
+    R = out[:, :nR].reshape(total, *slot_R.shape[1:])
+    Tt = out[:, nR:].reshape(total, *slot_T.shape[1:])
     return R, Tt
 
 
@@ -62,3 +89,76 @@ def all_reduce_gradients(params, average=True, group=None):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+class GradientReducer:
+    """Gradient all-reduce overlapped with the backward pass: the parameters are packed, in REVERSE registration order
+    (the order their gradients become ready: the deepest layer first), into buckets of at most `bucket_bytes`; a
+    bucket's all-reduce is launched asynchronously the moment its last gradient has been accumulated
+    (Tensor.register_post_accumulate_grad_hook), so it travels over xGMI while the earlier layers' backward kernels still
+    run; finish() waits for the buckets and writes the averaged gradients back.  With the 3-block backbone the 6 MB
+    deepest-layer bucket is in flight during the ~15 ms of the two shallower layers' backward.
+
+        reducer = GradientReducer(params)        # once
+        loss.backward(); reducer.finish(); optimizer.step()
+
+    Single-process runs register nothing and finish() is a no-op."""
+
+    def __init__(self, params, bucket_bytes=8 << 20, average=True, group=None):
+        self.group, self.average = group, average
+        self.buckets, self._handles = [], []
+        if not is_distributed():
+            return
+        params = [p for p in params if p.requires_grad]
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._add_bucket(cur)
+
+    def _add_bucket(self, params):
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        bucket = {'params': params, 'flat': flat, 'pending': len(params), 'work': None, 'offsets': []}
+        off = 0
+        for p in params:
+            bucket['offsets'].append(off)
+            off += p.numel()
+        for p, o in zip(params, bucket['offsets']):
+            self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket, o)))
+        self.buckets.append(bucket)
+
+    def _make_hook(self, bucket, offset):
+        def hook(p):
+            bucket['flat'][offset:offset + p.numel()].copy_(p.grad.reshape(-1))
+            bucket['pending'] -= 1
+            if bucket['pending'] == 0:
+                bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return hook
+
+    def finish(self):
+        """Wait for every bucket and write the reduced gradients back.  A parameter that received no gradient in this
+        backward (unused in the step) contributes zeros: its bucket is reduced here, synchronously."""
+        world = dist.get_world_size(self.group) if self.buckets else 1
+        for bucket in self.buckets:
+            if bucket['work'] is None:
+                for p, o in zip(bucket['params'], bucket['offsets']):
+                    if bucket['pending'] and p.grad is None:
+                        bucket['flat'][o:o + p.numel()].zero_()
+                bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            bucket['work'].wait()
+            if self.average:
+                bucket['flat'] /= world
+            for p, o in zip(bucket['params'], bucket['offsets']):
+                if p.grad is not None:
+                    p.grad.copy_(bucket['flat'][o:o + p.numel()].view_as(p.grad))
+            bucket['pending'], bucket['work'] = len(bucket['params']), None
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

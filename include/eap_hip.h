@@ -31,6 +31,9 @@ extern "C" {
 typedef void *eap_stream_t;
 
 const char *eap_last_error(void);
+/* Name, with its template arguments, of the dominant HIP kernel the calling thread's last entry launched ("" when the
+ * entry does not record one); reading clears it.  Lets a profiler-less caller (bench.py) attribute launch times to kernels. */
+const char *eap_last_kernel(void);
 int eap_abi_version(void);
 
 /* ---- grouping (vgtk/vgtk/cuda/grouping_cuda.cpp) ------------------------------------------ */

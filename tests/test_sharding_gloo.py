@@ -103,3 +103,62 @@ def test_batchnorm_statistics_exchange_world_size_2(tmp_path):
         np.testing.assert_allclose(r['var'], r['ref_var'], rtol=1e-9)
         assert r['total'] == 5 * 40
         np.testing.assert_allclose(r['sg'], np.arange(6) * 3.0)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, os.path.join(root, 'equi-articulated-pose_amd'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vgtk import sharding
+    n_items, S, A = 7, 2, 60                                        # 7 clouds over 2 ranks: shards of 4 and 3
+    start, stop = sharding.shard_range(n_items)
+    gen = torch.Generator().manual_seed(5)
+    R_all = torch.randn(n_items, S, A, 3, 3, generator=gen)
+    T_all = torch.randn(n_items, S, A, 3, generator=gen)
+    a1, b1 = sharding.all_gather_pose_hypotheses(R_all[start:stop], T_all[start:stop], n_items=n_items)    # sizes from the split
+    a2, b2 = sharding.all_gather_pose_hypotheses(R_all[start:stop], T_all[start:stop])                       # sizes exchanged
+    ok = all(torch.equal(x, y) for x, y in ((a1, R_all), (b1, T_all), (a2, R_all), (b2, T_all)))
+    # overlapped gradient reduction: three "layers", a bucket size that splits them 2 + 1, one parameter unused this step
+    torch.manual_seed(3)
+    layers = [torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3)]
+    unused = torch.nn.Parameter(torch.ones(3))
+    params = [p for l in layers for p in l.parameters()] + [unused]
+    reducer = sharding.GradientReducer(params, bucket_bytes=4 * (4 * 3 + 3 + 5 * 4 + 4))
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(10 + rank))
+    y = x
+    for l in layers:
+        y = torch.tanh(l(y))
+    y.square().sum().backward()
+    local = [p.grad.clone() for p in params[:-1]]
+    reducer.finish()
+    grads = [p.grad.clone() for p in params[:-1]]
+    # second step on the same reducer (hooks re-arm)
+    for p in params:
+        p.grad = None
+    y = x * 2.0
+    for l in layers:
+        y = torch.tanh(l(y))
+    y.sum().backward()
+    local2 = [p.grad.clone() for p in params[:-1]]
+    reducer.finish()
+    grads2 = [p.grad.clone() for p in params[:-1]]
+    np.savez(os.path.join(out_dir, f'u{rank}.npz'), ok=ok, n_buckets=len(reducer.buckets), unused_grad_is_none=unused.grad is None,
+             **{f'l{i}': g.numpy() for i, g in enumerate(local)}, **{f'g{i}': g.numpy() for i, g in enumerate(grads)},
+             **{f'm{i}': g.numpy() for i, g in enumerate(local2)}, **{f'h{i}': g.numpy() for i, g in enumerate(grads2)})
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_and_overlapped_gradient_reduction(tmp_path):
+    """7 clouds over 2 ranks (shards of 4 and 3): the pose all-gather returns all 7, rank-major, whether the shard sizes
+    come from the split or are exchanged; GradientReducer (all-reduce launched from autograd hooks while the backward
+    is still running) ends with the rank-averaged gradients, two steps in a row."""
+    world = 2
+    mp.spawn(_uneven_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(tmp_path / f'u{i}.npz')) for i in range(world)]
+    for i in range(world):
+        assert bool(r[i]['ok']) and int(r[i]['n_buckets']) >= 2 and bool(r[i]['unused_grad_is_none'])
+        for k in range(6):
+            np.testing.assert_allclose(r[i][f'g{k}'], 0.5 * (r[0][f'l{k}'] + r[1][f'l{k}']), rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(r[i][f'h{k}'], 0.5 * (r[0][f'm{k}'] + r[1][f'm{k}']), rtol=1e-6, atol=1e-7)
