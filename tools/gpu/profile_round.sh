@@ -1,0 +1,33 @@
+#!/bin/bash
+# tools/gpu/profile_round.sh TAG [quick] -- one GPU session on the box (run through gpurun): the GPU test suite, smoke, the
+# driver's bench line, rocprofv3 kernel statistics of the same command and the counter passes MI355X_MICROARCH.md
+# prescribes (separate --pmc runs, --kernel-trace only).  Everything lands in gpurun_out/TAG/; tools/pmc_traffic.py
+# turns the counter CSVs into gpurun_out/TAG/TAG_pmc_traffic.json (copy into profiles/).  `quick` skips the test suite and
+# the long bench.
+set -u
+export TMPDIR=/tmp
+TAG=$1
+QUICK=${2:-}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+if [ -z "$QUICK" ]; then
+  ( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 ) > $O/pytest.log 2>&1
+  echo "pytest rc $?" >> $O/pytest.log
+  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+  timeout 1500 python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+fi
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/bench_under_rocprof.json 2> $O/prof.err
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
+  tag=$(echo $c | tr ' ' '_')
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$tag -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $O/pmc_$tag.log 2>&1
+done
+cd $R
+python tools/pmc_traffic.py $O $O $TAG > $O/pmc_summary.txt 2>&1
+cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/bench_kernel_stats.csv 2>/dev/null
+# the counter CSVs are large: keep the summaries only
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum_TCC_MISS_sum $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES_SQ_BUSY_CU_CYCLES_GRBM_GUI_ACTIVE_SQ_WAVES $O/prof
+[ -z "$QUICK" ] && tail -5 $O/pytest.log && tail -2 $O/smoke.log
+head -12 $O/bench_kernel_stats.csv | cut -c1-160
+tail -60 $O/pmc_summary.txt
