@@ -401,13 +401,15 @@ def config3_step(dev, batch=16, points=4096, steps=2, warmup=1):
     dt = time.perf_counter() - t0
     records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
     kern = summarize_by_kernel(records)
-    flops = C3.algorithmic_flops(batch, points, synth_clouds.backbone_layers(points))
+    # flops of the launches actually made (each C-ABI launch carries its algorithmic count; the re-associated backward
+    # does less than the textbook 2 x forward, and the torch layers of the stand-ins are not counted): a LOWER bound
+    flops = sum(k['flops'] for k in kern.values()) / steps
     top = sorted(kern.items(), key=lambda kv: -kv[1]['ms'])[:6]
     out = {'workload': f'{batch} x {points}-pt clouds: 3 separable blocks forward (frozen, no_grad) + 2 x 3 inter blocks forward+backward + '
                        f'InvPPOutBlockOurs + {C3.SLOTS} batched SO3OutBlockRTWithMaskSep heads + chamfer [{batch},{points},3] forward+backward + Adam',
            'value': batch * steps / dt, 'unit': 'point-clouds/sec', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': warmup,
            'loss': float(loss), 'peak_memory_GB': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-           'whole_step': {'algorithmic_flops': flops, 'achieved_TFLOPs': flops / (dt / steps) / 1e12,
+           'whole_step': {'algorithmic_flops_of_the_hot_path_launches': flops, 'textbook_flops': C3.algorithmic_flops(batch, points, synth_clouds.backbone_layers(points)), 'achieved_TFLOPs': flops / (dt / steps) / 1e12,
                           'frac_of_fp32_mfma_peak': flops / (dt / steps) / 1e12 / PEAK_F32_MFMA_TFLOPS},
            'kernel_time_share': sum(k['ms'] for k in kern.values()) / (dt * 1e3),
            'top_kernels_ms_per_step': {n: round(k['ms'] / steps, 2) for n, k in top}}

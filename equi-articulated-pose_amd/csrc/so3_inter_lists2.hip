@@ -63,12 +63,21 @@ __device__ inline void glds4(const void *gsrc, unsigned lds_dst) {
 }
 __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Timing ablations (WRONG RESULTS), compiled only with `make ABLATION=1` and selected by EAP_LISTS2_DEBUG (bit mask):
+// 1 no feature DMA after the prologue, 2 constant weights (no weight evaluation), 4 no row-end stores, 8 no chunk barrier
+// (only together with 1), 16 no per-k-step LDS operand reads.  tools/lists2_ablation.py
+#ifdef EAP_ABLATION
+#define ABL(bit) ((dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
 // LISTS = true : rows / off / cnt describe variable-length entry lists (backward);
 // LISTS = false: row r of cloud b owns entries [ (b*R + r)*nn, +nn ) (forward: its neighbours).
 // LAYOUT of the output: 0 = [b,c,k,row,a] (reference), 2 = transposed [row*na+a][c*ks+k]
 template <bool LISTS, int LAYOUT>
 __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
-    int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, int AG, int RPB, float inv_sigma,
+    int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, int AG, int RPB, int ag_major, int dbg, float inv_sigma,
     const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
     const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
     const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
@@ -79,15 +88,29 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     const int nrun = (R + RPB - 1) / RPB;
     const int ny = gridDim.y, nsl = ny * gridDim.z, per_slice = nrun * AG;
     int qd = blockIdx.x, sl = blockIdx.y + ny * blockIdx.z;
-    if ((nsl & 7) == 0) {
+    int run, ag;
+    if (ag_major && ((nsl * AG) & 7) == 0) {
+        // an XCD owns whole (slice, cloud, ANCHOR GROUP) triples: the rows of a cloud that its resident workgroups walk
+        // at the same time are then 64-byte pieces, a quarter of the (slice, cloud) working set per point -- four times
+        // as many points of the walk stay in the 4 MB L2, and all 64 resident workgroups (not 16 x 4) share them
         const unsigned lin = blockIdx.x + (unsigned)per_slice * (blockIdx.y + (unsigned)ny * blockIdx.z);
         const unsigned j = lin >> 3;
-        sl = (int)((lin & 7u) + 8u * (j / (unsigned)per_slice));
-        qd = (int)(j % (unsigned)per_slice);
+        const unsigned sl2 = (lin & 7u) + 8u * (j / (unsigned)nrun);
+        run = (int)(j % (unsigned)nrun);
+        ag = (int)(sl2 % (unsigned)AG);
+        sl = (int)(sl2 / (unsigned)AG);
     } else {
-        qd = xcd_point(blockIdx.x, per_slice);
+        if ((nsl & 7) == 0) {
+            const unsigned lin = blockIdx.x + (unsigned)per_slice * (blockIdx.y + (unsigned)ny * blockIdx.z);
+            const unsigned j = lin >> 3;
+            sl = (int)((lin & 7u) + 8u * (j / (unsigned)per_slice));
+            qd = (int)(j % (unsigned)per_slice);
+        } else {
+            qd = xcd_point(blockIdx.x, per_slice);
+        }
+        run = qd / AG;
+        ag = qd - run * AG;
     }
-    const int run = qd / AG, ag = qd - run * AG;
     const int r_begin = run * RPB, rows_blk = min(RPB, R - r_begin);
     const int cy = sl % ny, bi = sl / ny, c0 = cy * CB;
     if (nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) != 0) return;   // permuted cloud: not ours
@@ -167,7 +190,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
         }
     };
     auto issue = [&](int u, int buf) {
-        if (d_valid)
+        if (d_valid && !ABL(1))
             glds16s(fb, src_off[u], __builtin_amdgcn_readfirstlane(lds_f + (unsigned)buf * BUF_BYTES + (unsigned)(u * TM + wave_u * 64) * 16u));
     };
 
@@ -192,6 +215,10 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
         return __float_as_int(dead ? -1e30f : b);
     };
     auto gather = [&](const float4 *fab, int gslot, int bases, int s, float4 &fa, float4 &fb1, float4 &g, float &bk) {
+        if (ABL(16)) {
+            fa = make_float4(1.f, 2.f, 3.f, 4.f); fb1 = fa; g = make_float4(0.01f * (float)s, 0.02f, 0.03f, 0.f); bk = 0.5f;
+            return;
+        }
         fa = fab[s * STEP_F4];
         fb1 = fab[s * STEP_F4 + TILE_F4];
         g = s_g[gslot * NBK + 2 * s + lh];
@@ -205,11 +232,16 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
         const float fa1[APW] = {fv1.x, fv1.y, fv1.z, fv1.w};
         f32x2 wv[APW / 2];
         const float bkc = bk + kcl;
+        if (ABL(2)) {
+            wv[0] = kxp[0];
+            wv[1] = kxp[1];
+        } else {
 #pragma unroll
-        for (int j = 0; j < APW / 2; ++j) {
-            f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], decltype(kcu)::value ? (f32x2){bkc, bkc} : kcp[j] + (f32x2){bk, bk});
-            x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
+            for (int j = 0; j < APW / 2; ++j) {
+                f32x2 x = __builtin_elementwise_fma((f32x2){g.x, g.x}, kxp[j], decltype(kcu)::value ? (f32x2){bkc, bkc} : kcp[j] + (f32x2){bk, bk});
+                x = __builtin_elementwise_fma((f32x2){g.y, g.y}, kyp[j], x);
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp\n\ts_nop 1" : "=v"(wv[j]) : "v"((f32x2){g.z, g.w}), "v"(kzp[j]), "v"(x));
+            }
         }
         __builtin_amdgcn_s_setprio(3);
         if (first) {
@@ -249,7 +281,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     const unsigned lane_off = (unsigned)((size_t)(4 * lh) * o_cs + (size_t)min(lk, ks - 1) * o_ks) + (unsigned)al_beg;
     float *obb = out + (size_t)bi * C * o_cs;
     auto store_row = [&](int row) {
-        if (active && lk < ks) {
+        if (active && lk < ks && !ABL(4)) {
             if (LAYOUT == 2) {
                 // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix the contraction GEMM reads)
                 const size_t CK = (size_t)C * ks;
@@ -328,7 +360,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
                 ch_row = 0;                                                                                           \
                 ++row;                                                                                                \
             }                                                                                                         \
-            __syncthreads();                                                                                          \
+            if (!ABL(8)) __syncthreads();                                                                             \
             const int gt = g0; g0 = g1; g1 = g2; g2 = gt;                                                             \
         }                                                                                                             \
         if (nchunk == 0) {                                                                                            \
@@ -354,6 +386,8 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 
 constexpr size_t SHMEM = 2 * BUF_BYTES + 16 * 3 * NBK + 16 * NBK;
 
+int g_xcd_map_fwd = 1, g_xcd_map_inv = 1;       // eap_so3_group_lists_xcd_map
+
 template <bool LISTS>
 int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
             const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
@@ -369,7 +403,12 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
     const int AG = (na + GSZ - 1) / GSZ;
     const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
     dim3 grid((R + RPB - 1) / RPB * AG, (C + CB - 1) / CB, b);
-    hipLaunchKernelGGL(kern, grid, dim3(TM), SHMEM, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, 1.0f / sigma, F,
+#ifdef EAP_ABLATION
+    const int dbg = getenv("EAP_LISTS2_DEBUG") ? atoi(getenv("EAP_LISTS2_DEBUG")) : 0;
+#else
+    const int dbg = 0;
+#endif
+    hipLaunchKernelGGL(kern, grid, dim3(TM), SHMEM, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, (LISTS ? g_xcd_map_inv : g_xcd_map_fwd) == 2, dbg, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
     eap::set_kernel(LISTS ? "so3_group_lists2_kernel<true, 0>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>");
     return eap::check_launch(what);
@@ -384,6 +423,14 @@ static int g_tiles = 2;       // eap_so3_group_lists_tiles
 extern "C" int eap_so3_group_lists_tiles(int tiles) {
     if (tiles == 1 || tiles == 2) g_tiles = tiles;
     return g_tiles;
+}
+
+// Which unit of work an XCD (one L2) owns in the two-tile kernel: 1 = whole (channel slice, cloud) pairs, 2 = whole
+// (channel slice, cloud, anchor group) triples.  `which` 0 = forward, 1 = backward (inverse lists); mode 0 = query.
+extern "C" int eap_so3_group_lists_xcd_map(int which, int mode) {
+    int &m = which ? g_xcd_map_inv : g_xcd_map_fwd;
+    if (mode == 1 || mode == 2) m = mode;
+    return m;
 }
 
 namespace eap {

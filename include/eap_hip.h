@@ -194,6 +194,9 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
  * count fills 64-channel blocks (csrc/so3_inter_lists2.hip), 1 = always the one-tile kernel (csrc/so3_inter_lists.hip);
  * 0 = query.  Returns the value in force.  Same results either way (tests compare them); A/B timing and tests only. */
 int eap_so3_group_lists_tiles(int tiles);
+/* Block -> XCD map of the two-tile kernel: mode 1 = an XCD (one L2) owns whole (channel slice, cloud) pairs, 2 = whole
+ * (channel slice, cloud, anchor group) triples; which = 0 forward, 1 backward; mode 0 = query.  Same results either way. */
+int eap_so3_group_lists_xcd_map(int which, int mode);
 
 /* so3_inter_group_inv: the feature gradient of the whole inter convolution by re-association,
  *   dF[c,q,a'] = sum_{o,k} W[o,(c,k)] Z[o,k,q,a'],

@@ -2,7 +2,7 @@
 unit: config3_step.Config3Model -- frozen separable glb_backbone forward, backbone + backbone_sec forward/backward,
 invariant head -> labels, batched per-slot pose heads -> R, T, one chamfer pair forward/backward, Adam -- at a reduced
 size (the bench leg `config3_step` runs it at 16 x 4096).  Checked here: every trained parameter receives a finite
-gradient, the frozen stage does not, the loss goes down over a few optimiser steps, the step is bit-reproducible, and the
+gradient, the frozen stage does not, the loss goes down over a few optimiser steps, the forward is bit-reproducible, and the
 piece config 3 adds over the other configurations -- the separable block with its intra conv at C = 512 on a 4096-point
 cloud -- agrees with the oracle on a slab of points."""
 import numpy as np
@@ -51,7 +51,10 @@ def test_config3_composite_step_trains():
             hist.append(loss.item())
         losses.append(hist)
     assert losses[0][-1] < losses[0][0], losses[0]
-    assert losses[0] == losses[1], 'the composite step is not reproducible run to run'
+    # the hot-path kernels are atomics-free; torch's own gather / index backward kernels in the stand-in layers use
+    # atomics, so only the first step (pure forward) is bit-reproducible, later ones to rounding
+    assert losses[0][0] == losses[1][0], 'the forward of the composite step is not reproducible run to run'
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-4)
 
 
 def test_separable_block_at_4096_points_full_width_vs_oracle():

@@ -37,8 +37,9 @@ for layer in (2, 1):
     fl = 2.0 * B * o * KS * P * NN * NA
     cn = cnt.flatten().float()
     print(f'layer {layer} O={o} rcap={rcap}: list lengths mean {cn[cn > 0].mean().item():.0f} max {cn.max().item():.0f} min {cn[cn > 0].min().item():.0f}', flush=True)
-    for tiles in (1, 2):        # csrc/so3_inter_lists.hip (one channel tile per wave) / so3_inter_lists2.hip (two)
+    for tiles, xmap in ((1, 1), (2, 1), (2, 2)):   # so3_inter_lists.hip (one channel tile per wave) / so3_inter_lists2.hip (two), XCD owns (slice, cloud) / (slice, cloud, anchor group)
         _hip.lib.eap_so3_group_lists_tiles(tiles)
+        _hip.lib.eap_so3_group_lists_xcd_map(1, xmap)
         for ep in variants.values():
             run(ep)
         torch.cuda.synchronize()
@@ -50,5 +51,6 @@ for layer in (2, 1):
                 res[k].append(e0.elapsed_time(e1))
         for k, v in res.items():
             v.sort()
-            print(f'layer {layer} O={o} tiles/wave {tiles}: rows {k:9s}: median {v[2]:.2f} ms  min {v[0]:.2f} ms  {fl / v[2] / 1e9:.1f} TFLOP/s algorithmic = {fl / v[2] / 1e9 / 157.3:.3f} of peak', flush=True)
+            print(f'layer {layer} O={o} tiles/wave {tiles} xcd map {xmap}: rows {k:9s}: median {v[2]:.2f} ms  min {v[0]:.2f} ms  {fl / v[2] / 1e9:.1f} TFLOP/s algorithmic = {fl / v[2] / 1e9 / 157.3:.3f} of peak', flush=True)
     _hip.lib.eap_so3_group_lists_tiles(2)
+    _hip.lib.eap_so3_group_lists_xcd_map(1, 1)

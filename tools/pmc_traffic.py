@@ -23,7 +23,8 @@ def key_of(name):
         elif ch == '(' and depth == 0:
             break
         out += ch
-    out = re.sub(r',\s*0>$', '>', out)      # trailing default template argument of the GEMM (ablation switch)
+    if out.startswith('gemm_dma_f32_kernel'):
+        out = re.sub(r',\s*0>$', '>', out)      # trailing default template argument of the GEMM (ablation switch)
     return out if any(w in out for w in WANT) else None
 
 
