@@ -195,6 +195,8 @@ __global__ __launch_bounds__(TM, 2) void zpconv_mfma_kernel(
         const float4 v = *reinterpret_cast<const float4 *>(tile0 + j * XT + x_rd);
         const int ch = 32 * (I >> 4) + (I & 3) + 8 * ((I & 15) >> 2);
         char *rowp = reinterpret_cast<char *>(ob + (size_t)row * na + (size_t)ch * o_cs);       // uniform
+        // (sc1 write-through stores, which drop the written lines from the XCD's L2, were measured here: 10.95 vs 10.90 ms,
+        // profiles/r03_store_flavour_experiment.txt -- the output stream is not what evicts the weight lines)
         if (x_on && ch < x_cmax) *reinterpret_cast<float4 *>(rowp + x_off) = v;
     };
 
@@ -389,7 +391,7 @@ int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, 
     // EAP_ZP_DEBUG (timing ablations only: wrong results): 1 = no output stores, 2 = every weight load hits the same
     // lines, 4 = no feature DMA
 #ifdef EAP_ABLATION      // only in a library built with `make ABLATION=1`; a production build never reads the variable
-    static const int dbg = getenv("EAP_ZP_DEBUG") ? atoi(getenv("EAP_ZP_DEBUG")) : 0;
+    const int dbg = getenv("EAP_ZP_DEBUG") ? atoi(getenv("EAP_ZP_DEBUG")) : 0;
 #else
     const int dbg = 0;
 #endif
