@@ -318,17 +318,6 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
                             *reinterpret_cast<float4 *>(rb + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * o_cs + lane_off) =
                                 make_float4(acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]);
                     } else {
-                            // write-through, line dropped from this XCD's L2 (sc1): the output stream (read next by another
-                            // kernel) does not evict the feature rows the resident workgroups share
-                            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const f32x4s vv = {acc[ct][0][r], acc[ct][1][r], acc[ct][2][r], acc[ct][3][r]};
-                                asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"(lane_off * 4u), "v"(vv),
-                                             "s"(rb + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * o_cs) : "memory");
-                            }
-                        }
-                    } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if (c0 + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh < C)
