@@ -75,6 +75,9 @@ def test_separable_block_at_4096_points_full_width_vs_oracle():
     skip = torch.nn.Conv2d(c, o, 1)
     gen = torch.Generator().manual_seed(10)
     f = torch.randn(1, c, P, 60, generator=gen)
+    # CPU copies for the oracle (Module.to moves the module in place)
+    anchors_c, kernels_c, W_inter_c = inter.anchors.clone(), inter.kernels.clone(), inter.basic_conv.W.detach().clone()
+    W_intra_c, intra_idx_c = intra.basic_conv.W.detach().clone(), intra.intra_idx.clone()
     inter_d, intra_d, skip_d = inter.to(dev), intra.to(dev), skip.to(dev)
     n1 = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
     n2 = sptk.InstanceNormLeakyReLU(o, negative_slope=0.01).to(dev)
@@ -90,11 +93,11 @@ def test_separable_block_at_4096_points_full_width_vs_oracle():
     q0, q1 = 1500, 1564
     # inter conv, slab of 64 query points
     res = so3_ref._poseconv_slab(T(xyz)[:, :, q0:q1].contiguous(), T(pose)[:, q0:q1].contiguous(), T(xyz), T(pose),
-                                 so3_ref.add_shadow_feature(f), 64, inter.anchors, inter.kernels, r, s, 1, True)
-    y_ref = so3_ref.basic_so3conv(inter.basic_conv.W.detach(), res[3])
+                                 so3_ref.add_shadow_feature(f), 64, anchors_c, kernels_c, r, s, 1, True)
+    y_ref = so3_ref.basic_so3conv(W_inter_c, res[3])
     assert rel_err(y.feats[:, :, q0:q1].cpu().numpy(), y_ref.numpy()) < 2e-5
     # intra conv at C = 512 on the slab, from the GPU's own (already checked) input
-    z_ref = so3_ref.intra_so3conv_layer(a1[:, :, q0:q1].cpu(), intra.basic_conv.W.detach(), intra.intra_idx)
+    z_ref = so3_ref.intra_so3conv_layer(a1[:, :, q0:q1].cpu(), W_intra_c, intra_idx_c)
     assert rel_err(z[:, :, q0:q1].cpu().numpy(), z_ref.numpy()) < 2e-5
     # epilogues on the full maps (torch modules on the CPU)
     lr = torch.nn.functional.leaky_relu
