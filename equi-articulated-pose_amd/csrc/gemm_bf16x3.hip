@@ -1,0 +1,266 @@
+// csrc/gemm_bf16x3.hip -- the forward contraction of the SO(3) convolution with fp32 operands, fp32 accumulation and
+// fp32-accurate products on the bf16 matrix cores ("3 x bf16 split").
+//
+//     C_z[M,N] = A[M,K] * B_z[N,K]^T          both operands k-contiguous (row-major), z = batch item
+//
+//   BasicSO3Conv.forward (vgtk/vgtk/so3conv/modules.py:L48-55):  y[b][O, P*A] = W[O, C*K] * X^T[b][P*A, C*K]^T with the
+//   grouped tensor X kept transposed by the grouping kernel (csrc/so3_inter_lists2.hip, layout 2).
+//
+// Why: v_mfma_f32_32x32x2_f32 peaks at 157 TFLOP/s and csrc/gemm_dma_f32.hip is at 0.89 of it; the bf16 matrix pipe is
+// 16 x faster.  Every fp32 operand value x is split EXACTLY into three bf16 values, x = h + m + l (h = bf16(x),
+// m = bf16(x - h), l = bf16(x - h - m): 3 x 8 significand bits), and a product a * b is taken as
+//     ah bh + (ah bm + am bh) + (ah bl + al bh + am bm)
+// -- six v_mfma_f32_32x32x16_bf16 per tile and k-block, each product of two bf16 values exact in the fp32 accumulator.
+// The dropped terms (am bl + al bm + al bl) are <= 2^-23 |a b|: the same order as the rounding of ONE fp32 product
+// (2^-24), i.e. the result is as accurate as the fmaf chain of the fp32 MFMA (tests: the same 1e-5 bars, and a
+// comparison against fp64 in tests/test_gpu_lists_and_modules.py).  Measured ceiling of the instruction stream from one
+// wave per SIMD with 16 accumulators: 1.9 PFLOP/s bf16 = 315 TFLOP/s of fp32-equivalent products, with up to three
+// vector instructions per MFMA riding along for free (tools/microbench/mfma_bf16_split.hip) -- the split is done ON THE
+// FLY on the way global -> VGPR -> LDS, so neither operand is ever stored in split form.
+//
+// Geometry (that of csrc/gemm_dma_f32.hip): 4 waves = one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256
+// AGPR/VGPRs), block tile 256 x 256, BK = 16.  Thread t owns row t of both operand tiles: it loads the row's 16 k's as
+// four 16-byte words three k-tiles ahead, splits them between the current tile's products and parks the three planes in the
+// LDS stage of the tile after next ([plane][row][16 k] bf16, 32 bytes per row; the row's two 16-byte k-halves swapped by
+// (row >> 3) & 1 so that the four 16-lane groups a ds_read_b128 is serviced in hit 16 different slots).  One
+// __syncthreads per k-tile, three LDS stages (144 KB): the barrier that closes tile t certifies the stage of tile t + 2,
+// so the first fragments of tile t + 1 are read before tile t's last product.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BK = 16, NT = 256, BM = 256, BN = 256;
+constexpr unsigned PLANE_BYTES = 256 * BK * 2;                 // one plane of one operand tile: 8 KB
+constexpr unsigned OPER_BYTES = 3 * PLANE_BYTES;               // 24 KB
+constexpr unsigned STAGE_BYTES = 2 * OPER_BYTES;               // 48 KB
+constexpr size_t SHMEM = 3 * STAGE_BYTES;                      // 144 KB
+
+struct Args {
+    int M, N, K;
+    const float *A; long long lda;
+    const float *B; long long ldb, sB;
+    float *C; long long ldc, sC;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // [15:0] = bf16(a), [31:16] = bf16(b), round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// 16 consecutive k's of one row (four 16-byte words) -> three planes of 16 bf16 (two 16-byte words each)
+struct Row16 { f32x4 q0, q1, q2, q3; };
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);       // exact
+    m = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);       // exact
+    l = pk_bf16(s0, s1);
+}
+
+__device__ __forceinline__ void split_quad(const f32x4 &a, const f32x4 &b, u32x4 &h, u32x4 &m, u32x4 &l) {   // 8 k's
+    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    split_pair(a.x, a.y, h0, m0, l0);
+    split_pair(a.z, a.w, h1, m1, l1);
+    split_pair(b.x, b.y, h2, m2, l2);
+    split_pair(b.z, b.w, h3, m3, l3);
+    h = (u32x4){h0, h1, h2, h3};
+    m = (u32x4){m0, m1, m2, m3};
+    l = (u32x4){l0, l1, l2, l3};
+}
+
+__global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // XCD-aware tile map (as csrc/gemm_dma_f32.hip): the row tiles of one column panel run back to back on one XCD
+    int id = blockIdx.x, tm, tn;
+    {
+        const int groups = g.tiles_n / 8 * 8;
+        const int xcd = id & 7, slot = id >> 3;
+        const int panel = (slot / g.tiles_m) * 8 + xcd;
+        if (panel < groups && id < groups * g.tiles_m) { tn = panel; tm = slot % g.tiles_m; }
+        else { const int r = id - groups * g.tiles_m; tn = groups + r / g.tiles_m; tm = r % g.tiles_m; }
+    }
+    const int z = blockIdx.y;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const float *B = g.B + (long long)z * g.sB;
+    float *C = g.C + (long long)z * g.sC;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- staging: thread t <-> row t of the A tile and row t of the B tile (clamped: rows past the edge repeat the
+    //      last one and are never stored) ------------------------------------------------------------------------------
+    const float *srcA = g.A + (long long)min(m0 + t, g.M - 1) * g.lda;
+    const float *srcB = B + (long long)min(n0 + t, g.N - 1) * g.ldb;
+    const unsigned wr_off = (unsigned)t * 32u;                         // row t of a plane
+    const unsigned swz = ((unsigned)(t >> 3) & 1u) * 16u;              // k-half h of the row sits at 16 (h ^ ((row >> 3) & 1))
+    const int nk = g.K / BK;
+
+    Row16 ra0, rb0, ra1, rb1;                                           // named: an indexed array would not stay in registers
+    auto load_tile = [&](int kt, Row16 &a, Row16 &b) __attribute__((always_inline)) {
+        const f32x4 *pa = reinterpret_cast<const f32x4 *>(srcA + (long long)kt * BK);
+        const f32x4 *pb = reinterpret_cast<const f32x4 *>(srcB + (long long)kt * BK);
+        a.q0 = pa[0]; a.q1 = pa[1]; a.q2 = pa[2]; a.q3 = pa[3];
+        b.q0 = pb[0]; b.q1 = pb[1]; b.q2 = pb[2]; b.q3 = pb[3];
+    };
+    // one half row (8 k's = two 16-byte words) -> three 16-byte words, parked at k-half `half` of row t
+    auto park_half = [&](unsigned char *oper, const f32x4 &qa, const f32x4 &qb, unsigned half) __attribute__((always_inline)) {
+        u32x4 h, m, l;
+        split_quad(qa, qb, h, m, l);
+        unsigned char *row = oper + wr_off + ((16u * half) ^ swz);
+        *reinterpret_cast<u32x4 *>(row) = h;
+        *reinterpret_cast<u32x4 *>(row + PLANE_BYTES) = m;
+        *reinterpret_cast<u32x4 *>(row + 2 * PLANE_BYTES) = l;
+    };
+    auto park = [&](unsigned char *oper, const Row16 &r) __attribute__((always_inline)) {
+        park_half(oper, r.q0, r.q1, 0);
+        park_half(oper, r.q2, r.q3, 1);
+    };
+
+    // ---- fragments: lane (row li of a 32-row tile, k-half lh) reads 16 bytes = 8 bf16 ------------------------------
+    // row r of the wave's A rows = 128 wm + 32 i + li: (r >> 3) & 1 == (li >> 3) & 1
+    const unsigned rd_half = 16u * ((unsigned)lh ^ (((unsigned)li >> 3) & 1u));
+    const unsigned rdA = (unsigned)(128 * wm + li) * 32u + rd_half;
+    const unsigned rdB = OPER_BYTES + (unsigned)(128 * wn + li) * 32u + rd_half;
+    auto frag = [&](const unsigned char *st, unsigned base, int p, u32x4 (&f)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4 *>(st + base + p * PLANE_BYTES + i * 32 * 32);
+    };
+
+    f32x16 acc[4][4];         // never zeroed: the first product of the first k-tile takes the constant 0 as its C operand
+    u32x4 ah[4], bl[4];       // the first two plane fragments of the NEXT tile are read before the tile's closing barrier
+
+    // One k-tile.  Stage `st` holds tile kt (certified by the barrier that closed tile kt - 1, like stage `s1` of tile
+    // kt + 1); (sa, sb) hold tile kt + 2 in registers since tile kt - 1: they are split and parked in stage `s2` in four
+    // pieces BETWEEN the products (vector instructions ride in the shadow of the matrix pipe,
+    // tools/microbench/mfma_bf16_split.hip), then take tile kt + 4.  Plane fragments are read one product ahead of
+    // their first use and dropped after their last.
+    auto tile = [&](auto first, int kt, const unsigned char *st, const unsigned char *s1, unsigned char *s2, Row16 &sa, Row16 &sb)
+                    __attribute__((always_inline)) {
+        auto product = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        };
+        u32x4 bm[4], am[4], bh[4], al[4];
+        frag(st, rdB, 1, bm);
+        if constexpr (decltype(first)::value) {
+            const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), zc, 0, 0, 0);
+        } else {
+            product(ah, bl);
+        }
+        park_half(s2, sa.q0, sa.q1, 0);
+        frag(st, rdA, 1, am);
+        product(ah, bm);
+        park_half(s2, sa.q2, sa.q3, 1);
+        frag(st, rdB, 0, bh);
+        product(am, bm);
+        park_half(s2 + OPER_BYTES, sb.q0, sb.q1, 0);
+        frag(st, rdA, 2, al);
+        product(am, bh);
+        park_half(s2 + OPER_BYTES, sb.q2, sb.q3, 1);
+        product(al, bh);
+        // branch-free on purpose (accumulators that cross a control-flow join get copied): past the last tiles the
+        // staged registers are re-split into a stage nobody reads, the loads repeat the last tile, the fragment reads hit
+        // a stale stage
+        load_tile(min(kt + 4, nk - 1), sa, sb);
+        u32x4 ah2[4];
+        frag(s1, rdA, 0, ah2);               // the next tile's first two planes (its stage was certified a tile ago)
+        frag(s1, rdB, 2, bl);
+        product(ah, bh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ah[i] = ah2[i];
+        __syncthreads();
+    };
+
+    // ---- prologue --------------------------------------------------------------------------------------------------
+    load_tile(0, ra0, rb0);
+    load_tile(min(1, nk - 1), ra1, rb1);
+    park(smem, ra0);
+    park(smem + OPER_BYTES, rb0);
+    load_tile(min(2, nk - 1), ra0, rb0);
+    park(smem + STAGE_BYTES, ra1);
+    park(smem + STAGE_BYTES + OPER_BYTES, rb1);
+    load_tile(min(3, nk - 1), ra1, rb1);
+    __syncthreads();
+    frag(smem, rdA, 0, ah);
+    frag(smem, rdB, 2, bl);
+
+    // stage of tile kt = kt % 3; register set of tile kt + 2 = kt % 2
+    unsigned s0 = 0, s1 = STAGE_BYTES, s2 = 2 * STAGE_BYTES;
+    tile(std::true_type{}, 0, smem + s0, smem + s1, smem + s2, ra0, rb0);
+    int kt = 1;
+    for (; kt + 1 < nk; kt += 2) {
+        { const unsigned r = s0; s0 = s1; s1 = s2; s2 = r; }
+        tile(std::false_type{}, kt, smem + s0, smem + s1, smem + s2, ra1, rb1);
+        { const unsigned r = s0; s0 = s1; s1 = s2; s2 = r; }
+        tile(std::false_type{}, kt + 1, smem + s0, smem + s1, smem + s2, ra0, rb0);
+    }
+    if (kt < nk) {
+        { const unsigned r = s0; s0 = s1; s1 = s2; s2 = r; }
+        tile(std::false_type{}, kt, smem + s0, smem + s1, smem + s2, ra1, rb1);
+    }
+
+    // ---- epilogue: D[i][j] of a 32 x 32 tile sits at col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) --------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 128 * wn + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 128 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M && col < g.N) C[(long long)row * g.ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+// can the split kernel take this product?  (both operands k-contiguous, K a multiple of 16, 16-byte aligned rows; it pays
+// from a 256 x 256 tile per CU upwards)
+extern "C" int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                                             int64_t strideB) {
+    if (M < 128 || N < 256 || K < BK || (K % BK) != 0) return 0;
+    if ((lda & 3) || (ldb & 3) || (strideB & 3)) return 0;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
+    return 1;
+}
+
+extern "C" int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                                   float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (!eap_gemm_bf16x3_f32_supported(M, N, K, A, lda, B, ldb, strideB)) return eap::bad_arg("gemm_bf16x3_f32: unsupported operands (ask eap_gemm_bf16x3_f32_supported)");
+    if (batch > 65535) return eap::bad_arg("gemm_bf16x3_f32: batch exceeds 65535");
+    Args g;
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda;
+    g.B = B; g.ldb = ldb; g.sB = strideB;
+    g.C = C; g.ldc = ldc; g.sC = strideC;
+    g.tiles_m = (M + BM - 1) / BM;
+    g.tiles_n = (N + BN - 1) / BN;
+    int e = eap::hip_fail(hipFuncSetAttribute((const void *)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM),
+                          "gemm_bf16x3_f32 shared memory");
+    if (e) return e;
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(g.tiles_m * g.tiles_n, batch), dim3(NT), SHMEM, eap::S(stream), g);
+    eap::set_kernel("gemm_bf16x3_kernel");
+    return eap::check_launch("gemm_bf16x3_f32");
+}

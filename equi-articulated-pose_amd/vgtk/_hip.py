@@ -103,9 +103,20 @@ def _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
                                                               _ptr(B), _I64(ldb), _I64(strideB)))
 
 
+# The forward contraction (A shared by the batch, both operands k-contiguous) on the bf16 matrix cores with 3 x bf16
+# split operands: fp32 in, fp32 accumulate, products as accurate as fp32's (csrc/gemm_bf16x3.hip).  False: the fp32-MFMA
+# kernel everywhere.
+SPLIT_BF16_CONTRACTION = True
+
+
 def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, b_blocked=False):
     """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored."""
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)}
+    if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and (strideA == 0 or batch == 1) and \
+            lib.eap_gemm_bf16x3_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB)):
+        call('eap_gemm_bf16x3_f32', C, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
+             batch, tag=tag)
+        return
     if not b_blocked and _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
         call('eap_gemm_dma_f32', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb),
              _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch, tag=tag)

@@ -275,6 +275,17 @@ int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, const float
                         int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C,
                         int64_t ldc, int batch, float *workspace, eap_stream_t stream);
 
+/* C_z[M,N] = A[M,K] * B_z[N,K]^T (the forward contraction of BasicSO3Conv.forward, vgtk/vgtk/so3conv/modules.py:L48-55,
+ * with the grouped tensor kept transposed: both operands k-contiguous, A shared by the batch) with fp32 operands, fp32
+ * accumulation and fp32-accurate products on the bf16 matrix cores: every operand value is split exactly into three bf16
+ * values on the fly and each product taken as the six largest of the nine partial products (the dropped ones are below
+ * the rounding of one fp32 product) -- csrc/gemm_bf16x3.hip.  Needs M >= 128, N >= 256, K % 16 == 0, lda / ldb /
+ * strideB multiples of 4, 16-byte aligned bases: eap_gemm_bf16x3_f32_supported tells (1 / 0). */
+int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                                  int64_t strideB);
+int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                        float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+
 /* The same GEMMs with both operands fed by global -> LDS DMA through a three-stage ring (csrc/gemm_dma_f32.hip);
  * conventions of eap_gemm_f32 / eap_gemm_f32_reduce.  Needs K % 16 == 0, leading dimensions and batch strides
  * multiples of 4, 16-byte aligned bases, and a multiple of 4 rows for an operand whose rows are contiguous

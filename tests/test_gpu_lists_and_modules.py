@@ -569,3 +569,34 @@ def test_orbit_selection_matches_reference_statements(dev, golden, tag, cd, sing
     dist, orbit = sptk.orbit_selection(d_soft, r2o, slot_single_cd=cd, slot_single_mode=single)
     np.testing.assert_array_equal(orbit.cpu().numpy(), g[f'{tag}_slot_orbits'])
     np.testing.assert_allclose(dist.cpu().numpy(), g[f'{tag}_slot_dist'], rtol=2e-5)
+
+
+@pytest.mark.parametrize('M,N,K,batch', [(512, 2048, 3072, 2), (128, 1920, 1536, 1), (300, 700, 48, 3), (256, 256, 16, 1)])
+def test_split_bf16_contraction_is_fp32_accurate(dev, M, N, K, batch):
+    """csrc/gemm_bf16x3.hip: C = A B^T with fp32 operands on the bf16 matrix cores (3 x bf16 split, six partial products,
+    fp32 accumulation) against fp64 -- its error must be of the size of the fp32-MFMA kernel's own (an fmaf chain), on
+    operands like the path's (weights ~N(0, s), grouped features non-negative with a wide dynamic range) and on edge tiles."""
+    from vgtk import _hip
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=gen) * 0.05).to(dev)
+    B = (torch.randn(batch, N, K, generator=gen).abs() * torch.exp(torch.randn(batch, N, 1, generator=gen) * 2.0)).to(dev)
+    ref = torch.matmul(A.double().cpu(), B.double().cpu().transpose(1, 2))                      # [batch, M, N]
+    out = {}
+    for split in (True, False):
+        _hip.SPLIT_BF16_CONTRACTION = split
+        try:
+            C = torch.full((batch, M, N), float('nan'), device=dev)
+            _hip.gemm(0, 1, M, N, K, A, K, 0, B, K, N * K, C, N, M * N, batch)
+        finally:
+            _hip.SPLIT_BF16_CONTRACTION = True
+        out[split] = C.double().cpu()
+    scale = ref.abs().max().item()
+    err_split = (out[True] - ref).abs().max().item() / scale
+    err_fp32 = (out[False] - ref).abs().max().item() / scale
+    # per-element bound: |a|.|b| accumulated in fp32
+    bound = torch.matmul(A.abs().double().cpu(), B.abs().double().cpu().transpose(1, 2))
+    rel_el = ((out[True] - ref).abs() / bound.clamp_min(1e-300)).max().item()
+    print(f'\nGEMM {M}x{N}x{K}: split {err_split:.2e}, fp32 MFMA {err_fp32:.2e} (max error / max |C|); split per-element {rel_el:.2e} of sum |a||b|')
+    # both kernels accumulate K products in fp32: their errors are of the same size (the split adds ~2^-23 per product)
+    assert err_split < 3 * err_fp32 + 2e-7, (err_split, err_fp32)
+    assert rel_el < 1e-6, rel_el

@@ -29,10 +29,12 @@ def bench(fns, flops, rounds=5):
 
 def old(*a, **k):
     _hip.USE_DMA_GEMM = False
+    _hip.SPLIT_BF16_CONTRACTION = False
     try:
         _hip.gemm(*a, **k)
     finally:
         _hip.USE_DMA_GEMM = True
+        _hip.SPLIT_BF16_CONTRACTION = True
 
 
 def old_reduce(*a, **k):
@@ -49,7 +51,14 @@ for (O, CK) in ((512, 3072),) if ONLY_FIRST else ((512, 3072), (128, 1536)):
     XT = torch.randn(B, PA, CK, device=dev)          # the transposed intermediate [P*A, C*K]
     Y = torch.empty(B, O, PA, device=dev)
     print(f'forward contraction Y[{O} x {PA}] = W[{O} x {CK}] . XT^T, batch {B}')
-    bench({'gemm_dma_f32 (TN)': lambda: _hip.gemm(0, 1, O, PA, CK, W, CK, 0, XT, CK, CK * PA, Y, PA, O * PA, B),
+    def fp32_ring():
+        _hip.SPLIT_BF16_CONTRACTION = False
+        try:
+            _hip.gemm(0, 1, O, PA, CK, W, CK, 0, XT, CK, CK * PA, Y, PA, O * PA, B)
+        finally:
+            _hip.SPLIT_BF16_CONTRACTION = True
+    bench({'gemm_bf16x3 (3 x bf16 split)': lambda: _hip.gemm(0, 1, O, PA, CK, W, CK, 0, XT, CK, CK * PA, Y, PA, O * PA, B),
+           'gemm_dma_f32 (TN)': fp32_ring,
            'gemm_f32 (TN, reg. staging)': lambda: old(0, 1, O, PA, CK, W, CK, 0, XT, CK, CK * PA, Y, PA, O * PA, B),
            'hipBLASLt (torch.matmul)': lambda: torch.matmul(W, XT.transpose(1, 2), out=Y)}, 2.0 * O * CK * PA * B)
     del XT, Y
