@@ -22,10 +22,11 @@
 // AGPR/VGPRs), block tile 256 x 256, BK = 16.  Thread t owns row t of both operand tiles: it loads the row's 16 k's as
 // four 16-byte words three k-tiles ahead, splits them between the current tile's products and parks the three planes in the
 // LDS stage of the tile after next ([plane][row][16 k] bf16, 32 bytes per row; the row's two 16-byte k-halves swapped by
-// (row >> 3) & 1 so that the four 16-lane groups a ds_read_b128 is serviced in hit 16 different slots).  One
+// ((row >> 2) ^ (row >> 3)) & 1: conflict-free for the parking ds_write_b128 and the fragment ds_read_b128).  One
 // __syncthreads per k-tile, three LDS stages (144 KB): the barrier that closes tile t certifies the stage of tile t + 2,
 // so the first fragments of tile t + 1 are read before tile t's last product.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -55,8 +56,10 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // [15:
     return r;
 }
 
-// 16 consecutive k's of one row (four 16-byte words) -> three planes of 16 bf16 (two 16-byte words each)
+// the eight 16-byte pieces a thread stages per k-tile: piece u = 4 consecutive k's of operand row 64 (u & 3) + (t >> 2)
+// (u < 4: A tile, u >= 4: B tile), k-chunk t & 3 -- four lanes cover the 64 contiguous bytes a row contributes to a k-tile
 struct Row16 { f32x4 q0, q1, q2, q3; };
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     h = pk_bf16(x0, x1);
@@ -77,6 +80,9 @@ __device__ __forceinline__ void split_quad(const f32x4 &a, const f32x4 &b, u32x4
     l = (u32x4){l0, l1, l2, l3};
 }
 
+// DBG (timing ablations, `make ABLATION=1` + EAP_GEMM_SPLIT_DEBUG, WRONG results): 1 = no global loads inside the k-loop,
+// 2 = no split / park, 4 = no fragment reads, 8 = no barrier
+template <int DBG>
 __global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -99,29 +105,45 @@ __global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(Args g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    // ---- staging: thread t <-> row t of the A tile and row t of the B tile (clamped: rows past the edge repeat the
-    //      last one and are never stored) ------------------------------------------------------------------------------
-    const float *srcA = g.A + (long long)min(m0 + t, g.M - 1) * g.lda;
-    const float *srcB = B + (long long)min(n0 + t, g.N - 1) * g.ldb;
-    const unsigned wr_off = (unsigned)t * 32u;                         // row t of a plane
-    const unsigned swz = ((unsigned)(t >> 3) & 1u) * 16u;              // k-half h of the row sits at 16 (h ^ ((row >> 3) & 1))
+    // ---- staging: per k-tile thread t moves eight 16-byte pieces global -> VGPR -> (split) -> LDS: pieces 0..3 of the A
+    //      tile (rows 64 u + (t >> 2), u = 0..3), 4..7 of the B tile, k-chunk t & 3.  Request address = wave-uniform base of
+    //      the 64-row group (clamped to the last group that exists: M, N multiples of 64) + one 32-bit offset per lane.
+    const int c4 = t & 3, rq = t >> 2;
+    const float *baseA[4], *baseB[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        baseA[u] = g.A + (long long)min(m0 + 64 * u, g.M - 64) * g.lda;
+        baseB[u] = B + (long long)min(n0 + 64 * u, g.N - 64) * g.ldb;
+    }
+    const unsigned offA = (unsigned)((long long)rq * g.lda + 4 * c4) * 4u, offB = (unsigned)((long long)rq * g.ldb + 4 * c4) * 4u;
+    // LDS: row r of a plane is 32 bytes (16 bf16); its two 16-byte k-halves are swapped by b(r) = ((r >> 2) ^ (r >> 3)) & 1:
+    // conflict-free for the fragment ds_read_b128 (four 16-lane groups, 256-byte bank window); the 8-byte parking writes of
+    // 16 contiguous lanes cover 4 whole rows = 128 contiguous bytes either way.  rows 64 u + rq: bits 2, 3 of the row = bits of rq
+    const unsigned wr_off = (unsigned)rq * 32u + ((16u * (unsigned)(c4 >> 1)) ^ ((((unsigned)rq >> 2) ^ ((unsigned)rq >> 3)) & 1u) * 16u) + 8u * (unsigned)(c4 & 1);
     const int nk = g.K / BK;
 
-    Row16 ra0, rb0, ra1, rb1;                                           // named: an indexed array would not stay in registers
-    auto load_tile = [&](int kt, Row16 &a, Row16 &b) __attribute__((always_inline)) {
-        const f32x4 *pa = reinterpret_cast<const f32x4 *>(srcA + (long long)kt * BK);
-        const f32x4 *pb = reinterpret_cast<const f32x4 *>(srcB + (long long)kt * BK);
-        a.q0 = pa[0]; a.q1 = pa[1]; a.q2 = pa[2]; a.q3 = pa[3];
-        b.q0 = pb[0]; b.q1 = pb[1]; b.q2 = pb[2]; b.q3 = pb[3];
+    Row16 ra0, rb0, ra1, rb1;                                           // (A pieces 0..3, B pieces 0..3) of two tiles in flight
+    auto ld = [&](const float *ubase, unsigned voff) __attribute__((always_inline)) {
+        return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(ubase) + voff);
     };
-    // one half row (8 k's = two 16-byte words) -> three 16-byte words, parked at k-half `half` of row t
+    auto load_tile = [&](int kt, Row16 &a, Row16 &b) __attribute__((always_inline)) {
+        const int ko = kt * BK;
+        a.q0 = ld(baseA[0] + ko, offA); a.q1 = ld(baseA[1] + ko, offA); a.q2 = ld(baseA[2] + ko, offA); a.q3 = ld(baseA[3] + ko, offA);
+        b.q0 = ld(baseB[0] + ko, offB); b.q1 = ld(baseB[1] + ko, offB); b.q2 = ld(baseB[2] + ko, offB); b.q3 = ld(baseB[3] + ko, offB);
+    };
+    // one piece (4 k's) -> three 8-byte words, parked at its place in row 64 u + rq of the operand tile
+    auto park_piece = [&](unsigned char *oper, int u, const f32x4 &q) __attribute__((always_inline)) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split_pair(q.x, q.y, h0, m0_, l0);
+        split_pair(q.z, q.w, h1, m1, l1);
+        unsigned char *row = oper + (unsigned)u * (64u * 32u) + wr_off;
+        *reinterpret_cast<u32x2 *>(row) = (u32x2){h0, h1};
+        *reinterpret_cast<u32x2 *>(row + PLANE_BYTES) = (u32x2){m0_, m1};
+        *reinterpret_cast<u32x2 *>(row + 2 * PLANE_BYTES) = (u32x2){l0, l1};
+    };
     auto park_half = [&](unsigned char *oper, const f32x4 &qa, const f32x4 &qb, unsigned half) __attribute__((always_inline)) {
-        u32x4 h, m, l;
-        split_quad(qa, qb, h, m, l);
-        unsigned char *row = oper + wr_off + ((16u * half) ^ swz);
-        *reinterpret_cast<u32x4 *>(row) = h;
-        *reinterpret_cast<u32x4 *>(row + PLANE_BYTES) = m;
-        *reinterpret_cast<u32x4 *>(row + 2 * PLANE_BYTES) = l;
+        park_piece(oper, 2 * (int)half, qa);
+        park_piece(oper, 2 * (int)half + 1, qb);
     };
     auto park = [&](unsigned char *oper, const Row16 &r) __attribute__((always_inline)) {
         park_half(oper, r.q0, r.q1, 0);
@@ -129,11 +151,16 @@ __global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(Args g) {
     };
 
     // ---- fragments: lane (row li of a 32-row tile, k-half lh) reads 16 bytes = 8 bf16 ------------------------------
-    // row r of the wave's A rows = 128 wm + 32 i + li: (r >> 3) & 1 == (li >> 3) & 1
-    const unsigned rd_half = 16u * ((unsigned)lh ^ (((unsigned)li >> 3) & 1u));
+    // row r of the wave's A rows = 128 wm + 32 i + li: bits 2 and 3 of r are those of li
+    const unsigned rd_half = 16u * ((unsigned)lh ^ ((((unsigned)li >> 2) ^ ((unsigned)li >> 3)) & 1u));
     const unsigned rdA = (unsigned)(128 * wm + li) * 32u + rd_half;
     const unsigned rdB = OPER_BYTES + (unsigned)(128 * wn + li) * 32u + rd_half;
     auto frag = [&](const unsigned char *st, unsigned base, int p, u32x4 (&f)[4]) __attribute__((always_inline)) {
+        if constexpr (DBG & 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = (u32x4){0x3f803f80u + (unsigned)p, 0x3f803f80u, 0x3f803f80u + base, 0x3f803f80u};
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const u32x4 *>(st + base + p * PLANE_BYTES + i * 32 * 32);
     };
@@ -167,28 +194,28 @@ __global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(Args g) {
         } else {
             product(ah, bl);
         }
-        park_half(s2, sa.q0, sa.q1, 0);
+        if constexpr (!(DBG & 2)) park_half(s2, sa.q0, sa.q1, 0);
         frag(st, rdA, 1, am);
         product(ah, bm);
-        park_half(s2, sa.q2, sa.q3, 1);
+        if constexpr (!(DBG & 2)) park_half(s2, sa.q2, sa.q3, 1);
         frag(st, rdB, 0, bh);
         product(am, bm);
-        park_half(s2 + OPER_BYTES, sb.q0, sb.q1, 0);
+        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb.q0, sb.q1, 0);
         frag(st, rdA, 2, al);
         product(am, bh);
-        park_half(s2 + OPER_BYTES, sb.q2, sb.q3, 1);
+        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb.q2, sb.q3, 1);
         product(al, bh);
         // branch-free on purpose (accumulators that cross a control-flow join get copied): past the last tiles the
         // staged registers are re-split into a stage nobody reads, the loads repeat the last tile, the fragment reads hit
         // a stale stage
-        load_tile(min(kt + 4, nk - 1), sa, sb);
+        if constexpr (!(DBG & 1)) load_tile(min(kt + 4, nk - 1), sa, sb);
         u32x4 ah2[4];
         frag(s1, rdA, 0, ah2);               // the next tile's first two planes (its stage was certified a tile ago)
         frag(s1, rdB, 2, bl);
         product(ah, bh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ah[i] = ah2[i];
-        __syncthreads();
+        if constexpr (!(DBG & 8)) __syncthreads();
     };
 
     // ---- prologue --------------------------------------------------------------------------------------------------
@@ -239,7 +266,9 @@ __global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(Args g) {
 // from a 256 x 256 tile per CU upwards)
 extern "C" int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
                                              int64_t strideB) {
-    if (M < 128 || N < 256 || K < BK || (K % BK) != 0) return 0;
+    // (block tile 256 x 256: a row count that leaves half a tile empty is better served by csrc/gemm_dma_f32.hip)
+    if (M < 256 || (M % 256) > 0 && (M % 256) <= 128 || N < 256 || (M & 63) || (N & 63) || K < BK || (K % BK) != 0) return 0;
+    if ((long long)64 * lda * 4 >= (1ll << 32) || (long long)64 * ldb * 4 >= (1ll << 32)) return 0;
     if ((lda & 3) || (ldb & 3) || (strideB & 3)) return 0;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
     return 1;
@@ -257,10 +286,28 @@ extern "C" int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t 
     g.C = C; g.ldc = ldc; g.sC = strideC;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
-    int e = eap::hip_fail(hipFuncSetAttribute((const void *)gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM),
-                          "gemm_bf16x3_f32 shared memory");
+    auto launch = [&](auto kern) {
+        int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM), "gemm_bf16x3_f32 shared memory");
+        if (e) return e;
+        hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, batch), dim3(NT), SHMEM, eap::S(stream), g);
+        return 0;
+    };
+    int e;
+#ifdef EAP_ABLATION
+    const int dbg = getenv("EAP_GEMM_SPLIT_DEBUG") ? atoi(getenv("EAP_GEMM_SPLIT_DEBUG")) : 0;
+    switch (dbg) {
+        case 1: e = launch(gemm_bf16x3_kernel<1>); break;
+        case 2: e = launch(gemm_bf16x3_kernel<2>); break;
+        case 3: e = launch(gemm_bf16x3_kernel<3>); break;
+        case 4: e = launch(gemm_bf16x3_kernel<4>); break;
+        case 7: e = launch(gemm_bf16x3_kernel<7>); break;
+        case 15: e = launch(gemm_bf16x3_kernel<15>); break;
+        default: e = launch(gemm_bf16x3_kernel<0>);
+    }
+#else
+    e = launch(gemm_bf16x3_kernel<0>);
+#endif
     if (e) return e;
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(g.tiles_m * g.tiles_n, batch), dim3(NT), SHMEM, eap::S(stream), g);
     eap::set_kernel("gemm_bf16x3_kernel");
     return eap::check_launch("gemm_bf16x3_f32");
 }
