@@ -279,7 +279,7 @@ int eap_gemm_f32_reduce(int transA, int transB, int M, int N, int K, const float
  * with the grouped tensor kept transposed: both operands k-contiguous, A shared by the batch) with fp32 operands, fp32
  * accumulation and fp32-accurate products on the bf16 matrix cores: every operand value is split exactly into three bf16
  * values on the fly and each product taken as the six largest of the nine partial products (the dropped ones are below
- * the rounding of one fp32 product) -- csrc/gemm_bf16x3.hip.  Needs M >= 128, N >= 256, M and N multiples of 64, K % 16 == 0, lda / ldb /
+ * the rounding of one fp32 product) -- csrc/gemm_bf16x3.hip.  Needs M >= 128, N >= 256, M and N multiples of 128, K % 16 == 0, lda / ldb /
  * strideB multiples of 4, 16-byte aligned bases: eap_gemm_bf16x3_f32_supported tells (1 / 0). */
 int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
                                   int64_t strideB);
