@@ -67,6 +67,14 @@ int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, i
 // blocks); group_lists2_preferred: the channel count fills the wider blocks and the variant has not been switched off
 // with eap_so3_group_lists_tiles(1)
 bool group_lists2_preferred(int c, int na, int ks, int layout);
+// csrc/so3_inter_lists3.hip: the same on the bf16 matrix cores (3 x bf16 split operands, fp32 accumulate)
+bool group_lists3_preferred(int c, int na, int ks, int layout);
+int group_lists3_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                     const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
+                     hipStream_t s);
+int group_lists3_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
+                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
+                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
 int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                      const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
                      hipStream_t s);

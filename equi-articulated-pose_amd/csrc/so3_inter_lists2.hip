@@ -419,10 +419,11 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
 
 static int g_tiles = 2;       // eap_so3_group_lists_tiles
 
-// A/B and test switch: 1 = always the one-tile kernel of csrc/so3_inter_lists.hip, 2 = two tiles where they pay (default);
-// 0 = query.  Returns the value in force.  Process-wide, not thread-safe (set it before launching).
+// A/B and test switch: 1 = always the one-tile kernel of csrc/so3_inter_lists.hip, 2 = two tiles where they pay (default),
+// 3 = the 3 x bf16 split kernel of csrc/so3_inter_lists3.hip where two tiles pay (measured slower on real neighbour lists: the
+// grouping is bound by the L2 -> LDS gather, not by the matrix pipe); 0 = query.  Returns the value in force.  Process-wide, not thread-safe (set it before launching).
 extern "C" int eap_so3_group_lists_tiles(int tiles) {
-    if (tiles == 1 || tiles == 2) g_tiles = tiles;
+    if (tiles >= 1 && tiles <= 3) g_tiles = tiles;
     return g_tiles;
 }
 
@@ -439,10 +440,14 @@ namespace eap {
 // two channel tiles per wave pay when the channel count fills (most of) the 64-channel blocks; layout 1 (blocked by
 // anchor quads) stays with the one-tile kernel
 bool group_lists2_preferred(int c, int na, int ks, int layout) {
-    if (g_tiles != 2 || na <= 0 || (na & 3) != 0 || na > 64 || ks <= 0 || ks > 32 || layout == 1) return false;
+    if (g_tiles < 2 || na <= 0 || (na & 3) != 0 || na > 64 || ks <= 0 || ks > 32 || layout == 1) return false;
     const int rem = c % CB;
     return c >= CB && (rem == 0 || rem > 32);
 }
+
+// mode 3 (eap_so3_group_lists_tiles): the 3 x bf16 split kernel of csrc/so3_inter_lists3.hip wherever the two-tile kernel
+// would run
+bool group_lists3_preferred(int c, int na, int ks, int layout) { return g_tiles == 3 && group_lists2_preferred(c, na, ks, layout); }
 
 int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                      const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,

@@ -190,9 +190,11 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
                                      float *gfeats, float *workspace, eap_stream_t stream);
 
 /* Which entry-list grouping kernel serves eap_so3_inter_group_fwd*_f32 / eap_so3_inter_group_inv*_f32 when no anchor
- * permutation is in play: 2 (default) = two channel tiles per wave sharing one weight evaluation where the channel
- * count fills 64-channel blocks (csrc/so3_inter_lists2.hip), 1 = always the one-tile kernel (csrc/so3_inter_lists.hip);
- * 0 = query.  Returns the value in force.  Same results either way (tests compare them); A/B timing and tests only. */
+ * permutation is in play: 2 (default) = the fp32-MFMA kernel with two channel tiles per wave where the channel count fills
+ * 64-channel blocks (csrc/so3_inter_lists2.hip), 1 = always the one-tile fp32-MFMA kernel (csrc/so3_inter_lists.hip),
+ * 3 = products on the bf16 matrix cores from exact 3 x bf16 splits of the fp32 operands, fp32 accumulate
+ * (csrc/so3_inter_lists3.hip; an experiment: correct, slower on real neighbour lists); 0 = query.  Returns the value in force.  1 and 2 agree bit for bit, 3 with them to fp32
+ * rounding (tests compare them). */
 int eap_so3_group_lists_tiles(int tiles);
 /* Block -> XCD map of the two-tile kernel: mode 1 = an XCD (one L2) owns whole (channel slice, cloud) pairs, 2 = whole
  * (channel slice, cloud, anchor group) triples; which = 0 forward, 1 backward; mode 0 = query.  Same results either way. */

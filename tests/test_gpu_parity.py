@@ -799,6 +799,14 @@ def test_native_known_answers(dev):
     K.known_chamfer(on_gpu(chamfer.forward), on_gpu(chamfer.backward))
 
 
+def ref_valu(feats, idx, gx, rk, sigma, b, c, p, n, nn, na, ks, dev):
+    from vgtk import _hip
+    ref = torch.empty(b, c, ks, p, na, device=dev)
+    _hip.call('eap_so3_inter_group_fwd_valu_f32', ref, b, c, p, n, nn, na, ks, _hip._F32(sigma), _hip._ptr(feats),
+              _hip._ptr(idx), _hip._ptr(gx), _hip._ptr(rk), _hip._ptr(None), _hip._ptr(ref))
+    return ref
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [
     (2, 64, 37, 37, 64, 60, 24),      # the shipped geometry: 64 channels = one full block, anchor groups 16+16+16+12
@@ -827,7 +835,7 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
     out = {}
     assert _hip.lib.eap_so3_group_lists_tiles(0) == 2
     try:
-        for tiles in (1, 2):
+        for tiles in (1, 2, 3):
             assert _hip.lib.eap_so3_group_lists_tiles(tiles) == tiles
             out[tiles] = (_hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma),
                           _hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma, blocked=2),
@@ -836,6 +844,11 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
         _hip.lib.eap_so3_group_lists_tiles(2)
     for a, bb, what in zip(out[1], out[2], ('forward', 'forward, transposed', 'backward Z')):
         assert torch.equal(a, bb), what
+    # mode 3 (csrc/so3_inter_lists3.hip: the same products on the bf16 matrix cores from exact 3 x bf16 splits of the fp32
+    # operands, fp32 accumulation) agrees with the fp32-MFMA kernels to fp32 rounding
+    for a, bb, what in zip(out[2], out[3], ('forward', 'forward, transposed', 'backward Z')):
+        assert rel_err(bb.cpu().numpy(), a.cpu().numpy()) < 1e-6, what
+    assert rel_err(out[3][0].cpu().numpy(), ref_valu(feats, idx, gx, rk, sigma, b, c, p, n, nn, na, ks, dev).cpu().numpy()) < 5e-6
     ref = torch.empty_like(out[2][0])
     _hip.call('eap_so3_inter_group_fwd_valu_f32', ref, b, c, p, n, nn, na, ks, _hip._F32(sigma), _hip._ptr(feats),
               _hip._ptr(idx), _hip._ptr(gx), _hip._ptr(rk), _hip._ptr(None), _hip._ptr(ref))

@@ -37,7 +37,7 @@ for layer in (2, 1):
     fl = 2.0 * B * o * KS * P * NN * NA
     cn = cnt.flatten().float()
     print(f'layer {layer} O={o} rcap={rcap}: list lengths mean {cn[cn > 0].mean().item():.0f} max {cn.max().item():.0f} min {cn[cn > 0].min().item():.0f}', flush=True)
-    for tiles, xmap in ((1, 1), (2, 1), (2, 2)):   # so3_inter_lists.hip (one channel tile per wave) / so3_inter_lists2.hip (two), XCD owns (slice, cloud) / (slice, cloud, anchor group)
+    for tiles, xmap in ((1, 1), (2, 1), (3, 1)):   # so3_inter_lists.hip (one channel tile per wave) / so3_inter_lists2.hip (two), XCD owns (slice, cloud) / (slice, cloud, anchor group)
         _hip.lib.eap_so3_group_lists_tiles(tiles)
         _hip.lib.eap_so3_group_lists_xcd_map(1, xmap)
         for ep in variants.values():
