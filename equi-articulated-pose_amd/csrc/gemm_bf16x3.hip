@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BK = 16, BM = 256, BN = 256;
+constexpr int BK = 16, BN = 256;
 constexpr unsigned PLANE_BYTES = 256 * BK * 2;                 // one plane of one operand tile: 8 KB
 constexpr unsigned OPER_BYTES = 3 * PLANE_BYTES;               // 24 KB
 constexpr unsigned STAGE_BYTES = 2 * OPER_BYTES;               // 48 KB
@@ -86,9 +86,13 @@ __device__ __forceinline__ void split_quad(const f32x4 &a, const f32x4 &b, u32x4
 // WN = waves along N: 2 -> 4 waves (one per SIMD), wave tile 128 x 128, 256 accumulators; 4 -> 8 waves (two per SIMD),
 // wave tile 128 x 64, 128 accumulators -- the second wave of a SIMD issues matrix instructions while the first waits for
 // its LDS fragments or its staged loads
-template <int WN, int DBG>
+// MI = row tiles per wave: 4 -> block tile 256 x 256; 2 -> 128 x 256 (wave tile 64 x 64) for row counts that would leave
+// half of a 256-row tile empty (the second layer's contraction: 128 output channels)
+template <int MI, int WN, int DBG>
 __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
-    constexpr int NT = 128 * WN, NI = 8 / WN, RG = NT / 4, NPO = 256 / RG;      // threads, column tiles per wave, rows per staging group, pieces per operand
+    constexpr int NT = 128 * WN, NI = 8 / WN, WM = 8 / WN, BM = 32 * MI * WM, RG = NT / 4;   // threads, column tiles per wave, waves along M, rows per block, rows per staging group
+    constexpr int NPA = BM / RG, NPO = 256 / RG;                                              // staged pieces per thread: A tile, B tile
+    static_assert(WN == 4 && NPO == 2 && (NPA == 1 || NPA == 2), "8 waves, 128-row staging groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // XCD-aware tile map (as csrc/gemm_dma_f32.hip): the row tiles of one column panel run back to back on one XCD
@@ -114,12 +118,11 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     //      tile (rows 64 u + (t >> 2), u = 0..3), 4..7 of the B tile, k-chunk t & 3.  Request address = wave-uniform base of
     //      the row group (RG = 64 or 128 rows; clamped to the last group that exists: M, N multiples of RG) + one 32-bit offset per lane.
     const int c4 = t & 3, rq = t >> 2;
-    const float *baseA[NPO], *baseB[NPO];
+    const float *baseA[NPA], *baseB[NPO];
 #pragma unroll
-    for (int u = 0; u < NPO; ++u) {
-        baseA[u] = g.A + (long long)min(m0 + RG * u, g.M - RG) * g.lda;
-        baseB[u] = B + (long long)min(n0 + RG * u, g.N - RG) * g.ldb;
-    }
+    for (int u = 0; u < NPA; ++u) baseA[u] = g.A + (long long)min(m0 + RG * u, g.M - RG) * g.lda;
+#pragma unroll
+    for (int u = 0; u < NPO; ++u) baseB[u] = B + (long long)min(n0 + RG * u, g.N - RG) * g.ldb;
     const unsigned offA = (unsigned)((long long)rq * g.lda + 4 * c4) * 4u, offB = (unsigned)((long long)rq * g.ldb + 4 * c4) * 4u;
     // LDS: row r of a plane is 32 bytes (16 bf16); its two 16-byte k-halves are swapped by b(r) = ((r >> 2) ^ (r >> 3)) & 1:
     // conflict-free for the fragment ds_read_b128 (four 16-lane groups, 256-byte bank window); the 8-byte parking writes of
@@ -133,12 +136,9 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     };
     auto load_tile = [&](int kt, Row16 &a, Row16 &b) __attribute__((always_inline)) {
         const int ko = kt * BK;
-        a.q0 = ld(baseA[0] + ko, offA); a.q1 = ld(baseA[1] + ko, offA);
+        a.q0 = ld(baseA[0] + ko, offA);
+        if constexpr (NPA == 2) a.q1 = ld(baseA[1] + ko, offA);
         b.q0 = ld(baseB[0] + ko, offB); b.q1 = ld(baseB[1] + ko, offB);
-        if constexpr (NPO == 4) {
-            a.q2 = ld(baseA[2] + ko, offA); a.q3 = ld(baseA[3] + ko, offA);
-            b.q2 = ld(baseB[2] + ko, offB); b.q3 = ld(baseB[3] + ko, offB);
-        }
     };
     // one piece (4 k's) -> three 8-byte words, parked at its place in row 64 u + rq of the operand tile
     auto park_piece = [&](unsigned char *oper, int u, const f32x4 &q) __attribute__((always_inline)) {
@@ -151,23 +151,18 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
         *reinterpret_cast<u32x2 *>(row + 2 * PLANE_BYTES) = (u32x2){l0, l1};
     };
     // half of an operand's pieces of a tile (the split rides between the products in four portions)
-    auto park_half = [&](unsigned char *oper, const Row16 &r, int half) __attribute__((always_inline)) {
-        if constexpr (NPO == 4) {
-            park_piece(oper, 2 * half, half ? r.q2 : r.q0);
-            park_piece(oper, 2 * half + 1, half ? r.q3 : r.q1);
-        } else {
-            park_piece(oper, half, half ? r.q1 : r.q0);
-        }
+    auto park_half = [&](unsigned char *oper, const Row16 &r, int half, int pieces) __attribute__((always_inline)) {
+        if (half < pieces) park_piece(oper, half, half ? r.q1 : r.q0);
     };
-    auto park = [&](unsigned char *oper, const Row16 &r) __attribute__((always_inline)) {
-        park_half(oper, r, 0);
-        park_half(oper, r, 1);
+    auto park = [&](unsigned char *oper, const Row16 &r, int pieces) __attribute__((always_inline)) {
+        park_half(oper, r, 0, pieces);
+        park_half(oper, r, 1, pieces);
     };
 
     // ---- fragments: lane (row li of a 32-row tile, k-half lh) reads 16 bytes = 8 bf16 ------------------------------
     // row r of the wave's A rows = 128 wm + 32 i + li: bits 2 and 3 of r are those of li
     const unsigned rd_half = 16u * ((unsigned)lh ^ ((((unsigned)li >> 2) ^ ((unsigned)li >> 3)) & 1u));
-    const unsigned rdA = (unsigned)(128 * wm + li) * 32u + rd_half;
+    const unsigned rdA = (unsigned)(32 * MI * wm + li) * 32u + rd_half;
     const unsigned rdB = OPER_BYTES + (unsigned)(32 * NI * wn + li) * 32u + rd_half;
     auto frag = [&](const unsigned char *st, unsigned base, int p, auto &f) __attribute__((always_inline)) {
         constexpr int NF = sizeof(f) / sizeof(u32x4);
@@ -180,8 +175,8 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
         for (int i = 0; i < NF; ++i) f[i] = *reinterpret_cast<const u32x4 *>(st + base + p * PLANE_BYTES + i * 32 * 32);
     };
 
-    f32x16 acc[4][NI];        // never zeroed: the first product of the first k-tile takes the constant 0 as its C operand
-    u32x4 ah[4], bl[NI];      // the first two plane fragments of the NEXT tile are read before the tile's closing barrier
+    f32x16 acc[MI][NI];       // never zeroed: the first product of the first k-tile takes the constant 0 as its C operand
+    u32x4 ah[MI], bl[NI];     // the first two plane fragments of the NEXT tile are read before the tile's closing barrier
 
     // One k-tile.  Stage `st` holds tile kt (certified by the barrier that closed tile kt - 1, like stage `s1` of tile
     // kt + 1); (sa, sb) hold tile kt + 2 in registers since tile kt - 1: they are split and parked in stage `s2` in four
@@ -190,57 +185,57 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     // their first use and dropped after their last.
     auto tile = [&](auto first, int kt, const unsigned char *st, const unsigned char *s1, unsigned char *s2, Row16 &sa, Row16 &sb)
                     __attribute__((always_inline)) {
-        auto product = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[NI]) __attribute__((always_inline)) {
+        auto product = [&](const u32x4 (&fa)[MI], const u32x4 (&fb)[NI]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
         };
-        u32x4 bm[NI], am[4], bh[NI], al[4];
+        u32x4 bm[NI], am[MI], bh[NI], al[MI];
         frag(st, rdB, 1, bm);
         if constexpr (decltype(first)::value) {
             const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), zc, 0, 0, 0);
         } else {
             product(ah, bl);
         }
-        if constexpr (!(DBG & 2)) park_half(s2, sa, 0);
+        if constexpr (!(DBG & 2)) park_half(s2, sa, 0, NPA);
         frag(st, rdA, 1, am);
         product(ah, bm);
-        if constexpr (!(DBG & 2)) park_half(s2, sa, 1);
+        if constexpr (!(DBG & 2)) park_half(s2, sa, 1, NPA);
         frag(st, rdB, 0, bh);
         product(am, bm);
-        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 0);
+        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 0, NPO);
         frag(st, rdA, 2, al);
         product(am, bh);
-        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 1);
+        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 1, NPO);
         product(al, bh);
         // branch-free on purpose (accumulators that cross a control-flow join get copied): past the last tiles the
         // staged registers are re-split into a stage nobody reads, the loads repeat the last tile, the fragment reads hit
         // a stale stage
         if constexpr (!(DBG & 1)) load_tile(min(kt + 4, nk - 1), sa, sb);
-        u32x4 ah2[4];
+        u32x4 ah2[MI];
         frag(s1, rdA, 0, ah2);               // the next tile's first two planes (its stage was certified a tile ago)
         frag(s1, rdB, 2, bl);
         product(ah, bh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ah[i] = ah2[i];
+        for (int i = 0; i < MI; ++i) ah[i] = ah2[i];
         if constexpr (!(DBG & 8)) __syncthreads();
     };
 
     // ---- prologue --------------------------------------------------------------------------------------------------
     load_tile(0, ra0, rb0);
     load_tile(min(1, nk - 1), ra1, rb1);
-    park(smem, ra0);
-    park(smem + OPER_BYTES, rb0);
+    park(smem, ra0, NPA);
+    park(smem + OPER_BYTES, rb0, NPO);
     load_tile(min(2, nk - 1), ra0, rb0);
-    park(smem + STAGE_BYTES, ra1);
-    park(smem + STAGE_BYTES + OPER_BYTES, rb1);
+    park(smem + STAGE_BYTES, ra1, NPA);
+    park(smem + STAGE_BYTES + OPER_BYTES, rb1, NPO);
     load_tile(min(3, nk - 1), ra1, rb1);
     __syncthreads();
     frag(smem, rdA, 0, ah);
@@ -263,13 +258,13 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
 
     // ---- epilogue: D[i][j] of a 32 x 32 tile sits at col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) --------
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int col = n0 + 32 * NI * wn + 32 * j + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 128 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + 32 * MI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M && col < g.N) C[(long long)row * g.ldc + col] = acc[i][j][r];
             }
         }
@@ -281,8 +276,7 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
 // from a 256 x 256 tile per CU upwards)
 extern "C" int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
                                              int64_t strideB) {
-    // (block tile 256 x 256: a row count that leaves half a tile empty is better served by csrc/gemm_dma_f32.hip)
-    if (M < 256 || ((M % 256) > 0 && (M % 256) <= 128) || N < 256 || (M % (32 * WAVES_N)) || (N % (32 * WAVES_N)) || K < BK || (K % BK) != 0) return 0;
+    if (M < 128 || N < 256 || (M % (32 * WAVES_N)) || (N % (32 * WAVES_N)) || K < BK || (K % BK) != 0) return 0;
     if ((long long)32 * WAVES_N * lda * 4 >= (1ll << 32) || (long long)32 * WAVES_N * ldb * 4 >= (1ll << 32)) return 0;
     if ((lda & 3) || (ldb & 3) || (strideB & 3)) return 0;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
@@ -299,7 +293,8 @@ extern "C" int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t 
     g.A = A; g.lda = lda;
     g.B = B; g.ldb = ldb; g.sB = strideB;
     g.C = C; g.ldc = ldc; g.sC = strideC;
-    g.tiles_m = (M + BM - 1) / BM;
+    const bool tall = (M % 256) == 0;            // 256-row tiles; otherwise 128-row tiles (M is a multiple of 128)
+    g.tiles_m = tall ? M / 256 : M / 128;
     g.tiles_n = (N + BN - 1) / BN;
     auto launch = [&](auto kern) {
         int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM), "gemm_bf16x3_f32 shared memory");
@@ -311,18 +306,18 @@ extern "C" int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t 
 #ifdef EAP_ABLATION
     const int dbg = getenv("EAP_GEMM_SPLIT_DEBUG") ? atoi(getenv("EAP_GEMM_SPLIT_DEBUG")) : 0;
     switch (dbg) {
-        case 1: e = launch(gemm_bf16x3_kernel<WAVES_N, 1>); break;
-        case 2: e = launch(gemm_bf16x3_kernel<WAVES_N, 2>); break;
-        case 3: e = launch(gemm_bf16x3_kernel<WAVES_N, 3>); break;
-        case 4: e = launch(gemm_bf16x3_kernel<WAVES_N, 4>); break;
-        case 7: e = launch(gemm_bf16x3_kernel<WAVES_N, 7>); break;
-        case 15: e = launch(gemm_bf16x3_kernel<WAVES_N, 15>); break;
-        default: e = launch(gemm_bf16x3_kernel<WAVES_N, 0>);
+        case 1: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 1>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 1>); break;
+        case 2: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 2>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 2>); break;
+        case 3: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 3>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 3>); break;
+        case 4: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 4>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 4>); break;
+        case 7: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 7>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 7>); break;
+        case 15: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 15>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 15>); break;
+        default: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0>);
     }
 #else
-    e = launch(gemm_bf16x3_kernel<WAVES_N, 0>);
+    e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0>);
 #endif
     if (e) return e;
-    eap::set_kernel("gemm_bf16x3_kernel");
+    eap::set_kernel(tall ? "gemm_bf16x3_kernel<4, 4>" : "gemm_bf16x3_kernel<2, 4>");
     return eap::check_launch("gemm_bf16x3_f32");
 }
