@@ -193,7 +193,12 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
         };
         u32x4 bm[NI], am[MI], bh[NI], al[MI];
+#define SB() __builtin_amdgcn_sched_barrier(0)
+        // issue order pinned per product: the LDS reads of the NEXT product's new plane first, then this product's MFMAs
+        // with a quarter of the split riding between them (the compiler otherwise sinks the reads next to their use and
+        // every product starts with an LDS round trip)
         frag(st, rdB, 1, bm);
+        SB();
         if constexpr (decltype(first)::value) {
             const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -205,24 +210,36 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
             product(ah, bl);
         }
         if constexpr (!(DBG & 2)) park_half(s2, sa, 0, NPA);
+        SB();
         frag(st, rdA, 1, am);
+        SB();
         product(ah, bm);
         if constexpr (!(DBG & 2)) park_half(s2, sa, 1, NPA);
+        SB();
         frag(st, rdB, 0, bh);
+        SB();
         product(am, bm);
         if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 0, NPO);
+        SB();
         frag(st, rdA, 2, al);
+        SB();
         product(am, bh);
         if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 1, NPO);
-        product(al, bh);
+        SB();
         // branch-free on purpose (accumulators that cross a control-flow join get copied): past the last tiles the
         // staged registers are re-split into a stage nobody reads, the loads repeat the last tile, the fragment reads hit
         // a stale stage
-        if constexpr (!(DBG & 1)) load_tile(min(kt + 4, nk - 1), sa, sb);
         u32x4 ah2[MI];
         frag(s1, rdA, 0, ah2);               // the next tile's first two planes (its stage was certified a tile ago)
+        SB();
+        product(al, bh);
+        if constexpr (!(DBG & 1)) load_tile(min(kt + 4, nk - 1), sa, sb);
+        SB();
         frag(s1, rdB, 2, bl);
+        SB();
         product(ah, bh);
+        SB();
+#undef SB
 #pragma unroll
         for (int i = 0; i < MI; ++i) ah[i] = ah2[i];
         if constexpr (!(DBG & 8)) __syncthreads();
