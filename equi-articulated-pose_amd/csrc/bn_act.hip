@@ -12,6 +12,12 @@
 // pass + one apply pass, the backward one reduction pass + one apply pass.  All of it is
 // HBM-bound streaming: 16-byte loads and stores, one (cloud, channel) row segment per block,
 // per-block partial sums written out and reduced in a fixed order by the caller (deterministic).
+//
+// CLOUD variants (the eap_bn_act_cloud_* entries): the pose heads call their unary stacks once per cloud on a point subset
+// (`for i_bz in range(bz)` of ...pn_38_multi_stage.py:L706-830), i.e. BatchNorm statistics per (cloud, channel) over the
+// member points only.  Batched here: scale / shift / mean / invstd / k2 / k3 are indexed [cloud][channel], the statistics
+// weigh every element by its point's 0/1 membership, every point is normalised, and the backward's two correction terms
+// reach the member points only (d mean / dx_i = m_i / cnt, d var / dx_i = 2 m_i (x_i - mean) / cnt).
 #include "common.h"
 
 namespace {
@@ -42,11 +48,16 @@ __device__ __forceinline__ void block_reduce2(float a, float b, float *pa, float
 
 // partial[(c*B + b)*nseg + seg] = (sum, sumsq) of the segment, relative to a per-channel pivot
 // (the first element of the channel's first row) so that E[x^2] - E[x]^2 does not cancel
+// MASK: every element weighs mask[cloud][point] (0 / 1), point = element / na (na a multiple of 4: a float4 never
+// straddles two points)
+template <bool MASK>
 __global__ __launch_bounds__(TB) void bn_stats_kernel(int c, long n, int nseg, const float *__restrict__ x,
-                                                     float *__restrict__ psum, float *__restrict__ psq) {
+                                                     float *__restrict__ psum, float *__restrict__ psq,
+                                                     const float *__restrict__ mask, int na) {
     const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
     const float pivot = x[(size_t)ci * n];
     const float *row = x + ((size_t)bi * c + ci) * n;
+    const float *mrow = MASK ? mask + (size_t)bi * (unsigned)(n / na) : nullptr;
     float s = 0.f, q = 0.f;
     const long base = (long)seg * SEG;
 #pragma unroll
@@ -55,10 +66,18 @@ __global__ __launch_bounds__(TB) void bn_stats_kernel(int c, long n, int nseg, c
         if (i + 3 < n) {
             const float4 a = *reinterpret_cast<const float4 *>(row + i);
             const float d0 = a.x - pivot, d1 = a.y - pivot, d2 = a.z - pivot, d3 = a.w - pivot;
-            s += (d0 + d1) + (d2 + d3);
-            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            const float ps = (d0 + d1) + (d2 + d3), pq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            if (MASK) {
+                const float m = mrow[(unsigned)i / (unsigned)na];
+                s = fmaf(m, ps, s); q = fmaf(m, pq, q);
+            } else {
+                s += ps; q += pq;
+            }
         } else {
-            for (long j = i; j < n; ++j) { const float d = row[j] - pivot; s += d; q += d * d; }
+            for (long j = i; j < n; ++j) {
+                const float d = row[j] - pivot, m = MASK ? mrow[(unsigned)j / (unsigned)na] : 1.f;
+                s += m * d; q += m * d * d;
+            }
         }
     }
     const size_t o = ((size_t)ci * gridDim.z + bi) * nseg + seg;
@@ -67,12 +86,13 @@ __global__ __launch_bounds__(TB) void bn_stats_kernel(int c, long n, int nseg, c
 
 // RES: y = leaky_relu(x * scale + shift) + res -- the separable block's skip connection
 // (`x.feats + skip_feature`, SPConvNets/utils/base_so3poseconv.py:L319-328) folded into the epilogue pass
-template <bool RES>
+template <bool RES, bool CLOUD>
 __global__ __launch_bounds__(TB) void bn_act_fwd_kernel(int c, long n, float slope, const float *__restrict__ x,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ res, float *__restrict__ y) {
     const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
-    const float sc = scale[ci], sh = shift[ci];
+    const int si = CLOUD ? bi * c + ci : ci;
+    const float sc = scale[si], sh = shift[si];
     const size_t r0 = ((size_t)bi * c + ci) * n;
     const long base = (long)seg * SEG;
 #pragma unroll
@@ -98,13 +118,15 @@ __global__ __launch_bounds__(TB) void bn_act_fwd_kernel(int c, long n, float slo
 }
 
 // partials of sum(g) and sum(g * xhat)
+template <bool CLOUD>
 __global__ __launch_bounds__(TB) void bn_act_bwd_reduce_kernel(int c, long n, int nseg, float slope,
                                                               const float *__restrict__ gy, const float *__restrict__ x,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
                                                               float *__restrict__ pg, float *__restrict__ pgx) {
     const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
-    const float sc = scale[ci], sh = shift[ci], mu = mean[ci], is = invstd[ci];
+    const int si = CLOUD ? bi * c + ci : ci;
+    const float sc = scale[si], sh = shift[si], mu = mean[si], is = invstd[si];
     const size_t r0 = ((size_t)bi * c + ci) * n;
     const long base = (long)seg * SEG;
     float s = 0.f, q = 0.f;
@@ -130,18 +152,24 @@ __global__ __launch_bounds__(TB) void bn_act_bwd_reduce_kernel(int c, long n, in
 }
 
 // gx = k1[c] * g - k2[c] - xhat * k3[c]   with k1 = gamma*invstd, k2 = k1*mean(g), k3 = k1*mean(g*xhat)
+// CLOUD: coefficients per (cloud, channel); with a mask the two correction terms reach member points only
+template <bool CLOUD>
 __global__ __launch_bounds__(TB) void bn_act_bwd_apply_kernel(int c, long n, float slope, const float *__restrict__ gy,
                                                              const float *__restrict__ x, const float *__restrict__ scale,
                                                              const float *__restrict__ shift, const float *__restrict__ mean,
                                                              const float *__restrict__ invstd, const float *__restrict__ k2,
-                                                             const float *__restrict__ k3, float *__restrict__ gx) {
+                                                             const float *__restrict__ k3, float *__restrict__ gx,
+                                                             const float *__restrict__ mask, int na) {
     const int seg = blockIdx.x, ci = blockIdx.y, bi = blockIdx.z;
-    const float sc = scale[ci], sh = shift[ci], mu = mean[ci], is = invstd[ci], c2 = k2[ci], c3 = k3[ci];
+    const int si = CLOUD ? bi * c + ci : ci;
+    const float sc = scale[si], sh = shift[si], mu = mean[si], is = invstd[si], c2 = k2[si], c3 = k3[si];
     const size_t r0 = ((size_t)bi * c + ci) * n;
+    const float *mrow = (CLOUD && mask) ? mask + (size_t)bi * (unsigned)(n / na) : nullptr;
     const long base = (long)seg * SEG;
-    auto one = [&](float g, float xv) {
+    auto one = [&](float g, float xv, float m) {
         const float pre = fmaf(xv, sc, sh);
         const float gg = pre > 0.f ? g : g * slope;
+        if (CLOUD) return fmaf(-m, fmaf((xv - mu) * is, c3, c2), gg * sc);
         return fmaf(gg, sc, -c2) - ((xv - mu) * is) * c3;      // scale = gamma * invstd = k1
     };
 #pragma unroll
@@ -150,9 +178,10 @@ __global__ __launch_bounds__(TB) void bn_act_bwd_apply_kernel(int c, long n, flo
         if (i + 3 < n) {
             const float4 g = *reinterpret_cast<const float4 *>(gy + r0 + i);
             const float4 a = *reinterpret_cast<const float4 *>(x + r0 + i);
-            *reinterpret_cast<float4 *>(gx + r0 + i) = make_float4(one(g.x, a.x), one(g.y, a.y), one(g.z, a.z), one(g.w, a.w));
+            const float m = mrow ? mrow[(unsigned)i / (unsigned)na] : 1.f;
+            *reinterpret_cast<float4 *>(gx + r0 + i) = make_float4(one(g.x, a.x, m), one(g.y, a.y, m), one(g.z, a.z, m), one(g.w, a.w, m));
         } else {
-            for (long j = i; j < n; ++j) gx[r0 + j] = one(gy[r0 + j], x[r0 + j]);
+            for (long j = i; j < n; ++j) gx[r0 + j] = one(gy[r0 + j], x[r0 + j], mrow ? mrow[(unsigned)j / (unsigned)na] : 1.f);
         }
     }
 }
@@ -168,7 +197,7 @@ extern "C" int eap_bn_stats_f32(int b, int c, int64_t n, const float *x, float *
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_stats: row length must be a multiple of 4; at most 65535 channels / clouds");
     const int nseg = nseg_of(n);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, x, psum, psq);
+    hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, x, psum, psq, (const float *)nullptr, 1);
     return eap::check_launch("bn_stats");
 }
 
@@ -176,7 +205,7 @@ extern "C" int eap_bn_act_fwd_f32(int b, int c, int64_t n, float slope, const fl
                                   const float *shift, float *y, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_fwd: row length must be a multiple of 4; at most 65535 channels / clouds");
-    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift,
+    hipLaunchKernelGGL((bn_act_fwd_kernel<false, false>), dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift,
                        (const float *)nullptr, y);
     return eap::check_launch("bn_act_fwd");
 }
@@ -185,7 +214,7 @@ extern "C" int eap_bn_act_add_fwd_f32(int b, int c, int64_t n, float slope, cons
                                       const float *shift, const float *res, float *y, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_add_fwd: row length must be a multiple of 4; at most 65535 channels / clouds");
-    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift, res, y);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<true, false>), dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift, res, y);
     return eap::check_launch("bn_act_add_fwd");
 }
 
@@ -195,7 +224,7 @@ extern "C" int eap_bn_act_bwd_reduce_f32(int b, int c, int64_t n, float slope, c
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_bwd_reduce: row length must be a multiple of 4; at most 65535 channels / clouds");
     const int nseg = nseg_of(n);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, slope, gy, x,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, slope, gy, x,
                        scale, shift, mean, invstd, pg, pgx);
     return eap::check_launch("bn_act_bwd_reduce");
 }
@@ -206,7 +235,63 @@ extern "C" int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, co
                                         eap_stream_t stream) {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!ok_dims(b, c, n) || (n & 3) != 0) return eap::bad_arg("bn_act_bwd_apply: row length must be a multiple of 4; at most 65535 channels / clouds");
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, gy, x,
-                       scale, shift, mean, invstd, k2, k3, gx);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, gy, x,
+                       scale, shift, mean, invstd, k2, k3, gx, (const float *)nullptr, 1);
     return eap::check_launch("bn_act_bwd_apply");
+}
+
+// ---- per-cloud statistics over a point subset (the pose heads' batched per-cloud calls) ---------------------------
+namespace {
+inline int cloud_dims(const char *who, int b, int c, long n, int na, bool masked) {
+    char buf[200];
+    if (!ok_dims(b, c, n) || (n & 3) != 0 || n >= (1l << 31)) {
+        snprintf(buf, sizeof(buf), "%s: row length must be a multiple of 4 below 2^31; at most 65535 channels / clouds", who);
+        return eap::bad_arg(buf);
+    }
+    if (masked && (na <= 0 || (na & 3) != 0 || n % na != 0)) {
+        snprintf(buf, sizeof(buf), "%s: with a mask a row is [points][na], na a multiple of 4", who);
+        return eap::bad_arg(buf);
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int eap_bn_stats_masked_f32(int b, int c, int64_t n, int na, const float *x, const float *mask, float *psum, float *psq,
+                                       eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!mask) return eap::bad_arg("bn_stats_masked: mask is null");
+    if (int e = cloud_dims("bn_stats_masked", b, c, (long)n, na, true)) return e;
+    const int nseg = nseg_of(n);
+    hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, x, psum, psq, mask, na);
+    return eap::check_launch("bn_stats_masked");
+}
+
+extern "C" int eap_bn_act_cloud_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale, const float *shift,
+                                        float *y, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (int e = cloud_dims("bn_act_cloud_fwd", b, c, (long)n, 0, false)) return e;
+    hipLaunchKernelGGL((bn_act_fwd_kernel<false, true>), dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, x, scale, shift,
+                       (const float *)nullptr, y);
+    return eap::check_launch("bn_act_cloud_fwd");
+}
+
+extern "C" int eap_bn_act_cloud_bwd_reduce_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x, const float *scale,
+                                               const float *shift, const float *mean, const float *invstd, float *pg, float *pgx,
+                                               eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (int e = cloud_dims("bn_act_cloud_bwd_reduce", b, c, (long)n, 0, false)) return e;
+    const int nseg = nseg_of(n);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, dim3(nseg, c, b), dim3(TB), 0, eap::S(stream), c, (long)n, nseg, slope, gy, x,
+                       scale, shift, mean, invstd, pg, pgx);
+    return eap::check_launch("bn_act_cloud_bwd_reduce");
+}
+
+extern "C" int eap_bn_act_cloud_bwd_apply_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *x,
+                                              const float *scale, const float *shift, const float *mean, const float *invstd,
+                                              const float *k2, const float *k3, const float *mask, float *gx, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (int e = cloud_dims("bn_act_cloud_bwd_apply", b, c, (long)n, na, mask != nullptr)) return e;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, gy, x,
+                       scale, shift, mean, invstd, k2, k3, gx, mask, mask ? na : 1);
+    return eap::check_launch("bn_act_cloud_bwd_apply");
 }

@@ -302,6 +302,35 @@ def bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, slope):
     return gx
 
 
+# per-cloud statistics over a point subset (the pose heads' batched per-cloud calls); scale .. k3 are [b, c]
+
+def bn_stats_masked(x, b, c, n, na, mask):
+    """-> (sum, sumsq) of mask * (x - pivot) per (cloud, channel), float64 [b, c] (pivot = x[0, c, 0])."""
+    ps, pq = _partials(x, b, c, n)
+    call('eap_bn_stats_masked_f32', x, b, c, _I64(n), na, _ptr(x), _ptr(mask), _ptr(ps), _ptr(pq))
+    return ps.view(c, b, -1).sum(2, dtype=torch.float64).t(), pq.view(c, b, -1).sum(2, dtype=torch.float64).t()
+
+
+def bn_act_cloud_fwd(x, b, c, n, scale, shift, slope):
+    y = torch.empty_like(x)
+    call('eap_bn_act_cloud_fwd_f32', x, b, c, _I64(n), _F32(slope), _ptr(x), _ptr(scale), _ptr(shift), _ptr(y))
+    return y
+
+
+def bn_act_cloud_bwd_reduce(gy, x, b, c, n, scale, shift, mean, invstd, slope):
+    pg, pgx = _partials(x, b, c, n)
+    call('eap_bn_act_cloud_bwd_reduce_f32', x, b, c, _I64(n), _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
+         _ptr(mean), _ptr(invstd), _ptr(pg), _ptr(pgx))
+    return pg.view(c, b, -1).sum(2, dtype=torch.float64).t(), pgx.view(c, b, -1).sum(2, dtype=torch.float64).t()
+
+
+def bn_act_cloud_bwd_apply(gy, x, b, c, n, na, scale, shift, mean, invstd, k2, k3, mask, slope):
+    gx = torch.empty_like(x)
+    call('eap_bn_act_cloud_bwd_apply_f32', x, b, c, _I64(n), na, _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
+         _ptr(mean), _ptr(invstd), _ptr(k2), _ptr(k3), _ptr(mask), _ptr(gx))
+    return gx
+
+
 def so3_intra_conv(feats, W, intra_idx32):
     """Implicit-GEMM intra conv forward: feats [b,c,p,na], W [o, c*nt], intra_idx int32 [na,nt] -> [b,o,p,na]."""
     b, c, p, na = feats.shape

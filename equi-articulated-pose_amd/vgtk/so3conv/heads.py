@@ -422,38 +422,90 @@ class SO3OutBlockRTWithMaskSep(nn.Module):
         return output
 
 
-def _masked_unary_stack(x, m, cnt, linears, norms):
-    """_unary_stack for B independent batch-1 calls on point SUBSETS at once: x [B,C,P,A] full clouds, m [B,1,P,1] the
-    0/1 membership, cnt [B,1] = points in the subset x anchors.  Training-mode BatchNorm statistics are those of each
-    cloud's subset alone (what a batch-1 call on the gathered subset computes), and the running statistics receive the
-    B momentum updates in cloud order, as the loop would apply them."""
+class _SubsetBNAct(torch.autograd.Function):
+    """leaky_relu(BatchNorm2d(y + bias)) with the statistics of every cloud's member points alone -- what B separate
+    batch-1 calls on the gathered subsets compute -- as two passes over y forward (masked statistics, apply) and two
+    backward (reduce, apply): csrc/bn_act.hip, the eap_bn_act_cloud_* entries.  Every point is normalised; the head's
+    later masked poolings drop the non-members.  The running statistics receive the B momentum updates in cloud
+    order, as the loop would apply them."""
+
+    @staticmethod
+    def forward(ctx, y, bias, mask, weight, beta, running_mean, running_var, training, momentum, eps, slope):
+        y = y.contiguous()
+        b, c, p, na = y.shape
+        n = p * na
+        if training:
+            cnt = (mask.sum(1, dtype=torch.float64) * na).view(b, 1)                # member points x anchors
+            pivot = y.view(b, c, n)[0, :, 0].double().view(1, c)
+            s1, s2 = _hip.bn_stats_masked(y, b, c, n, na, mask)                     # of y - pivot, [b, c] float64
+            d = s1 / cnt
+            var = (s2 / cnt - d * d).clamp_min(0.0)                                 # biased, as BatchNorm normalises with
+            mean = d + pivot                                                        # of y (without the bias)
+            with torch.no_grad():
+                full = (mean + bias.double().view(1, c)) if bias is not None else mean
+                unb = var * (cnt / (cnt - 1.0).clamp_min(1.0))
+                # B sequential updates r <- (1 - mom) r + mom v_i in closed form
+                keep = (1.0 - momentum) ** torch.arange(b - 1, -1, -1, device=y.device, dtype=torch.float64).view(b, 1)
+                running_mean.mul_((1.0 - momentum) ** b).add_((momentum * (keep * full).sum(0)).to(running_mean.dtype))
+                running_var.mul_((1.0 - momentum) ** b).add_((momentum * (keep * unb).sum(0)).to(running_var.dtype))
+        else:
+            mean = (running_mean.double() - (bias.double() if bias is not None else 0.0)).view(1, c).expand(b, c)
+            var = running_var.double().view(1, c).expand(b, c)
+        invstd = torch.rsqrt(var + eps)
+        scale64 = weight.double().view(1, c) * invstd
+        scale = scale64.float().contiguous()
+        shift = (beta.double().view(1, c) - mean * scale64).float().contiguous()
+        out = _hip.bn_act_cloud_fwd(y, b, c, n, scale, shift, slope)
+        ctx.save_for_backward(y, scale, shift, mean.float().contiguous(), invstd.float().contiguous(), mask)
+        ctx.training, ctx.slope, ctx.dims, ctx.has_bias = training, slope, (b, c, n, na), bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, scale, shift, mean, invstd, mask = ctx.saved_tensors
+        b, c, n, na = ctx.dims
+        g = g.contiguous()
+        sg, sgx = _hip.bn_act_cloud_bwd_reduce(g, y, b, c, n, scale, shift, mean, invstd, ctx.slope)     # [b, c] float64
+        g_y = None
+        if ctx.needs_input_grad[0]:
+            if ctx.training:
+                cnt = (mask.sum(1, dtype=torch.float64) * na).view(b, 1)
+                k2 = (scale.double() * sg / cnt).float().contiguous()
+                k3 = (scale.double() * sgx / cnt).float().contiguous()
+            else:
+                k2 = torch.zeros_like(scale)
+                k3 = torch.zeros_like(scale)
+            g_y = _hip.bn_act_cloud_bwd_apply(g, y, b, c, n, na, scale, shift, mean, invstd, k2, k3, mask, ctx.slope)
+        # the bias is absorbed by the batch mean in training mode (its gradient is exactly zero); in eval mode it shifts the
+        # pre-activation like beta does
+        g_bias = None
+        if ctx.has_bias:
+            g_bias = torch.zeros(c, dtype=torch.float32, device=g.device) if ctx.training else (sg * scale.double()).sum(0).float()
+        return g_y, g_bias, None, sgx.sum(0).float(), sg.sum(0).float(), None, None, None, None, None, None
+
+
+def _subset_batchnorm_act(y, bias, mask, bn, slope):
+    """act(bn(y + bias)) per cloud subset; y [B,C,P,A] raw contraction output, mask [B,P] float 0/1, slope 0 = relu."""
+    if bn.training:
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(y.shape[0])
+    if bn.momentum is None:
+        raise NotImplementedError('pose_head_over_subsets: cumulative-average BatchNorm (momentum=None) is not batched')
+    return _SubsetBNAct.apply(y, bias, mask, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, slope)
+
+
+def _masked_unary_stack(x, mask, linears, norms):
+    """_unary_stack for B independent batch-1 calls on point SUBSETS at once: x [B,C,P,A] full clouds, mask [B,P] the
+    0/1 membership.  Training-mode BatchNorm statistics are those of each cloud's subset alone (what a batch-1 call on
+    the gathered subset computes), and the running statistics receive the B momentum updates in cloud order."""
     for lid, linear in enumerate(linears):
         b, c, n, a = x.shape
         y = L.so3_contract(linear.weight.view(linear.out_channels, c), x.reshape(b, c, n * a)).view(b, linear.out_channels, n, a)
-        if linear.bias is not None:
-            y = y + linear.bias.view(1, -1, 1, 1)
         if norms is not None:
-            y = _subset_batchnorm(y, m, cnt, norms[lid])
-        x = F.relu(y)
+            x = _subset_batchnorm_act(y, linear.bias, mask, norms[lid], 0.0)
+        else:
+            x = F.relu(y + linear.bias.view(1, -1, 1, 1) if linear.bias is not None else y)
     return x
-
-
-def _subset_batchnorm(y, m, cnt, bn):
-    """nn.BatchNorm2d applied to every cloud's subset as its own batch-1 call (see _masked_unary_stack)."""
-    if bn.training:
-        ym = y * m
-        mean = ym.sum((2, 3)) / cnt                                        # [B, C]
-        var = ((ym * ym).sum((2, 3)) / cnt - mean * mean).clamp_min(0.0)   # biased, as BatchNorm normalises with
-        with torch.no_grad():
-            unb = var * (cnt / (cnt - 1.0).clamp_min(1.0))
-            for i in range(y.shape[0]):                                    # B tiny [C]-vector updates, in loop order
-                bn.running_mean.mul_(1.0 - bn.momentum).add_(mean[i], alpha=bn.momentum)
-                bn.running_var.mul_(1.0 - bn.momentum).add_(unb[i], alpha=bn.momentum)
-            bn.num_batches_tracked.add_(y.shape[0])
-        mean, var = mean[:, :, None, None], var[:, :, None, None]
-    else:
-        mean, var = bn.running_mean.view(1, -1, 1, 1), bn.running_var.view(1, -1, 1, 1)
-    return (y - mean) * torch.rsqrt(var + bn.eps) * bn.weight.view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
 
 
 def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
@@ -469,20 +521,22 @@ def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
         raise NotImplementedError('pose_head_over_subsets: mean / max pooling without the global scalar only')
     import math
     b, _, n, na = feats.shape
-    m = member.to(feats.dtype).view(b, 1, n, 1)
-    npts = m.sum((2, 3))                                                    # [B, 1]
-    cnt = npts * na
+    mask = member.to(feats.dtype).contiguous()                              # [B, P]
+    m = mask.view(b, 1, n, 1)
+    npts = mask.sum(1, keepdim=True)                                        # [B, 1]
 
     def pool(f):
-        return (f * m).max(2)[0] if head.pooling_method == 'max' else (f * m).sum(2) / npts.view(b, 1, 1)
+        if head.pooling_method == 'max':
+            return (f * m).max(2)[0]
+        return slot_masked_mean(f, mask.view(b, 1, n))[:, 0]               # [B, c, A]: one pass over f (csrc/heads.hip)
 
-    x_out = pool(_masked_unary_stack(feats, m, cnt, head.linear, head.norm))                     # [B, c, A]
-    shared = _masked_unary_stack(feats, m, cnt, head.trans_linear, head.trans_norm)            # [B, c, P, A]
+    x_out = pool(_masked_unary_stack(feats, mask, head.linear, head.norm))                       # [B, c, A]
+    shared = _masked_unary_stack(feats, mask, head.trans_linear, head.trans_norm)              # [B, c, P, A]
     trans_x_out = pool(shared)
     d0, dbn, dact, d1 = head.regressor_dense_layer
     cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, n, -1), shared], dim=1).contiguous()
     y = L.so3_contract(d0.weight.view(d0.out_channels, cat.shape[1]), cat.reshape(b, cat.shape[1], n * na)).view(b, d0.out_channels, n, na)
-    y = F.leaky_relu(_subset_batchnorm(y + d0.bias.view(1, -1, 1, 1), m, cnt, dbn), dact.negative_slope)
+    y = _subset_batchnorm_act(y, d0.bias, mask, dbn, dact.negative_slope)
     t_out = F.conv2d(y, d1.weight, d1.bias).reshape(b, head.num_heads, 3, n, na)
     A = anchors if anchors.dim() == 4 else anchors.unsqueeze(0)
     y_t = torch.matmul(A.unsqueeze(1), t_out.permute(0, 1, 4, 2, 3).contiguous())                # [B, h, A, 3, P]

@@ -370,6 +370,26 @@ int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, const float *
                              const float *invstd, const float *k2, const float *k3, float *gx,
                              eap_stream_t stream);
 
+/* Per-cloud statistics over a point subset: the pose heads run their unary stacks once per cloud on the cloud's member
+ * points (`for i_bz in range(bz): ...` SPConvNets/models/..pn_38_multi_stage.py:L706-830, the head's BatchNorm2d layers
+ * SPConvNets/utils/base_so3conv.py: SO3OutBlockRTWithMaskSep), i.e. BatchNorm statistics per (cloud, channel) over the
+ * members.  Batched form: a row is [points][na], mask [b, points] holds 0 / 1; scale, shift, mean, invstd, k2, k3 are
+ * [b, c]; every point is normalised, the statistics and the backward's two correction terms see members only. */
+/* partial sums [c][b][segments] of mask * (x - pivot_c) and mask * (x - pivot_c)^2, pivot_c = x[0, c, 0] */
+int eap_bn_stats_masked_f32(int b, int c, int64_t n, int na, const float *x, const float *mask, float *psum, float *psq,
+                            eap_stream_t stream);
+/* y = leaky_relu(x * scale[b,c] + shift[b,c], slope) */
+int eap_bn_act_cloud_fwd_f32(int b, int c, int64_t n, float slope, const float *x, const float *scale, const float *shift,
+                             float *y, eap_stream_t stream);
+/* partial sums of g and g * xhat over ALL points of the row, statistics per (cloud, channel) */
+int eap_bn_act_cloud_bwd_reduce_f32(int b, int c, int64_t n, float slope, const float *gy, const float *x, const float *scale,
+                                    const float *shift, const float *mean, const float *invstd, float *pg, float *pgx,
+                                    eap_stream_t stream);
+/* gx = scale[b,c] * g - mask * (k2[b,c] + xhat * k3[b,c]);  mask may be null (all ones) */
+int eap_bn_act_cloud_bwd_apply_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *x,
+                                   const float *scale, const float *shift, const float *mean, const float *invstd,
+                                   const float *k2, const float *k3, const float *mask, float *gx, eap_stream_t stream);
+
 /* ---- heads on the backbone's [b,c,n,na] feature map ------------------------ */
 /* Anchor attention pooling, InvPPOutBlockOurs.forward (SPConvNets/utils/base_so3conv.py:L905-912):
  * conf[b,n,a] = softmax_a(logits[b,n,a] * temperature), out[b,c,n] = sum_a x[b,c,n,a] conf[b,n,a].  na % 4 == 0, <= 64.

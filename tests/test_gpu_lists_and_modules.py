@@ -447,6 +447,61 @@ def test_pose_head_matches_reference_golden(dev, golden):
                     assert rel_err(v.cpu().numpy(), np.asarray(G[f'after_{k}'])) < 1e-5, k
 
 
+@pytest.mark.parametrize('shape,slope', [((3, 8, 40, 60), 0.0), ((2, 5, 700, 60), 0.2), ((4, 16, 33, 12), 0.01)])
+def test_subset_batchnorm_act_matches_torch(dev, shape, slope):
+    """csrc/bn_act.hip eap_bn_act_cloud_*: leaky_relu(BatchNorm2d(y + bias)) with per-cloud statistics over a point subset
+    against plain torch fp32 ops (per-cloud nn.functional.batch_norm on the gathered subset statistics), training and
+    eval mode, forward, all gradients, running statistics."""
+    import vgtk.so3conv.heads as H
+    torch.manual_seed(5)
+    B, C, P, A = shape
+    y0 = (torch.randn(B, C, P, A, device=dev) * 1.7 + 0.4)
+    bias0 = torch.randn(C, device=dev)
+    member = torch.rand(B, P, device=dev) > 0.4
+    member[:, 0] = True
+    member[0] = False; member[0, :3] = True
+    mask = member.float()
+    probe = torch.randn(B, C, P, A, device=dev) * mask.view(B, 1, P, 1) + 0.1 * torch.randn(B, C, P, A, device=dev)
+    for training in (True, False):
+        bns = [torch.nn.BatchNorm2d(C).to(dev).train(training) for _ in range(2)]
+        for bn in bns:
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+                bn.running_mean.copy_(torch.linspace(-0.2, 0.6, C)); bn.running_var.copy_(torch.linspace(0.7, 2.0, C))
+        res = []
+        for which, bn in enumerate(bns):
+            y = y0.clone().requires_grad_(True)
+            bias = bias0.clone().requires_grad_(True)
+            if which == 0:                       # reference: one batch-1 BatchNorm call per cloud; statistics of the members
+                outs = []
+                for b in range(B):
+                    sel = member[b].nonzero().squeeze(1)
+                    z = y[b:b + 1] + bias.view(1, C, 1, 1)
+                    if training:
+                        sub = z[:, :, sel]
+                        mean = sub.mean((0, 2, 3)); var = sub.var((0, 2, 3), unbiased=False)
+                        cnt = sub.numel() / C
+                        with torch.no_grad():
+                            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                            bn.running_var.mul_(1 - bn.momentum).add_(var * cnt / max(cnt - 1, 1), alpha=bn.momentum)
+                    else:
+                        mean, var = bn.running_mean, bn.running_var
+                    zn = (z - mean.view(1, C, 1, 1)) * torch.rsqrt(var.view(1, C, 1, 1) + bn.eps) * bn.weight.view(1, C, 1, 1) + bn.bias.view(1, C, 1, 1)
+                    outs.append(torch.nn.functional.leaky_relu(zn, slope))
+                out = torch.cat(outs, 0)
+            else:
+                out = H._subset_batchnorm_act(y, bias, mask, bn, slope)
+            (out * probe).sum().backward()
+            res.append((out.detach(), y.grad, bias.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+        names = ('out', 'dy', 'dbias', 'dgamma', 'dbeta', 'running_mean', 'running_var')
+        for name, r, g in zip(names, res[0], res[1]):
+            r, g = r.cpu().numpy(), g.cpu().numpy()
+            if name == 'dbias' and training:     # absorbed by the batch mean: rounding noise in torch, exactly zero here
+                assert np.abs(g).max() == 0.0 and np.abs(r).max() < 1e-3 * np.abs(res[0][1].cpu().numpy()).max() * P * A
+                continue
+            assert rel_err(g, r) < 2e-5, (training, name, rel_err(g, r))
+
+
 @pytest.mark.parametrize('pooling', ['max', 'mean'])
 def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling):
     """vgtk.so3conv.pose_head_over_subsets (one call per slot) against the model's inner loop: the head called once per
@@ -482,6 +537,36 @@ def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling):
         for (k, v), (_, w) in zip(ref_head.state_dict().items(), fast_head.state_dict().items()):
             if 'running' in k:
                 assert rel_err(w.cpu().numpy(), v.cpu().numpy()) < 1e-5, k
+        # gradients of a random linear functional of every output: the fused per-cloud BatchNorm + activation backward
+        # (csrc/bn_act.hip, eap_bn_act_cloud_*) and the masked pooling against autograd through the per-cloud loop
+        ref_head, fast_head = copy.deepcopy(head).train(training), copy.deepcopy(head).train(training)
+        keys = ('R', 'T', 'axis', 'pv_points', 'central_points')
+        gen = torch.Generator().manual_seed(11)
+        f_ref = feats.clone().requires_grad_(True)
+        outs = []
+        for b in range(B):
+            sel = member[b].nonzero().squeeze(1)
+            fx, px = f_ref[b:b + 1, :, sel].contiguous(), xyz[b:b + 1, :, sel].contiguous()
+            outs.append(ref_head(zptk.SphericalPointCloud(px, fx, None), None, fx, trans_xyz=px, anchors=anchors.unsqueeze(0)))
+        probes = {k: torch.randn(torch.cat([o[k] for o in outs], 0).shape, generator=gen).to(dev) for k in keys}
+        sum((torch.cat([o[k] for o in outs], 0) * probes[k]).sum() for k in keys).backward()
+        f_fast = feats.clone().requires_grad_(True)
+        got = sptk.pose_head_over_subsets(fast_head, f_fast, xyz, member, anchors)
+        sum((got[k] * probes[k]).sum() for k in keys).backward()
+        assert rel_err(f_fast.grad.cpu().numpy(), f_ref.grad.cpu().numpy()) < 5e-5, training
+        assert (f_fast.grad.permute(0, 2, 1, 3)[~member] == 0).all(), 'points outside the subset must receive no gradient'
+        for (k, v), (_, w) in zip(ref_head.named_parameters(), fast_head.named_parameters()):
+            if v.grad is None:
+                assert w.grad is None or w.grad.abs().max().item() == 0.0, k
+                continue
+            ref_g = v.grad.cpu().numpy()
+            pre_bn_bias = training and k.endswith('.bias') and (k.startswith('linear.') or k.startswith('trans_linear.') or k.startswith('regressor_dense_layer.0.'))
+            if pre_bn_bias:        # a bias in front of a training-mode BatchNorm is absorbed by the batch mean: rounding noise in
+                                   # autograd's sum, exactly zero in the fused backward
+                top = max(float(p_.grad.abs().max()) for p_ in ref_head.parameters() if p_.grad is not None)
+                assert np.abs(ref_g).max() < 1e-4 * top and (w.grad is None or np.abs(w.grad.cpu().numpy()).max() == 0.0), k
+            else:
+                assert rel_err(w.grad.cpu().numpy(), ref_g) < 1e-4, (training, k)
 
 
 # ------------------------------------------------------------------------------------------------------------------
