@@ -18,13 +18,21 @@
 // vector instructions per MFMA riding along for free (tools/microbench/mfma_bf16_split.hip) -- the split is done ON THE
 // FLY on the way global -> VGPR -> LDS, so neither operand is ever stored in split form.
 //
-// Geometry (that of csrc/gemm_dma_f32.hip): 4 waves = one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256
-// AGPR/VGPRs), block tile 256 x 256, BK = 16.  Thread t owns row t of both operand tiles: it loads the row's 16 k's as
-// four 16-byte words three k-tiles ahead, splits them between the current tile's products and parks the three planes in the
+// Geometry: 8 waves (two per SIMD: the second wave issues matrix instructions while the first waits for its fragments or
+// its staged loads), wave tile 128 x 64 (8 accumulator tiles = 128 registers), block tile 256 x 256 (128 x 256 for row
+// counts that are not a multiple of 256), BK = 16.  Per k-tile every thread stages up to four 16-byte pieces (4 k's of one
+// operand row) global -> VGPR four k-tiles ahead, splits them BETWEEN the tile's products and parks the three planes in the
 // LDS stage of the tile after next ([plane][row][16 k] bf16, 32 bytes per row; the row's two 16-byte k-halves swapped by
-// ((row >> 2) ^ (row >> 3)) & 1: conflict-free for the parking ds_write_b128 and the fragment ds_read_b128).  One
-// __syncthreads per k-tile, three LDS stages (144 KB): the barrier that closes tile t certifies the stage of tile t + 2,
-// so the first fragments of tile t + 1 are read before tile t's last product.
+// ((row >> 2) ^ (row >> 3)) & 1: conflict-free for the fragment ds_read_b128).  One __syncthreads per k-tile, three LDS
+// stages (144 KB): the barrier that closes tile t certifies the stage of tile t + 2, so the first fragments of tile t + 1
+// are read before tile t's last product.
+//
+// B operand layouts (template BMODE; A is always k-contiguous and shared by the batch):
+//   0  B_z[N, K] k-contiguous rows: one 16-byte load per piece (the transposed intermediate of the inter conv)
+//   1  B_z[K, N] row-major ("NN"): the pointwise contractions `so3_contract` (every 1 x 1 conv of the blocks and heads over
+//      [b, C, P*A]); a piece = four dword loads from four k-rows, lanes along n (256 contiguous bytes per request)
+//   2  implicit intra-SO(3) gather: B[(c, t), (p, a)] = F_z[c, p, idx[a, t]] (so3conv/functional.py:L2553-2602), the 60 x 12
+//      table in LDS; a piece = the four taps t0..t0+3 of one channel, four dword loads inside the point's 240-byte row
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -40,7 +48,7 @@ constexpr int BK = 16, BN = 256;
 constexpr unsigned PLANE_BYTES = 256 * BK * 2;                 // one plane of one operand tile: 8 KB
 constexpr unsigned OPER_BYTES = 3 * PLANE_BYTES;               // 24 KB
 constexpr unsigned STAGE_BYTES = 2 * OPER_BYTES;               // 48 KB
-constexpr size_t SHMEM = 3 * STAGE_BYTES;                      // 144 KB
+constexpr size_t SHMEM = 3 * STAGE_BYTES;                      // 144 KB (+ TBL_BYTES for the gather table)
 constexpr int WAVES_N = 4;                                     // 8 waves per workgroup (see the kernel's template comment)
 
 struct Args {
@@ -49,7 +57,10 @@ struct Args {
     const float *B; long long ldb, sB;
     float *C; long long ldc, sC;
     int tiles_m, tiles_n;
+    const int *tbl; int na;             // BMODE 2: gather table [na][TAPS], anchors per point
 };
+constexpr int TAPS = 12;                // intra_idx is [60, 12] (vgtk/so3conv/functional.py get_intra_idx)
+constexpr unsigned TBL_BYTES = 64 * TAPS * 4;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // [15:0] = bf16(a), [31:16] = bf16(b), round to nearest even
     unsigned r;
@@ -88,7 +99,7 @@ __device__ __forceinline__ void split_quad(const f32x4 &a, const f32x4 &b, u32x4
 // its LDS fragments or its staged loads
 // MI = row tiles per wave: 4 -> block tile 256 x 256; 2 -> 128 x 256 (wave tile 64 x 64) for row counts that would leave
 // half of a 256-row tile empty (the second layer's contraction: 128 output channels)
-template <int MI, int WN, int DBG>
+template <int MI, int WN, int DBG, int BMODE>
 __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     constexpr int NT = 128 * WN, NI = 8 / WN, WM = 8 / WN, BM = 32 * MI * WM, RG = NT / 4;   // threads, column tiles per wave, waves along M, rows per block, rows per staging group
     constexpr int NPA = BM / RG, NPO = 256 / RG;                                              // staged pieces per thread: A tile, B tile
@@ -118,45 +129,82 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     //      tile (rows 64 u + (t >> 2), u = 0..3), 4..7 of the B tile, k-chunk t & 3.  Request address = wave-uniform base of
     //      the row group (RG = 64 or 128 rows; clamped to the last group that exists: M, N multiples of RG) + one 32-bit offset per lane.
     const int c4 = t & 3, rq = t >> 2;
+    // BMODE 1, 2: lanes along the columns (a request = 64 consecutive columns of one k-row), the k-chunk wave-uniform
+    const int c4b = BMODE ? __builtin_amdgcn_readfirstlane(t >> 7) : c4, rqb = BMODE ? (t & 127) : rq;
     const float *baseA[NPA], *baseB[NPO];
 #pragma unroll
     for (int u = 0; u < NPA; ++u) baseA[u] = g.A + (long long)min(m0 + RG * u, g.M - RG) * g.lda;
 #pragma unroll
     for (int u = 0; u < NPO; ++u) baseB[u] = B + (long long)min(n0 + RG * u, g.N - RG) * g.ldb;
     const unsigned offA = (unsigned)((long long)rq * g.lda + 4 * c4) * 4u, offB = (unsigned)((long long)rq * g.ldb + 4 * c4) * 4u;
+    unsigned colB[NPO], tapB[NPO];      // BMODE 1: byte offset of the piece's column; BMODE 2: of its point's row, and of its anchor's table row
+#pragma unroll
+    for (int u = 0; u < NPO; ++u) {
+        const int n = min(n0 + RG * u, g.N - RG) + rqb;
+        if constexpr (BMODE == 2) {
+            const int pt = n / g.na;
+            colB[u] = (unsigned)(pt * g.na) * 4u;
+            tapB[u] = (unsigned)(n - pt * g.na) * (TAPS * 4u);
+        } else {
+            colB[u] = (unsigned)n * 4u; tapB[u] = 0;
+        }
+    }
     // LDS: row r of a plane is 32 bytes (16 bf16); its two 16-byte k-halves are swapped by b(r) = ((r >> 2) ^ (r >> 3)) & 1:
     // conflict-free for the fragment ds_read_b128 (four 16-lane groups, 256-byte bank window); the 8-byte parking writes of
-    // 16 contiguous lanes cover 4 whole rows = 128 contiguous bytes either way.  rows 64 u + rq: bits 2, 3 of the row = bits of rq
-    const unsigned wr_off = (unsigned)rq * 32u + ((16u * (unsigned)(c4 >> 1)) ^ ((((unsigned)rq >> 2) ^ ((unsigned)rq >> 3)) & 1u) * 16u) + 8u * (unsigned)(c4 & 1);
+    // 16 contiguous lanes cover 4 whole rows = 128 contiguous bytes either way (BMODE 0; lanes along the columns write 8 of
+    // every 32 bytes: two-way conflicts on a sixth of the LDS traffic).  rows RG u + rq: bits 2, 3 of the row = bits of rq
+    auto wr_of = [](int r, int c) { return (unsigned)r * 32u + ((16u * (unsigned)(c >> 1)) ^ ((((unsigned)r >> 2) ^ ((unsigned)r >> 3)) & 1u) * 16u) + 8u * (unsigned)(c & 1); };
+    const unsigned wr_off = wr_of(rq, c4), wr_offB = wr_of(rqb, c4b);
+    const unsigned char *tbl = smem + 3 * STAGE_BYTES;
+    if constexpr (BMODE == 2) {
+        for (int i = t; i < g.na * TAPS; i += NT) reinterpret_cast<int *>(smem + 3 * STAGE_BYTES)[i] = g.tbl[i] * 4;   // byte offsets
+        __syncthreads();
+    }
     const int nk = g.K / BK;
 
     Row16 ra0, rb0, ra1, rb1;                                           // (A pieces 0..3, B pieces 0..3) of two tiles in flight
     auto ld = [&](const float *ubase, unsigned voff) __attribute__((always_inline)) {
         return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(ubase) + voff);
     };
+    auto ldw = [&](const float *ubase, unsigned voff) __attribute__((always_inline)) {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + voff);
+    };
     auto load_tile = [&](int kt, Row16 &a, Row16 &b) __attribute__((always_inline)) {
         const int ko = kt * BK;
         a.q0 = ld(baseA[0] + ko, offA);
         if constexpr (NPA == 2) a.q1 = ld(baseA[1] + ko, offA);
-        b.q0 = ld(baseB[0] + ko, offB); b.q1 = ld(baseB[1] + ko, offB);
+        if constexpr (BMODE == 0) {
+            b.q0 = ld(baseB[0] + ko, offB); b.q1 = ld(baseB[1] + ko, offB);
+        } else if constexpr (BMODE == 1) {
+            const float *r0 = B + (long long)(ko + 4 * c4b) * g.ldb, *r1 = r0 + g.ldb, *r2 = r1 + g.ldb, *r3 = r2 + g.ldb;   // wave-uniform
+            b.q0 = (f32x4){ldw(r0, colB[0]), ldw(r1, colB[0]), ldw(r2, colB[0]), ldw(r3, colB[0])};
+            b.q1 = (f32x4){ldw(r0, colB[1]), ldw(r1, colB[1]), ldw(r2, colB[1]), ldw(r3, colB[1])};
+        } else {
+            const int k0 = ko + 4 * c4b, ch = k0 / TAPS, t0 = k0 - ch * TAPS;                  // wave-uniform: channel, first tap
+            const float *r = B + (long long)ch * g.ldb;
+            const u32x4 o0 = *reinterpret_cast<const u32x4 *>(tbl + tapB[0] + 4 * t0);
+            const u32x4 o1 = *reinterpret_cast<const u32x4 *>(tbl + tapB[1] + 4 * t0);
+            b.q0 = (f32x4){ldw(r, colB[0] + o0.x), ldw(r, colB[0] + o0.y), ldw(r, colB[0] + o0.z), ldw(r, colB[0] + o0.w)};
+            b.q1 = (f32x4){ldw(r, colB[1] + o1.x), ldw(r, colB[1] + o1.y), ldw(r, colB[1] + o1.z), ldw(r, colB[1] + o1.w)};
+        }
     };
     // one piece (4 k's) -> three 8-byte words, parked at its place in row 64 u + rq of the operand tile
-    auto park_piece = [&](unsigned char *oper, int u, const f32x4 &q) __attribute__((always_inline)) {
+    auto park_piece = [&](unsigned char *oper, int u, const f32x4 &q, unsigned wr) __attribute__((always_inline)) {
         unsigned h0, m0_, l0, h1, m1, l1;
         split_pair(q.x, q.y, h0, m0_, l0);
         split_pair(q.z, q.w, h1, m1, l1);
-        unsigned char *row = oper + (unsigned)u * ((unsigned)RG * 32u) + wr_off;
+        unsigned char *row = oper + (unsigned)u * ((unsigned)RG * 32u) + wr;
         *reinterpret_cast<u32x2 *>(row) = (u32x2){h0, h1};
         *reinterpret_cast<u32x2 *>(row + PLANE_BYTES) = (u32x2){m0_, m1};
         *reinterpret_cast<u32x2 *>(row + 2 * PLANE_BYTES) = (u32x2){l0, l1};
     };
     // half of an operand's pieces of a tile (the split rides between the products in four portions)
-    auto park_half = [&](unsigned char *oper, const Row16 &r, int half, int pieces) __attribute__((always_inline)) {
-        if (half < pieces) park_piece(oper, half, half ? r.q1 : r.q0);
+    auto park_half = [&](unsigned char *oper, const Row16 &r, int half, int pieces, unsigned wr) __attribute__((always_inline)) {
+        if (half < pieces) park_piece(oper, half, half ? r.q1 : r.q0, wr);
     };
-    auto park = [&](unsigned char *oper, const Row16 &r, int pieces) __attribute__((always_inline)) {
-        park_half(oper, r, 0, pieces);
-        park_half(oper, r, 1, pieces);
+    auto park = [&](unsigned char *oper, const Row16 &r, int pieces, unsigned wr) __attribute__((always_inline)) {
+        park_half(oper, r, 0, pieces, wr);
+        park_half(oper, r, 1, pieces, wr);
     };
 
     // ---- fragments: lane (row li of a 32-row tile, k-half lh) reads 16 bytes = 8 bf16 ------------------------------
@@ -209,22 +257,22 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
         } else {
             product(ah, bl);
         }
-        if constexpr (!(DBG & 2)) park_half(s2, sa, 0, NPA);
+        if constexpr (!(DBG & 2)) park_half(s2, sa, 0, NPA, wr_off);
         SB();
         frag(st, rdA, 1, am);
         SB();
         product(ah, bm);
-        if constexpr (!(DBG & 2)) park_half(s2, sa, 1, NPA);
+        if constexpr (!(DBG & 2)) park_half(s2, sa, 1, NPA, wr_off);
         SB();
         frag(st, rdB, 0, bh);
         SB();
         product(am, bm);
-        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 0, NPO);
+        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 0, NPO, wr_offB);
         SB();
         frag(st, rdA, 2, al);
         SB();
         product(am, bh);
-        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 1, NPO);
+        if constexpr (!(DBG & 2)) park_half(s2 + OPER_BYTES, sb, 1, NPO, wr_offB);
         SB();
         // branch-free on purpose (accumulators that cross a control-flow join get copied): past the last tiles the
         // staged registers are re-split into a stage nobody reads, the loads repeat the last tile, the fragment reads hit
@@ -248,11 +296,11 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     // ---- prologue --------------------------------------------------------------------------------------------------
     load_tile(0, ra0, rb0);
     load_tile(min(1, nk - 1), ra1, rb1);
-    park(smem, ra0, NPA);
-    park(smem + OPER_BYTES, rb0, NPO);
+    park(smem, ra0, NPA, wr_off);
+    park(smem + OPER_BYTES, rb0, NPO, wr_offB);
     load_tile(min(2, nk - 1), ra0, rb0);
-    park(smem + STAGE_BYTES, ra1, NPA);
-    park(smem + STAGE_BYTES + OPER_BYTES, rb1, NPO);
+    park(smem + STAGE_BYTES, ra1, NPA, wr_off);
+    park(smem + STAGE_BYTES + OPER_BYTES, rb1, NPO, wr_offB);
     load_tile(min(3, nk - 1), ra1, rb1);
     __syncthreads();
     frag(smem, rdA, 0, ah);
@@ -289,11 +337,54 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
 
 }  // namespace
 
+namespace {
+
+template <int BMODE>
+int launch_split(Args &g, int batch, hipStream_t stream, const char *who) {
+    const bool tall = (g.M % 256) == 0;            // 256-row tiles; otherwise 128-row tiles (M is a multiple of 128)
+    g.tiles_m = tall ? g.M / 256 : g.M / 128;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const size_t shmem = SHMEM + (BMODE == 2 ? TBL_BYTES : 0);
+    auto launch = [&](auto kern) {
+        int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), who);
+        if (e) return e;
+        hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, batch), dim3(128 * WAVES_N), shmem, stream, g);
+        return 0;
+    };
+    int e;
+#ifdef EAP_ABLATION
+    const int dbg = getenv("EAP_GEMM_SPLIT_DEBUG") ? atoi(getenv("EAP_GEMM_SPLIT_DEBUG")) : 0;
+    switch (dbg) {
+        case 1: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 1, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 1, BMODE>); break;
+        case 2: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 2, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 2, BMODE>); break;
+        case 3: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 3, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 3, BMODE>); break;
+        case 4: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 4, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 4, BMODE>); break;
+        case 7: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 7, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 7, BMODE>); break;
+        case 15: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 15, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 15, BMODE>); break;
+        default: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0, BMODE>);
+    }
+#else
+    e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0, BMODE>);
+#endif
+    if (e) return e;
+    static const char *names[3][2] = {{"gemm_bf16x3_kernel<2, 4>", "gemm_bf16x3_kernel<4, 4>"},
+                                      {"gemm_bf16x3_kernel<2, 4, nn>", "gemm_bf16x3_kernel<4, 4, nn>"},
+                                      {"gemm_bf16x3_kernel<2, 4, gather>", "gemm_bf16x3_kernel<4, 4, gather>"}};
+    eap::set_kernel(names[BMODE][tall ? 1 : 0]);
+    return eap::check_launch(who);
+}
+
+inline bool tile_dims_ok(int M, int N, int K) {
+    return M >= 128 && N >= 256 && (M % (32 * WAVES_N)) == 0 && (N % (32 * WAVES_N)) == 0 && K >= BK && (K % BK) == 0;
+}
+
+}  // namespace
+
 // can the split kernel take this product?  (both operands k-contiguous, K a multiple of 16, 16-byte aligned rows; it pays
 // from a 256 x 256 tile per CU upwards)
 extern "C" int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
                                              int64_t strideB) {
-    if (M < 128 || N < 256 || (M % (32 * WAVES_N)) || (N % (32 * WAVES_N)) || K < BK || (K % BK) != 0) return 0;
+    if (!tile_dims_ok(M, N, K)) return 0;
     if ((long long)32 * WAVES_N * lda * 4 >= (1ll << 32) || (long long)32 * WAVES_N * ldb * 4 >= (1ll << 32)) return 0;
     if ((lda & 3) || (ldb & 3) || (strideB & 3)) return 0;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
@@ -305,36 +396,55 @@ extern "C" int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t 
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (!eap_gemm_bf16x3_f32_supported(M, N, K, A, lda, B, ldb, strideB)) return eap::bad_arg("gemm_bf16x3_f32: unsupported operands (ask eap_gemm_bf16x3_f32_supported)");
     if (batch > 65535) return eap::bad_arg("gemm_bf16x3_f32: batch exceeds 65535");
-    Args g;
+    Args g{};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda;
     g.B = B; g.ldb = ldb; g.sB = strideB;
     g.C = C; g.ldc = ldc; g.sC = strideC;
-    const bool tall = (M % 256) == 0;            // 256-row tiles; otherwise 128-row tiles (M is a multiple of 128)
-    g.tiles_m = tall ? M / 256 : M / 128;
-    g.tiles_n = (N + BN - 1) / BN;
-    auto launch = [&](auto kern) {
-        int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM), "gemm_bf16x3_f32 shared memory");
-        if (e) return e;
-        hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, batch), dim3(128 * WAVES_N), SHMEM, eap::S(stream), g);
-        return 0;
-    };
-    int e;
-#ifdef EAP_ABLATION
-    const int dbg = getenv("EAP_GEMM_SPLIT_DEBUG") ? atoi(getenv("EAP_GEMM_SPLIT_DEBUG")) : 0;
-    switch (dbg) {
-        case 1: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 1>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 1>); break;
-        case 2: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 2>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 2>); break;
-        case 3: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 3>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 3>); break;
-        case 4: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 4>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 4>); break;
-        case 7: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 7>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 7>); break;
-        case 15: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 15>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 15>); break;
-        default: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0>);
-    }
-#else
-    e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0>);
-#endif
-    if (e) return e;
-    eap::set_kernel(tall ? "gemm_bf16x3_kernel<4, 4>" : "gemm_bf16x3_kernel<2, 4>");
-    return eap::check_launch("gemm_bf16x3_f32");
+    return launch_split<0>(g, batch, eap::S(stream), "gemm_bf16x3_f32");
+}
+
+// C_z[M,N] = A[M,K] * B_z[K,N]: A k-contiguous and shared by the batch, B row-major (the pointwise contraction
+// so3_contract: W [O, C] times x_z [C, P*A])
+extern "C" int eap_gemm_bf16x3_nn_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                                                int64_t strideB) {
+    if (!tile_dims_ok(M, N, K)) return 0;
+    if ((long long)32 * WAVES_N * lda * 4 >= (1ll << 32) || (long long)ldb * 4 >= (1ll << 32) || ldb < N) return 0;
+    if ((lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 3)) return 0;
+    return 1;
+}
+
+extern "C" int eap_gemm_bf16x3_nn_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                                      float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (!eap_gemm_bf16x3_nn_f32_supported(M, N, K, A, lda, B, ldb, strideB)) return eap::bad_arg("gemm_bf16x3_nn_f32: unsupported operands (ask eap_gemm_bf16x3_nn_f32_supported)");
+    if (batch > 65535) return eap::bad_arg("gemm_bf16x3_nn_f32: batch exceeds 65535");
+    Args g{};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda;
+    g.B = B; g.ldb = ldb; g.sB = strideB;
+    g.C = C; g.ldc = ldc; g.sC = strideC;
+    return launch_split<1>(g, batch, eap::S(stream), "gemm_bf16x3_nn_f32");
+}
+
+// the intra-SO(3) conv as an implicit GEMM on the split kernel: out[b,o,p,a] = sum_{c,t} W[o, c*12 + t] feats[b,c,p,idx[a,t]]
+extern "C" int eap_so3_intra_conv_bf16x3_f32_supported(int b, int o, int c, int p, int na, int nt) {
+    if (nt != TAPS || na <= 0 || na > 64 || (long long)p * na >= (1ll << 29)) return 0;
+    return tile_dims_ok(o, p * na, c * nt) ? 1 : 0;
+}
+
+extern "C" int eap_so3_intra_conv_bf16x3_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
+                                             const int32_t *intra_idx, float *out, eap_stream_t stream) {
+    if (b <= 0 || o <= 0 || p <= 0) return 0;
+    if (!eap_so3_intra_conv_bf16x3_f32_supported(b, o, c, p, na, nt) || (reinterpret_cast<uintptr_t>(W) & 15))
+        return eap::bad_arg("so3_intra_conv_bf16x3_f32: unsupported shape (ask eap_so3_intra_conv_bf16x3_f32_supported)");
+    if (b > 65535) return eap::bad_arg("so3_intra_conv_bf16x3_f32: batch exceeds 65535");
+    Args g{};
+    const long long pa = (long long)p * na;
+    g.M = o; g.N = (int)pa; g.K = c * nt;
+    g.A = W; g.lda = (long long)c * nt;
+    g.B = feats; g.ldb = pa; g.sB = (long long)c * pa;
+    g.C = out; g.ldc = pa; g.sC = (long long)o * pa;
+    g.tbl = intra_idx; g.na = na;
+    return launch_split<2>(g, b, eap::S(stream), "so3_intra_conv_bf16x3_f32");
 }

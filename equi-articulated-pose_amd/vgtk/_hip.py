@@ -103,9 +103,10 @@ def _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
                                                               _ptr(B), _I64(ldb), _I64(strideB)))
 
 
-# The forward contraction (A shared by the batch, both operands k-contiguous) on the bf16 matrix cores with 3 x bf16
+# Contractions whose A operand is shared by the batch (the inter conv's forward contraction on the transposed
+# intermediate, the pointwise contraction so3_contract, the implicit intra conv) on the bf16 matrix cores with 3 x bf16
 # split operands: fp32 in, fp32 accumulate, products as accurate as fp32's (csrc/gemm_bf16x3.hip).  False: the fp32-MFMA
-# kernel everywhere.
+# kernels everywhere.
 SPLIT_BF16_CONTRACTION = True
 
 
@@ -115,6 +116,11 @@ def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, stri
     if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and (strideA == 0 or batch == 1) and \
             lib.eap_gemm_bf16x3_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB)):
         call('eap_gemm_bf16x3_f32', C, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
+             batch, tag=tag)
+        return
+    if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and not transB and (strideA == 0 or batch == 1) and \
+            lib.eap_gemm_bf16x3_nn_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB)):
+        call('eap_gemm_bf16x3_nn_f32', C, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
              batch, tag=tag)
         return
     if not b_blocked and _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
@@ -336,6 +342,7 @@ def so3_intra_conv(feats, W, intra_idx32):
     b, c, p, na = feats.shape
     o, nt = W.shape[0], intra_idx32.shape[1]
     out = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
-    call('eap_so3_intra_conv_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats), _ptr(intra_idx32), _ptr(out),
-         tag={'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)})
+    split = SPLIT_BF16_CONTRACTION and W.data_ptr() % 16 == 0 and lib.eap_so3_intra_conv_bf16x3_f32_supported(b, o, c, p, na, nt)
+    call('eap_so3_intra_conv_bf16x3_f32' if split else 'eap_so3_intra_conv_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats),
+         _ptr(intra_idx32), _ptr(out), tag={'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)})
     return out

@@ -275,7 +275,11 @@ class _Contract(torch.autograd.Function):
         gW = gx = None
         if ctx.needs_input_grad[1]:
             gx = torch.empty_like(x)          # W^T gy : [ck,o] [o,pa]
-            _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy, pa, o * pa, gx, pa, ck * pa, b)
+            if _hip.SPLIT_BF16_CONTRACTION and ck >= 128 and ck % 128 == 0 and o % 16 == 0:
+                Wt = W.t().contiguous()       # the split kernel reads its shared operand k-contiguous: [ck, o]
+                _hip.gemm(0, 0, ck, pa, o, Wt, o, 0, gy, pa, o * pa, gx, pa, ck * pa, b)
+            else:
+                _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy, pa, o * pa, gx, pa, ck * pa, b)
         if ctx.needs_input_grad[0]:
             gW = torch.empty_like(W)          # sum_b gy_b x_b^T : [o,pa] [pa,ck]
             _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)

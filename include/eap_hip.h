@@ -287,6 +287,17 @@ int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t l
                                   int64_t strideB);
 int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
                         float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+/* the same product with B_z row-major [K, N] ("NN": W [O, C] times x_z [C, P*A], the pointwise contraction behind every
+ * 1 x 1 conv of the blocks and heads -- torch.matmul / nn.Conv2d(1) in SPConvNets/utils/base_so3conv.py) */
+int eap_gemm_bf16x3_nn_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                                     int64_t strideB);
+int eap_gemm_bf16x3_nn_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                           float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+/* eap_so3_intra_conv_f32 on the split kernel (nt = 12; o, p*na multiples of 128; c*nt a multiple of 16) */
+int eap_so3_intra_conv_bf16x3_f32_supported(int b, int o, int c, int p, int na, int nt);
+int eap_so3_intra_conv_bf16x3_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
+                                  const int32_t *intra_idx, float *out, eap_stream_t stream);
+
 
 /* The same GEMMs with both operands fed by global -> LDS DMA through a three-stage ring (csrc/gemm_dma_f32.hip);
  * conventions of eap_gemm_f32 / eap_gemm_f32_reduce.  Needs K % 16 == 0, leading dimensions and batch strides

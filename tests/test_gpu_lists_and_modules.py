@@ -685,3 +685,82 @@ def test_split_bf16_contraction_is_fp32_accurate(dev, M, N, K, batch):
     # both kernels accumulate K products in fp32: their errors are of the same size (the split adds ~2^-23 per product)
     assert err_split < 3 * err_fp32 + 2e-7, (err_split, err_fp32)
     assert rel_el < 1e-6, rel_el
+
+
+@pytest.mark.parametrize('M,N,K,batch', [(512, 2048, 512, 2), (256, 1920, 256, 2), (128, 768, 48, 3), (384, 256, 16, 1)])
+def test_split_bf16_pointwise_contraction_is_fp32_accurate(dev, M, N, K, batch):
+    """The same kernel reading B_z row-major [K, N] (so3_contract: W [O, C] times x_z [C, P*A]) against fp64, with the
+    fp32-MFMA kernel's error as the yardstick; then so3_contract forward + both gradients with the split on and off."""
+    from vgtk import _hip
+    import vgtk.so3conv.functional as L
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=gen) * 0.05).to(dev)
+    B = (torch.randn(batch, K, N, generator=gen).abs() * torch.exp(torch.randn(batch, 1, N, generator=gen) * 2.0)).to(dev)
+    assert _hip.lib.eap_gemm_bf16x3_nn_f32_supported(M, N, K, _hip._ptr(A), _hip._I64(K), _hip._ptr(B), _hip._I64(N), _hip._I64(K * N))
+    ref = torch.matmul(A.double().cpu(), B.double().cpu())                                       # [batch, M, N]
+    out = {}
+    for split in (True, False):
+        _hip.SPLIT_BF16_CONTRACTION = split
+        try:
+            C = torch.full((batch, M, N), float('nan'), device=dev)
+            _hip.gemm(0, 0, M, N, K, A, K, 0, B, N, K * N, C, N, M * N, batch)
+        finally:
+            _hip.SPLIT_BF16_CONTRACTION = True
+        out[split] = C.double().cpu()
+    scale = ref.abs().max().item()
+    err_split = (out[True] - ref).abs().max().item() / scale
+    err_fp32 = (out[False] - ref).abs().max().item() / scale
+    bound = torch.matmul(A.abs().double().cpu(), B.abs().double().cpu())
+    rel_el = ((out[True] - ref).abs() / bound.clamp_min(1e-300)).max().item()
+    print(f'\nNN GEMM {M}x{N}x{K}: split {err_split:.2e}, fp32 MFMA {err_fp32:.2e}; split per-element {rel_el:.2e} of sum |a||b|')
+    assert err_split < 3 * err_fp32 + 2e-7, (err_split, err_fp32)
+    assert rel_el < 1e-6, rel_el
+    # the autograd op on top of it (dX through the transposed weights on the same kernel)
+    res = {}
+    gy = torch.randn(batch, M, N, generator=gen).to(dev)
+    for split in (True, False):
+        _hip.SPLIT_BF16_CONTRACTION = split
+        try:
+            W = A.clone().requires_grad_(True)
+            x = B.clone().requires_grad_(True)
+            y = L.so3_contract(W, x)
+            gW, gx = torch.autograd.grad(y, [W, x], gy)
+        finally:
+            _hip.SPLIT_BF16_CONTRACTION = True
+        res[split] = (y.detach(), gW, gx)
+    for name, a, b in zip(('y', 'dW', 'dx'), res[True], res[False]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, name
+
+
+@pytest.mark.parametrize('B,C,O,P', [(2, 64, 128, 64), (1, 128, 256, 32), (2, 16, 128, 128)])
+def test_split_bf16_intra_conv_matches_fp32_kernel_and_fp64(dev, B, C, O, P):
+    """eap_so3_intra_conv_bf16x3_f32 (implicit gather on the split kernel) against the gathered fp64 einsum and the fp32-MFMA
+    implicit kernel; forward and dF (the same kernel with the inverse table)."""
+    from vgtk import _hip
+    import vgtk.so3conv.functional as L
+    A_ = 60
+    gen = torch.Generator().manual_seed(B + C + O + P)
+    idx = torch.from_numpy(np.ascontiguousarray(L.get_intra_idx())).long().to(dev)                # [60, 12]
+    nt = idx.shape[1]
+    feats = (torch.randn(B, C, P, A_, generator=gen).abs() * torch.exp(torch.randn(B, 1, P, 1, generator=gen))).to(dev)
+    W = (torch.randn(O, C * nt, generator=gen) * 0.05).to(dev)
+    assert _hip.lib.eap_so3_intra_conv_bf16x3_f32_supported(B, O, C, P, A_, nt)
+    g = feats.double().cpu()[:, :, :, idx.cpu()]                                                 # [B, C, P, A, T]
+    ref = torch.einsum('oct,bcpat->bopa', W.double().cpu().view(O, C, nt), g)
+    out = {}
+    gy = torch.randn(B, O, P, A_, generator=gen).to(dev)
+    for split in (True, False):
+        _hip.SPLIT_BF16_CONTRACTION = split
+        try:
+            f = feats.clone().requires_grad_(True)
+            y = L.intra_so3conv(f, W, idx)
+            gF, = torch.autograd.grad(y, [f], gy)
+        finally:
+            _hip.SPLIT_BF16_CONTRACTION = True
+        out[split] = (y.detach().double().cpu(), gF.double().cpu())
+    scale = ref.abs().max().item()
+    err_split = (out[True][0] - ref).abs().max().item() / scale
+    err_fp32 = (out[False][0] - ref).abs().max().item() / scale
+    print(f'\nintra conv B{B} C{C} O{O} P{P}: split {err_split:.2e}, fp32 MFMA {err_fp32:.2e}')
+    assert err_split < 3 * err_fp32 + 2e-7, (err_split, err_fp32)
+    assert rel_err(out[True][1].numpy(), out[False][1].numpy()) < 1e-5       # two fp32 accumulations of K = 12 O products against each other
