@@ -56,7 +56,10 @@ from .. import _hip  # noqa: E402  (after the pure-torch helpers: they are unit-
 class _BNAct(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, sync, residual=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, sync, residual=None, pre_bias=None):
+        """pre_bias [C]: act(bn(x + pre_bias)) without the pass that would add it -- a per-channel constant in front of a
+        BatchNorm moves the batch mean and nothing else (training: it only enters the running mean, its gradient is
+        exactly zero; eval: it shifts the pre-activation like beta)."""
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -71,16 +74,20 @@ class _BNAct(torch.autograd.Function):
             mean, var, count = batch_moments(s1, s2, pivot, count, sync)    # biased variance, as BatchNorm normalises with
             if running_mean is not None:
                 with torch.no_grad():
-                    running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                    full = mean if pre_bias is None else mean + pre_bias.double()
+                    running_mean.mul_(1.0 - momentum).add_(full.to(running_mean.dtype), alpha=momentum)
                     running_var.mul_(1.0 - momentum).add_((var * (count / (count - 1))).to(running_var.dtype), alpha=momentum)
         else:
             mean, var = running_mean.double(), running_var.double()
+            if pre_bias is not None:
+                mean = mean - pre_bias.double()
         invstd = torch.rsqrt(var + eps)
         scale64 = weight.double() * invstd
         scale = scale64.float()
         shift = (bias.double() - mean * scale64).float()
         y = _hip.bn_act_fwd(x, b, c, n, scale, shift, slope, residual)
         ctx.has_res = residual is not None
+        ctx.has_pre_bias = pre_bias is not None
         ctx.save_for_backward(x, scale, shift, mean.float(), invstd.float())
         ctx.training, ctx.slope, ctx.dims, ctx.sync, ctx.count = training, slope, (b, c, n), sync, count
         return y
@@ -101,7 +108,10 @@ class _BNAct(torch.autograd.Function):
                 k2 = torch.zeros_like(scale)
                 k3 = torch.zeros_like(scale)
             g_x = _hip.bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, ctx.slope)
-        return g_x, sgx.float(), sg.float(), None, None, None, None, None, None, None, (gy if ctx.has_res else None)
+        g_pre = None
+        if ctx.has_pre_bias:
+            g_pre = torch.zeros_like(scale) if ctx.training else (sg * scale.double()).float()
+        return g_x, sgx.float(), sg.float(), None, None, None, None, None, None, None, (gy if ctx.has_res else None), g_pre
 
 
 class BatchNormLeakyReLU(nn.BatchNorm2d):

@@ -94,9 +94,9 @@ class InvPPOutBlockOurs(nn.Module):
             self.attention_layer = nn.Conv2d(c_in, 1, 1)
 
     def forward(self, x, label=None, sel_mode_new=None):
-        x_out = x.feats
-        for lid, linear in enumerate(self.linear):
-            x_out = F.relu(self.norm[lid](linear(x_out)))
+        if not x.feats.is_cuda:
+            raise RuntimeError('InvPPOutBlockOurs: tensor must be a CUDA(HIP) tensor (no CPU fallback)')
+        x_out = _unary_stack(x.feats, self.linear, self.norm)      # contraction GEMM + fused BatchNorm / ReLU epilogue
         if self.pooling_method == 'mean':
             return x_out.mean(dim=-1)
         if self.pooling_method == 'debug':
@@ -243,16 +243,19 @@ def _unary_stack(x, linears, norms):
     for lid, linear in enumerate(linears):
         b, c, n, a = x.shape
         y = L.so3_contract(linear.weight.view(linear.out_channels, c), x.reshape(b, c, n * a)).view(b, linear.out_channels, n, a)
-        if linear.bias is not None:
+        fused = norms is not None and (n * a) % 4 == 0 and norms[lid].momentum is not None and norms[lid].track_running_stats
+        if linear.bias is not None and not fused:
             y = y + linear.bias.view(1, -1, 1, 1)
         if norms is not None:
             bn = norms[lid]
-            if (n * a) % 4 != 0:          # the fused epilogue moves 16-byte words; odd row lengths take the torch modules
+            if not fused:                 # the fused epilogue moves 16-byte words; odd row lengths take the torch modules
                 x = F.relu(bn(y))
                 continue
             if bn.training:
                 bn.num_batches_tracked.add_(1)
-            x = _BNAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, 0.0, False)
+            # the conv bias rides into the BatchNorm as a shift of its mean (no pass of its own over the feature map)
+            x = _BNAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, 0.0, False,
+                             None, linear.bias)
         else:
             x = F.relu(y)
     return x
@@ -355,11 +358,10 @@ class SO3OutBlockRTWithMaskSep(nn.Module):
         cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, trans_shared_feat.shape[2], -1), trans_shared_feat], dim=1).contiguous()
         b, c2, n, a = cat.shape
         y = L.so3_contract(d0.weight.view(d0.out_channels, c2), cat.reshape(b, c2, n * a)).view(b, d0.out_channels, n, a)
-        y = y + d0.bias.view(1, -1, 1, 1)
         if dbn.training:
             dbn.num_batches_tracked.add_(1)
         y = _BNAct.apply(y, dbn.weight, dbn.bias, dbn.running_mean, dbn.running_var, dbn.training, dbn.momentum, dbn.eps,
-                         dact.negative_slope, False)
+                         dact.negative_slope, False, None, d0.bias)
         t_out = F.conv2d(y, d1.weight, d1.bias)                                                       # [b, 3 h, n, a]: 3 h output channels
         t_out = t_out.reshape((nb, self.num_heads, 3) + t_out.shape[-2:])                             # [b, h, 3, n, a]
         if self.global_scalar:

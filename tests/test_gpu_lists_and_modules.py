@@ -352,6 +352,9 @@ def test_anchor_attention_pool_and_invariant_head(dev):
     for nme, a, b in zip(['x'] + names, grads, grefs):
         # conv biases in front of a training-mode BatchNorm have an exactly-zero gradient (rounding noise on both
         # sides, ~1e-6): the bar is relative to the tensor's own scale, floored at 1 % of the largest gradient
+        if nme == 'attention_layer.bias':      # the softmax ignores a constant logit shift: analytically zero, noise on both sides
+            assert float(a.abs().max()) < 1e-3 * top and float(b.abs().max()) < 1e-3 * top, nme
+            continue
         scale = max(float(b.abs().max()), 1e-2 * top)
         assert float((a - b).abs().max()) < 2e-5 * scale, nme
     # the other pooling modes are plain reductions
