@@ -58,6 +58,7 @@ struct Args {
     float *C; long long ldc, sC;
     int tiles_m, tiles_n;
     const int *tbl; int na;             // BMODE 2: gather table [na][TAPS], anchors per point
+    long long sA; int slabs, kslab;     // batch-reduce form (BMODE 0): z = item * slabs + slab; both operands start at k = slab * kslab
 };
 constexpr int TAPS = 12;                // intra_idx is [60, 12] (vgtk/so3conv/functional.py get_intra_idx)
 constexpr unsigned TBL_BYTES = 64 * TAPS * 4;
@@ -117,7 +118,10 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     }
     const int z = blockIdx.y;
     const int m0 = tm * BM, n0 = tn * BN;
-    const float *B = g.B + (long long)z * g.sB;
+    const int item = g.slabs > 1 ? z / g.slabs : z;
+    const long long kbeg = g.slabs > 1 ? (long long)(z - item * g.slabs) * g.kslab : 0;
+    const float *A = g.A + item * g.sA + kbeg;
+    const float *B = g.B + item * g.sB + (BMODE == 0 ? kbeg : 0);
     float *C = g.C + (long long)z * g.sC;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     const int c4b = BMODE ? __builtin_amdgcn_readfirstlane(t >> 7) : c4, rqb = BMODE ? (t & 127) : rq;
     const float *baseA[NPA], *baseB[NPO];
 #pragma unroll
-    for (int u = 0; u < NPA; ++u) baseA[u] = g.A + (long long)min(m0 + RG * u, g.M - RG) * g.lda;
+    for (int u = 0; u < NPA; ++u) baseA[u] = A + (long long)min(m0 + RG * u, g.M - RG) * g.lda;
 #pragma unroll
     for (int u = 0; u < NPO; ++u) baseB[u] = B + (long long)min(n0 + RG * u, g.N - RG) * g.ldb;
     const unsigned offA = (unsigned)((long long)rq * g.lda + 4 * c4) * 4u, offB = (unsigned)((long long)rq * g.ldb + 4 * c4) * 4u;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
         for (int i = t; i < g.na * TAPS; i += NT) reinterpret_cast<int *>(smem + 3 * STAGE_BYTES)[i] = g.tbl[i] * 4;   // byte offsets
         __syncthreads();
     }
-    const int nk = g.K / BK;
+    const int nk = (g.slabs > 1 ? g.kslab : g.K) / BK;
 
     Row16 ra0, rb0, ra1, rb1;                                           // (A pieces 0..3, B pieces 0..3) of two tiles in flight
     auto ld = [&](const float *ubase, unsigned voff) __attribute__((always_inline)) {
@@ -447,4 +451,64 @@ extern "C" int eap_so3_intra_conv_bf16x3_f32(int b, int o, int c, int p, int na,
     g.C = out; g.ldc = pa; g.sC = (long long)o * pa;
     g.tbl = intra_idx; g.na = na;
     return launch_split<2>(g, b, eap::S(stream), "so3_intra_conv_bf16x3_f32");
+}
+
+// ---- batch-reduce form: C[M,N] = sum_z A_z[M,K] B_z[N,K]^T (the weight gradient of the pointwise contraction: dW = sum over
+// clouds of dY_z x_z^T, both operands k-contiguous, K = P*A long).  Every (cloud, k-slab) pair is one z of the kernel above and
+// writes its own [M,N] partial; a second kernel sums the partials in a fixed order (deterministic, no atomics).
+namespace {
+
+__global__ __launch_bounds__(256) void split_reduce_kernel(long long mn4, int parts, const f32x4 *__restrict__ ws, float *__restrict__ C, int N, long long ldc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn4) return;
+    f32x4 acc = ws[i];
+    for (int z = 1; z < parts; ++z) acc += ws[(long long)z * mn4 + i];
+    const long long e = i * 4, row = e / N, col = e - row * N;
+    *reinterpret_cast<f32x4 *>(C + row * ldc + col) = acc;
+}
+
+inline int reduce_slabs(int M, int N, int K, int batch) {
+    // enough (item, slab) pairs to fill the chip twice over; slabs of whole k-tiles, at least 64 k-tiles each
+    const int tiles = ((M % 256) == 0 ? M / 256 : M / 128) * ((N + BN - 1) / BN);
+    int s = 1;
+    while (s < 64 && (long long)tiles * batch * s < 512 && (K / BK) % (2 * s) == 0 && K / (2 * s) >= 64 * BK) s *= 2;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int eap_gemm_bf16x3_reduce_f32_supported(int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B,
+                                                    int64_t ldb, int64_t strideB, int64_t ldc) {
+    if (!tile_dims_ok(M, N, K)) return 0;
+    if ((long long)32 * WAVES_N * lda * 4 >= (1ll << 32) || (long long)32 * WAVES_N * ldb * 4 >= (1ll << 32)) return 0;
+    if ((lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3) || (ldc & 3)) return 0;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
+    return 1;
+}
+
+// floats of scratch eap_gemm_bf16x3_reduce_f32 needs
+extern "C" int64_t eap_gemm_bf16x3_reduce_workspace(int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+    return (int64_t)M * N * batch * reduce_slabs(M, N, K, batch);
+}
+
+extern "C" int eap_gemm_bf16x3_reduce_f32(int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B, int64_t ldb,
+                                          int64_t strideB, float *C, int64_t ldc, int batch, float *workspace, eap_stream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (!eap_gemm_bf16x3_reduce_f32_supported(M, N, K, A, lda, strideA, B, ldb, strideB, ldc) || (reinterpret_cast<uintptr_t>(C) & 15) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return eap::bad_arg("gemm_bf16x3_reduce_f32: unsupported operands (ask eap_gemm_bf16x3_reduce_f32_supported)");
+    const int slabs = reduce_slabs(M, N, K, batch);
+    if ((long long)batch * slabs > 65535) return eap::bad_arg("gemm_bf16x3_reduce_f32: batch x slabs exceeds 65535");
+    Args g{};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.sA = strideA;
+    g.B = B; g.ldb = ldb; g.sB = strideB;
+    g.C = workspace; g.ldc = N; g.sC = (long long)M * N;
+    g.slabs = slabs; g.kslab = K / slabs;          // one slab: z is the item and the kernel's k-loop covers K
+    if (int e = launch_split<0>(g, batch * slabs, eap::S(stream), "gemm_bf16x3_reduce_f32")) return e;
+    const long long mn4 = (long long)M * N / 4;
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, eap::S(stream), mn4, batch * slabs,
+                       reinterpret_cast<const f32x4 *>(workspace), C, N, (long long)ldc);
+    return eap::check_launch("gemm_bf16x3_reduce_f32 (sum of the partials)");
 }

@@ -96,6 +96,7 @@ def suffix(t):
 # EAP_DMA_GEMM=0 forces the older kernel everywhere (A/B runs).
 USE_DMA_GEMM = os.environ.get('EAP_DMA_GEMM', '1') != '0'
 lib.eap_gemm_dma_f32_reduce_workspace.restype = ctypes.c_int64
+lib.eap_gemm_bf16x3_reduce_workspace.restype = ctypes.c_int64
 
 
 def _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
@@ -133,6 +134,12 @@ def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, stri
 
 def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch, b_blocked=False):
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)}
+    if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and \
+            lib.eap_gemm_bf16x3_reduce_f32_supported(M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb), _I64(strideB), _I64(ldc)):
+        ws = torch.empty(int(lib.eap_gemm_bf16x3_reduce_workspace(M, N, K, batch)), dtype=torch.float32, device=C.device)
+        call('eap_gemm_bf16x3_reduce_f32', C, M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C),
+             _I64(ldc), batch, _ptr(ws), tag=tag)
+        return
     if not b_blocked and _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
         ws = torch.empty(max(int(lib.eap_gemm_dma_f32_reduce_workspace(M, N, K, batch)), 1), dtype=torch.float32, device=C.device)
         call('eap_gemm_dma_f32_reduce', C, int(transA), int(transB), M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb),

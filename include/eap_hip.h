@@ -293,6 +293,14 @@ int eap_gemm_bf16x3_nn_f32_supported(int M, int N, int K, const float *A, int64_
                                      int64_t strideB);
 int eap_gemm_bf16x3_nn_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
                            float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+/* C[M,N] = sum_z A_z[M,K] B_z[N,K]^T on the split kernel (the weight gradient of the pointwise contraction, dW = sum over the
+ * clouds of dY_z x_z^T): every (item, k-slab) pair writes its partial into `workspace` (eap_gemm_bf16x3_reduce_workspace
+ * floats, 16-byte aligned), a second kernel sums them in a fixed order. */
+int eap_gemm_bf16x3_reduce_f32_supported(int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B,
+                                         int64_t ldb, int64_t strideB, int64_t ldc);
+int64_t eap_gemm_bf16x3_reduce_workspace(int M, int N, int K, int batch);
+int eap_gemm_bf16x3_reduce_f32(int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B, int64_t ldb,
+                               int64_t strideB, float *C, int64_t ldc, int batch, float *workspace, eap_stream_t stream);
 /* eap_so3_intra_conv_f32 on the split kernel (nt = 12; o, p*na multiples of 128; c*nt a multiple of 16) */
 int eap_so3_intra_conv_bf16x3_f32_supported(int b, int o, int c, int p, int na, int nt);
 int eap_so3_intra_conv_bf16x3_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
