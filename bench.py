@@ -75,8 +75,8 @@ class Backbone(nn.Module):
             x = zptk.SphericalPointCloudPose(x.xyz, norm(x.feats), x.anchors, x.pose)
         return x.feats
 
-    def hypotheses(self, feats):
-        pooled = feats.mean(2).transpose(1, 2)                       # [B, A, 512]
+    def hypotheses(self, feats, pooled=None):
+        pooled = (feats.mean(2) if pooled is None else pooled).transpose(1, 2)                       # [B, A, 512]
         h = self.pose_head(pooled).view(feats.shape[0], NA, SLOTS, 12).transpose(1, 2)
         return h[..., :9].reshape(feats.shape[0], SLOTS, NA, 3, 3).contiguous(), h[..., 9:].contiguous()
 
@@ -130,9 +130,10 @@ class StandInLoss(torch.autograd.Function):
     of torch glue per step that has nothing to do with the path being measured)."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias):
+    def forward(ctx, feats, weight, bias, pooled=None):
         b, c, p, a = feats.shape
-        pooled = feats.mean(2)                                            # [B, C, A]
+        if pooled is None:
+            pooled = feats.mean(2)                                        # [B, C, A]; the step hands over the one its hypotheses used
         h = torch.addmm(bias, pooled.transpose(1, 2).reshape(b * a, c), weight.t())
         loss = torch.linalg.vector_norm(feats).square() / feats.numel() + h.square().mean()
         ctx.save_for_backward(feats, weight, pooled, h)
@@ -147,7 +148,7 @@ class StandInLoss(torch.autograd.Function):
         g_b = gh.sum(0)
         g_pool = (gh @ weight).view(b, a, c).transpose(1, 2) / p          # [B, C, A]
         g_f = torch.addcmul(g_pool.unsqueeze(2), feats, g * (2.0 / feats.numel()))
-        return g_f, g_w, g_b
+        return g_f, g_w, g_b, None
 
 
 CPU_BASELINE_MAX_THREADS = 16   # torch CPU ops of this path slow down beyond ~8-16 threads (measured on the 256-core GPU host)
@@ -486,9 +487,10 @@ def main():
         opt.zero_grad(set_to_none=True)
         feats = model(xyz, pose)
         with torch.no_grad():
-            R, T = model.hypotheses(feats)
+            pooled = feats.mean(2)                                        # one pass over the 4 GB feature map for both consumers
+            R, T = model.hypotheses(feats, pooled)
         allR, allT = sharding.all_gather_pose_hypotheses(R, T, n_items=n_items)
-        loss = StandInLoss.apply(feats, model.pose_head.weight, model.pose_head.bias)
+        loss = StandInLoss.apply(feats, model.pose_head.weight, model.pose_head.bias, pooled)
         loss.backward()
         reducer.finish()
         opt.step()
