@@ -42,6 +42,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 16, BN = 256;
@@ -58,6 +59,7 @@ struct Args {
     float *C; long long ldc, sC;
     int tiles_m, tiles_n;
     const int *tbl; int na;             // BMODE 2: gather table [na][TAPS], anchors per point
+    const unsigned *Apre;               // APRE: A split once by presplit_kernel, [M][K/4] pieces of 32 bytes (h0 h1 m0 m1 | l0 l1 - -)
     long long sA; int slabs, kslab;     // batch-reduce form (BMODE 0): z = item * slabs + slab; both operands start at k = slab * kslab
 };
 constexpr int TAPS = 12;                // intra_idx is [60, 12] (vgtk/so3conv/functional.py get_intra_idx)
@@ -71,8 +73,7 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // [15:
 
 // the eight 16-byte pieces a thread stages per k-tile: piece u = 4 consecutive k's of operand row 64 (u & 3) + (t >> 2)
 // (u < 4: A tile, u >= 4: B tile), k-chunk t & 3 -- four lanes cover the 64 contiguous bytes a row contributes to a k-tile
-struct Row16 { f32x4 q0, q1, q2, q3; };
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct Row16 { f32x4 q0, q1; u32x2 p0, p1; };      // p0, p1: the l words of a pre-split A piece whose h, m words sit in q0 / q1 (APRE)
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     h = pk_bf16(x0, x1);
@@ -100,7 +101,7 @@ __device__ __forceinline__ void split_quad(const f32x4 &a, const f32x4 &b, u32x4
 // its LDS fragments or its staged loads
 // MI = row tiles per wave: 4 -> block tile 256 x 256; 2 -> 128 x 256 (wave tile 64 x 64) for row counts that would leave
 // half of a 256-row tile empty (the second layer's contraction: 128 output channels)
-template <int MI, int WN, int DBG, int BMODE>
+template <int MI, int WN, int DBG, int BMODE, bool APRE>
 __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     constexpr int NT = 128 * WN, NI = 8 / WN, WM = 8 / WN, BM = 32 * MI * WM, RG = NT / 4;   // threads, column tiles per wave, waves along M, rows per block, rows per staging group
     constexpr int NPA = BM / RG, NPO = 256 / RG;                                              // staged pieces per thread: A tile, B tile
@@ -140,6 +141,12 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     for (int u = 0; u < NPA; ++u) baseA[u] = A + (long long)min(m0 + RG * u, g.M - RG) * g.lda;
 #pragma unroll
     for (int u = 0; u < NPO; ++u) baseB[u] = B + (long long)min(n0 + RG * u, g.N - RG) * g.ldb;
+    // APRE: the weights were split once (presplit_kernel): piece (row, k / 4) = 32 bytes (h0 h1 m0 m1 | l0 l1 - -)
+    const unsigned char *preA[NPA];
+    const long long pre_pitch = (long long)(g.K / 4) * 32;
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) preA[u] = reinterpret_cast<const unsigned char *>(g.Apre) + (long long)min(m0 + RG * u, g.M - RG) * pre_pitch;
+    const unsigned offP = (unsigned)((long long)rq * pre_pitch + 32 * c4);
     const unsigned offA = (unsigned)((long long)rq * g.lda + 4 * c4) * 4u, offB = (unsigned)((long long)rq * g.ldb + 4 * c4) * 4u;
     unsigned colB[NPO], tapB[NPO];      // BMODE 1: byte offset of the piece's column; BMODE 2: of its point's row, and of its anchor's table row
 #pragma unroll
@@ -175,8 +182,17 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     };
     auto load_tile = [&](int kt, Row16 &a, Row16 &b) __attribute__((always_inline)) {
         const int ko = kt * BK;
-        a.q0 = ld(baseA[0] + ko, offA);
-        if constexpr (NPA == 2) a.q1 = ld(baseA[1] + ko, offA);
+        if constexpr (APRE) {
+            const unsigned char *p0 = preA[0] + kt * 128 + offP;
+            a.q0 = *reinterpret_cast<const f32x4 *>(p0); a.p0 = *reinterpret_cast<const u32x2 *>(p0 + 16);
+            if constexpr (NPA == 2) {
+                const unsigned char *p1 = preA[1] + kt * 128 + offP;
+                a.q1 = *reinterpret_cast<const f32x4 *>(p1); a.p1 = *reinterpret_cast<const u32x2 *>(p1 + 16);
+            }
+        } else {
+            a.q0 = ld(baseA[0] + ko, offA);
+            if constexpr (NPA == 2) a.q1 = ld(baseA[1] + ko, offA);
+        }
         if constexpr (BMODE == 0) {
             b.q0 = ld(baseB[0] + ko, offB); b.q1 = ld(baseB[1] + ko, offB);
         } else if constexpr (BMODE == 1) {
@@ -206,9 +222,28 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     auto park_half = [&](unsigned char *oper, const Row16 &r, int half, int pieces, unsigned wr) __attribute__((always_inline)) {
         if (half < pieces) park_piece(oper, half, half ? r.q1 : r.q0, wr);
     };
+    // an A piece that arrived split: three 8-byte words straight to the planes
+    auto park_half_a = [&](unsigned char *oper, const Row16 &r, int half, unsigned wr) __attribute__((always_inline)) {
+        if constexpr (APRE) {
+            if (half < NPA) {
+                const f32x4 &q = half ? r.q1 : r.q0;
+                const u32x2 &l = half ? r.p1 : r.p0;
+                unsigned char *row = oper + (unsigned)half * ((unsigned)RG * 32u) + wr;
+                *reinterpret_cast<u32x2 *>(row) = (u32x2){__float_as_uint(q.x), __float_as_uint(q.y)};
+                *reinterpret_cast<u32x2 *>(row + PLANE_BYTES) = (u32x2){__float_as_uint(q.z), __float_as_uint(q.w)};
+                *reinterpret_cast<u32x2 *>(row + 2 * PLANE_BYTES) = l;
+            }
+        } else {
+            park_half(oper, r, half, NPA, wr);
+        }
+    };
     auto park = [&](unsigned char *oper, const Row16 &r, int pieces, unsigned wr) __attribute__((always_inline)) {
         park_half(oper, r, 0, pieces, wr);
         park_half(oper, r, 1, pieces, wr);
+    };
+    auto park_a = [&](unsigned char *oper, const Row16 &r, unsigned wr) __attribute__((always_inline)) {
+        park_half_a(oper, r, 0, wr);
+        park_half_a(oper, r, 1, wr);
     };
 
     // ---- fragments: lane (row li of a 32-row tile, k-half lh) reads 16 bytes = 8 bf16 ------------------------------
@@ -261,12 +296,12 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
         } else {
             product(ah, bl);
         }
-        if constexpr (!(DBG & 2)) park_half(s2, sa, 0, NPA, wr_off);
+        if constexpr (!(DBG & 2)) park_half_a(s2, sa, 0, wr_off);
         SB();
         frag(st, rdA, 1, am);
         SB();
         product(ah, bm);
-        if constexpr (!(DBG & 2)) park_half(s2, sa, 1, NPA, wr_off);
+        if constexpr (!(DBG & 2)) park_half_a(s2, sa, 1, wr_off);
         SB();
         frag(st, rdB, 0, bh);
         SB();
@@ -300,10 +335,10 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
     // ---- prologue --------------------------------------------------------------------------------------------------
     load_tile(0, ra0, rb0);
     load_tile(min(1, nk - 1), ra1, rb1);
-    park(smem, ra0, NPA, wr_off);
+    park_a(smem, ra0, wr_off);
     park(smem + OPER_BYTES, rb0, NPO, wr_offB);
     load_tile(min(2, nk - 1), ra0, rb0);
-    park(smem + STAGE_BYTES, ra1, NPA, wr_off);
+    park_a(smem + STAGE_BYTES, ra1, wr_off);
     park(smem + STAGE_BYTES + OPER_BYTES, rb1, NPO, wr_offB);
     load_tile(min(3, nk - 1), ra1, rb1);
     __syncthreads();
@@ -343,8 +378,40 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
 
 namespace {
 
+// the shared operand (the weights) split once per call instead of once per k-tile by every workgroup: piece (row, k / 4) ->
+// 32 bytes (h0 h1 m0 m1 | l0 l1 - -), the same roundings as the in-kernel split
+__global__ __launch_bounds__(256) void presplit_kernel(int M, int K4, const float *__restrict__ A, long long lda, u32x4 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * K4) return;
+    const int row = (int)(i / K4), c = (int)(i - (long long)row * K4);
+    const f32x4 q = *reinterpret_cast<const f32x4 *>(A + row * lda + 4 * c);
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(q.x, q.y, h0, m0, l0);
+    split_pair(q.z, q.w, h1, m1, l1);
+    out[2 * i] = (u32x4){h0, h1, m0, m1};
+    out[2 * i + 1] = (u32x4){l0, l1, 0u, 0u};
+}
+
+int g_presplit = 1;      // eap_gemm_bf16x3_presplit(0): split the weights in the k-loop like the other operand (A/B runs, tests)
+
 template <int BMODE>
 int launch_split(Args &g, int batch, hipStream_t stream, const char *who) {
+    // pays from a few thousand k-tiles per workgroup column upwards (+2.7 % on the deepest layer's contraction; on the 1-2 ms
+    // pointwise contractions the extra launch and the allocation cost more than the saved vector work:
+    // tools/split_modes_timing.py); the test switch value 2 forces it for every shape
+    const bool pre = g.sA == 0 && g.slabs <= 1 && (g_presplit == 2 || (g_presplit == 1 && g.K >= 1024));
+    void *scratch = nullptr;
+    if (pre) {
+        const long long pieces = (long long)g.M * (g.K / 4);
+        if (int e = eap::hip_fail(hipMallocAsync(&scratch, (size_t)pieces * 32, stream), who)) return e;
+        hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, g.M, g.K / 4, g.A, g.lda,
+                           reinterpret_cast<u32x4 *>(scratch));
+        g.Apre = reinterpret_cast<const unsigned *>(scratch);
+    }
+    struct Release {           // stream-ordered: the buffer is released after the product that reads it
+        void *p; hipStream_t s;
+        ~Release() { if (p) (void)hipFreeAsync(p, s); }
+    } release{scratch, stream};
     const bool tall = (g.M % 256) == 0;            // 256-row tiles; otherwise 128-row tiles (M is a multiple of 128)
     g.tiles_m = tall ? g.M / 256 : g.M / 128;
     g.tiles_n = (g.N + BN - 1) / BN;
@@ -355,20 +422,29 @@ int launch_split(Args &g, int batch, hipStream_t stream, const char *who) {
         hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, batch), dim3(128 * WAVES_N), shmem, stream, g);
         return 0;
     };
+    auto run = [&](auto dbg_c) {
+        constexpr int D = decltype(dbg_c)::value;
+        if (pre) return tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, D, BMODE, true>) : launch(gemm_bf16x3_kernel<2, WAVES_N, D, BMODE, true>);
+        return tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, D, BMODE, false>) : launch(gemm_bf16x3_kernel<2, WAVES_N, D, BMODE, false>);
+    };
     int e;
 #ifdef EAP_ABLATION
     const int dbg = getenv("EAP_GEMM_SPLIT_DEBUG") ? atoi(getenv("EAP_GEMM_SPLIT_DEBUG")) : 0;
-    switch (dbg) {
-        case 1: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 1, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 1, BMODE>); break;
-        case 2: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 2, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 2, BMODE>); break;
-        case 3: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 3, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 3, BMODE>); break;
-        case 4: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 4, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 4, BMODE>); break;
-        case 7: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 7, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 7, BMODE>); break;
-        case 15: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 15, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 15, BMODE>); break;
-        default: e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0, BMODE>);
+    if constexpr (BMODE == 0) {
+        switch (dbg) {
+            case 1: e = run(std::integral_constant<int, 1>{}); break;
+            case 2: e = run(std::integral_constant<int, 2>{}); break;
+            case 3: e = run(std::integral_constant<int, 3>{}); break;
+            case 4: e = run(std::integral_constant<int, 4>{}); break;
+            case 7: e = run(std::integral_constant<int, 7>{}); break;
+            case 15: e = run(std::integral_constant<int, 15>{}); break;
+            default: e = run(std::integral_constant<int, 0>{});
+        }
+    } else {
+        e = run(std::integral_constant<int, 0>{});
     }
 #else
-    e = tall ? launch(gemm_bf16x3_kernel<4, WAVES_N, 0, BMODE>) : launch(gemm_bf16x3_kernel<2, WAVES_N, 0, BMODE>);
+    e = run(std::integral_constant<int, 0>{});
 #endif
     if (e) return e;
     static const char *names[3][2] = {{"gemm_bf16x3_kernel<2, 4>", "gemm_bf16x3_kernel<4, 4>"},
@@ -383,6 +459,14 @@ inline bool tile_dims_ok(int M, int N, int K) {
 }
 
 }  // namespace
+
+// 1 (default): for K >= 1024 the shared operand is split once per call into a stream-ordered scratch buffer (hipMallocAsync,
+// M * K * 8 bytes, released after the product); 2: for every shape; 0: both operands are split inside the k-loop.  Same values.
+extern "C" int eap_gemm_bf16x3_presplit(int on) {
+    const int was = g_presplit;
+    if (on >= 0 && on <= 2) g_presplit = on;
+    return was;
+}
 
 // can the split kernel take this product?  (both operands k-contiguous, K a multiple of 16, 16-byte aligned rows; it pays
 // from a 256 x 256 tile per CU upwards)

@@ -287,6 +287,11 @@ int eap_gemm_bf16x3_f32_supported(int M, int N, int K, const float *A, int64_t l
                                   int64_t strideB);
 int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
                         float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+/* 1 (default): for K >= 1024 the operand shared by the batch (the weights) is split once per call into a stream-ordered
+ * scratch buffer (hipMallocAsync on the launch stream, 8 bytes per element, released after the product) instead of once per
+ * k-tile by every workgroup; 2: for every shape; 0: never (split inside the k-loop like the other operand).  Bit-identical
+ * results.  Returns the previous setting; any other argument only queries. */
+int eap_gemm_bf16x3_presplit(int on);
 /* the same product with B_z row-major [K, N] ("NN": W [O, C] times x_z [C, P*A], the pointwise contraction behind every
  * 1 x 1 conv of the blocks and heads -- torch.matmul / nn.Conv2d(1) in SPConvNets/utils/base_so3conv.py) */
 int eap_gemm_bf16x3_nn_f32_supported(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb,

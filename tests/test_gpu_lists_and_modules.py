@@ -767,3 +767,30 @@ def test_split_bf16_intra_conv_matches_fp32_kernel_and_fp64(dev, B, C, O, P):
     print(f'\nintra conv B{B} C{C} O{O} P{P}: split {err_split:.2e}, fp32 MFMA {err_fp32:.2e}')
     assert err_split < 3 * err_fp32 + 2e-7, (err_split, err_fp32)
     assert rel_err(out[True][1].numpy(), out[False][1].numpy()) < 1e-5       # two fp32 accumulations of K = 12 O products against each other
+
+
+def test_split_contraction_presplit_weights_is_bit_identical(dev):
+    """eap_gemm_bf16x3_presplit: the shared operand split once per call (scratch from hipMallocAsync) or inside the k-loop --
+    the same roundings, so the three layouts must agree bit for bit."""
+    from vgtk import _hip
+    import vgtk.so3conv.functional as L
+    gen = torch.Generator().manual_seed(77)
+    idx = torch.from_numpy(np.ascontiguousarray(L.get_intra_idx())).to(torch.int32).to(dev)
+    W = (torch.randn(256, 768, generator=gen) * 0.05).to(dev)
+    Bt = torch.randn(2, 1920, 768, generator=gen).to(dev)            # k-contiguous rows
+    Bn = torch.randn(2, 768, 1920, generator=gen).to(dev)            # row-major [K, N]
+    feats = torch.randn(2, 64, 32, 60, generator=gen).to(dev)        # intra: K = 64 * 12 = 768
+    outs = {}
+    for on in (2, 0):
+        was = _hip.lib.eap_gemm_bf16x3_presplit(on)
+        try:
+            c1 = torch.empty(2, 256, 1920, device=dev); c2 = torch.empty(2, 256, 1920, device=dev)
+            _hip.gemm(0, 1, 256, 1920, 768, W, 768, 0, Bt, 768, 1920 * 768, c1, 1920, 256 * 1920, 2)
+            _hip.gemm(0, 0, 256, 1920, 768, W, 768, 0, Bn, 1920, 768 * 1920, c2, 1920, 256 * 1920, 2)
+            c3 = _hip.so3_intra_conv(feats, W, idx)
+            outs[on] = (c1.cpu(), c2.cpu(), c3.cpu())
+        finally:
+            _hip.lib.eap_gemm_bf16x3_presplit(was)
+    assert _hip.lib.eap_gemm_bf16x3_presplit(-1) == 1, 'pre-split weights are the default'
+    for a, b in zip(outs[2], outs[0]):
+        assert torch.equal(a, b)

@@ -44,8 +44,20 @@ for (O, C) in ((256, 512), (512, 256), (512, 512), (128, 128)):
     print(f'pointwise contraction O={O} C={C} B={B}')
     f = lambda: _hip.gemm(0, 0, O, PA, C, W, C, 0, x, PA, C * PA, y, PA, O * PA, B)
     timed(with_split(True, f), fl, 'split (B row-major)')
+    _hip.lib.eap_gemm_bf16x3_presplit(0); timed(with_split(True, f), fl, 'split, weights split in the loop'); _hip.lib.eap_gemm_bf16x3_presplit(1)
     timed(with_split(False, f), fl, 'fp32 MFMA')
     del x, y
+for (O, CK) in ((512, 3072), (128, 1536)):
+    W = torch.randn(O, CK, device=dev) * 0.05
+    XT = torch.randn(B, PA, CK, device=dev)
+    y = torch.empty(B, O, PA, device=dev)
+    fl = 2.0 * O * CK * PA * B
+    print(f'forward contraction of the inter conv O={O} CK={CK} B={B}')
+    f = lambda: _hip.gemm(0, 1, O, PA, CK, W, CK, 0, XT, CK, PA * CK, y, PA, O * PA, B)
+    timed(with_split(True, f), fl, 'split')
+    _hip.lib.eap_gemm_bf16x3_presplit(0); timed(with_split(True, f), fl, 'split, weights split in the loop'); _hip.lib.eap_gemm_bf16x3_presplit(1)
+    timed(with_split(False, f), fl, 'fp32 MFMA')
+    del XT, y
 idx = torch.from_numpy(np.ascontiguousarray(L.get_intra_idx())).to(torch.int32).to(dev)
 for (O, C) in ((512, 512), (128, 128)):
     W = torch.randn(O, C * 12, device=dev) * 0.05
@@ -54,5 +66,6 @@ for (O, C) in ((512, 512), (128, 128)):
     print(f'intra conv O={O} C={C} B={B}')
     f = lambda: _hip.so3_intra_conv(feats, W, idx)
     timed(with_split(True, f), fl, 'split (implicit gather)')
+    _hip.lib.eap_gemm_bf16x3_presplit(0); timed(with_split(True, f), fl, 'split, weights split in the loop'); _hip.lib.eap_gemm_bf16x3_presplit(1)
     timed(with_split(False, f), fl, 'fp32 MFMA (implicit gather)')
     del feats
