@@ -399,11 +399,18 @@ int launch_split(Args &g, int batch, hipStream_t stream, const char *who) {
     // pays from a few thousand k-tiles per workgroup column upwards (+2.7 % on the deepest layer's contraction; on the 1-2 ms
     // pointwise contractions the extra launch and the allocation cost more than the saved vector work:
     // tools/split_modes_timing.py); the test switch value 2 forces it for every shape
-    const bool pre = g.sA == 0 && g.slabs <= 1 && (g_presplit == 2 || (g_presplit == 1 && g.K >= 1024));
+    bool pre = g.sA == 0 && g.slabs <= 1 && (g_presplit == 2 || (g_presplit == 1 && g.K >= 1024));
     void *scratch = nullptr;
     if (pre) {
         const long long pieces = (long long)g.M * (g.K / 4);
-        if (int e = eap::hip_fail(hipMallocAsync(&scratch, (size_t)pieces * 32, stream), who)) return e;
+        if (hipMallocAsync(&scratch, (size_t)pieces * 32, stream) != hipSuccess) {      // no stream-ordered pool on this device / out of
+            (void)hipGetLastError();                                                      // memory: split in the k-loop instead
+            scratch = nullptr;
+            pre = false;
+        }
+    }
+    if (pre) {
+        const long long pieces = (long long)g.M * (g.K / 4);
         hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, g.M, g.K / 4, g.A, g.lda,
                            reinterpret_cast<u32x4 *>(scratch));
         g.Apre = reinterpret_cast<const unsigned *>(scratch);
