@@ -109,7 +109,7 @@ class InvPPOutBlockOurs(nn.Module):
             idx = sel_mode_new.view(-1, 1, 1, 1).expand(-1, x_out.shape[1], x_out.shape[2], 1)
             return torch.gather(x_out, 3, idx).squeeze(-1)
         if self.pooling_method.startswith('attention'):
-            out_feat = self.attention_layer(x_out)                       # [b,1,n,a]
+            out_feat = _conv1x1(self.attention_layer, x_out)             # [b,1,n,a]
             return anchor_attention_pool(x_out, out_feat, self.temperature)
         raise NotImplementedError(f"Pooling mode {self.pooling_method} is not implemented!")
 
@@ -234,6 +234,14 @@ def compute_rotation_matrix_from_angle(anchors, angles, defined_axis=None):
             u * w * k - v * s, v * w * k + u * s, w * w + (u * u + v * v) * c]
     rows = [r.expand_as(ang) if r.shape != ang.shape else r for r in rows]
     return torch.stack(rows, -1).reshape(*ang.shape, 3, 3)
+
+
+def _conv1x1(conv, x):
+    """nn.Conv2d(c, o, 1) on x [b,c,n,a] as the path's contraction (no vendor convolution, no layout transposes; narrow
+    outputs -- 3 translation components, 1 attention logit -- are a single streaming read of x)."""
+    b, c, n, a = x.shape
+    y = L.so3_contract(conv.weight.view(conv.out_channels, c), x.reshape(b, c, n * a)).view(b, conv.out_channels, n, a)
+    return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
 
 
 def _unary_stack(x, linears, norms):
@@ -362,7 +370,7 @@ class SO3OutBlockRTWithMaskSep(nn.Module):
             dbn.num_batches_tracked.add_(1)
         y = _BNAct.apply(y, dbn.weight, dbn.bias, dbn.running_mean, dbn.running_var, dbn.training, dbn.momentum, dbn.eps,
                          dact.negative_slope, False, None, d0.bias)
-        t_out = F.conv2d(y, d1.weight, d1.bias)                                                       # [b, 3 h, n, a]: 3 h output channels
+        t_out = _conv1x1(d1, y)                                                                       # [b, 3 h, n, a]: 3 h output channels
         t_out = t_out.reshape((nb, self.num_heads, 3) + t_out.shape[-2:])                             # [b, h, 3, n, a]
         if self.global_scalar:
             y_t = self.regressor_scalar_layer(trans_shared_feat.max(dim=-1)[0]).reshape(nb, self.num_heads, -1)
@@ -539,7 +547,7 @@ def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
     cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, n, -1), shared], dim=1).contiguous()
     y = L.so3_contract(d0.weight.view(d0.out_channels, cat.shape[1]), cat.reshape(b, cat.shape[1], n * na)).view(b, d0.out_channels, n, na)
     y = _subset_batchnorm_act(y, d0.bias, mask, dbn, dact.negative_slope)
-    t_out = F.conv2d(y, d1.weight, d1.bias).reshape(b, head.num_heads, 3, n, na)
+    t_out = _conv1x1(d1, y).reshape(b, head.num_heads, 3, n, na)
     A = anchors if anchors.dim() == 4 else anchors.unsqueeze(0)
     y_t = torch.matmul(A.unsqueeze(1), t_out.permute(0, 1, 4, 2, 3).contiguous())                # [B, h, A, 3, P]
     if use_offset:
