@@ -16,7 +16,8 @@ and 3), mirroring the reference classes so a maintainer can swap the import:
 
   pose_head_over_subsets   the model's per-cloud loop around that head (...pn_38_multi_stage.py:L706-830) as one call per slot
 
-InvPPOutBlockOurs' 1x1 convolutions / BatchNorms are dense torch layers (rocBLAS / MIOpen plumbing)."""
+Every 1x1 convolution over the [B,C,N,A] map (InvPPOutBlockOurs' included) is the path's contraction, every BatchNorm +
+activation after one the fused epilogue; only the regressors on pooled [B,c,A] tensors are torch layers."""
 import ctypes
 
 import torch
@@ -244,6 +245,17 @@ def _conv1x1(conv, x):
     return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
 
 
+def _dense_on_pooled_and_shared(d0, pooled, shared):
+    """conv1x1(cat([pooled broadcast over the points, shared], dim=1)) of the dense translation branch
+    (model_utils.py:L537-548) without the concatenated tensor: the pooled half of the input is constant over the points, so
+    its product with the first half of the weights is a [b, o, a] term added to the contraction of the other half
+    (half the GEMM, no 2 GB cat).  pooled [b,c,a], shared [b,c,n,a] -> [b,o,n,a] (bias not added)."""
+    b, c, n, a = shared.shape
+    W = d0.weight.view(d0.out_channels, 2 * c)
+    y = L.so3_contract(W[:, c:], shared.reshape(b, c, n * a)).view(b, d0.out_channels, n, a)
+    return y + torch.einsum('oc,bca->boa', W[:, :c], pooled).unsqueeze(2)
+
+
 def _unary_stack(x, linears, norms):
     """relu(norm_i(conv1x1_i(x))) for every layer of a ModuleList pair (model_utils.py:L478-485): the 1x1 convolution
     is the path's contraction GEMM (csrc/gemm_dma_f32.hip through so3_contract), BatchNorm + ReLU the fused block
@@ -363,9 +375,7 @@ class SO3OutBlockRTWithMaskSep(nn.Module):
         # dense branch: per point and anchor, 3 * num_heads translation components.  Layers 0-2 of the Sequential
         # (conv, BatchNorm, LeakyReLU(0.01)) go through the fused epilogue
         d0, dbn, dact, d1 = self.regressor_dense_layer
-        cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, trans_shared_feat.shape[2], -1), trans_shared_feat], dim=1).contiguous()
-        b, c2, n, a = cat.shape
-        y = L.so3_contract(d0.weight.view(d0.out_channels, c2), cat.reshape(b, c2, n * a)).view(b, d0.out_channels, n, a)
+        y = _dense_on_pooled_and_shared(d0, trans_x_out, trans_shared_feat.contiguous())
         if dbn.training:
             dbn.num_batches_tracked.add_(1)
         y = _BNAct.apply(y, dbn.weight, dbn.bias, dbn.running_mean, dbn.running_var, dbn.training, dbn.momentum, dbn.eps,
@@ -544,8 +554,7 @@ def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
     shared = _masked_unary_stack(feats, mask, head.trans_linear, head.trans_norm)              # [B, c, P, A]
     trans_x_out = pool(shared)
     d0, dbn, dact, d1 = head.regressor_dense_layer
-    cat = torch.cat([trans_x_out.unsqueeze(2).expand(-1, -1, n, -1), shared], dim=1).contiguous()
-    y = L.so3_contract(d0.weight.view(d0.out_channels, cat.shape[1]), cat.reshape(b, cat.shape[1], n * na)).view(b, d0.out_channels, n, na)
+    y = _dense_on_pooled_and_shared(d0, trans_x_out, shared)
     y = _subset_batchnorm_act(y, d0.bias, mask, dbn, dact.negative_slope)
     t_out = _conv1x1(d1, y).reshape(b, head.num_heads, 3, n, na)
     A = anchors if anchors.dim() == 4 else anchors.unsqueeze(0)
