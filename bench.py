@@ -86,7 +86,7 @@ class SeparableBackbone(nn.Module):
     conv block -> + relu(norm(1x1 skip conv)) (SPConvNets/utils/base_so3poseconv.py:L270-328,
     ...pn_38_multi_stage.py:L369-374).  The reference only ever runs it forward, under no_grad
     (trainer_unsup_arti_align.py:L594-597); `bench.py --separable` reports it separately
-    (SURVEY.md 8(d)).  The 1x1 skip conv is a plain channel matmul (torch / rocBLAS plumbing)."""
+    (SURVEY.md 8(d)).  The 1x1 skip conv is the pointwise contraction (vgtk.so3conv.pointwise_conv)."""
 
     def __init__(self, input_num):
         super().__init__()
@@ -115,7 +115,7 @@ class SeparableBackbone(nn.Module):
             y = zptk.SphericalPointCloud(y.xyz, self.inter_norm[i](y.feats), y.anchors)
             y = self.intra[i](y)
             f = self.intra_norm[i](y.feats)
-            f = self.skip_norm[i](self.skip[i](skip), residual=f)        # relu(norm(skip)) + intra output, one pass
+            f = self.skip_norm[i](sptk.pointwise_conv(self.skip[i], skip, add_bias=False), residual=f, pre_bias=self.skip[i].bias)        # relu(norm(skip)) + intra output, one pass; the skip conv on the contraction kernel
             x = zptk.SphericalPointCloudPose(x.xyz, f, y.anchors, x.pose)
         return x.feats
 

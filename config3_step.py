@@ -71,7 +71,7 @@ class SeparableBackbone(nn.Module):
             skip = x.feats
             _, _, _, y = self.inter[i](x)
             y = self.intra[i](zptk.SphericalPointCloud(y.xyz, self.inter_norm[i](y.feats), y.anchors))
-            f = self.skip_norm[i](self.skip[i](skip), residual=self.intra_norm[i](y.feats))
+            f = self.skip_norm[i](sptk.pointwise_conv(self.skip[i], skip, add_bias=False), residual=self.intra_norm[i](y.feats), pre_bias=self.skip[i].bias)
             x = zptk.SphericalPointCloudPose(x.xyz, f, y.anchors, x.pose)
         return x.feats
 

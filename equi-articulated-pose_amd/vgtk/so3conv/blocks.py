@@ -123,16 +123,17 @@ class BatchNormLeakyReLU(nn.BatchNorm2d):
         self.negative_slope = negative_slope
         self.sync = sync          # batch statistics over all ranks (what nn.SyncBatchNorm does for the reference)
 
-    def forward(self, x, residual=None):
-        """leaky_relu(BatchNorm(x)) (+ residual: the separable block's `x.feats + skip_feature`,
-        base_so3poseconv.py:L319-328, added in the same pass).  In eval mode the normalisation is already folded
-        into one per-channel scale / shift (no statistics pass): a single read + write of the tensor."""
+    def forward(self, x, residual=None, pre_bias=None):
+        """leaky_relu(BatchNorm(x + pre_bias)) (+ residual: the separable block's `x.feats + skip_feature`,
+        base_so3poseconv.py:L319-328, added in the same pass).  pre_bias [C]: the bias of the 1x1 conv in front, folded into
+        the mean instead of a pass of its own.  In eval mode the normalisation is already folded into one per-channel
+        scale / shift (no statistics pass): a single read + write of the tensor."""
         if not x.is_cuda:
             raise RuntimeError('BatchNormLeakyReLU: tensor must be a CUDA(HIP) tensor (no CPU fallback)')
         if self.training:
             self.num_batches_tracked.add_(1)
         return _BNAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                            self.momentum, self.eps, self.negative_slope, self.sync, residual)
+                            self.momentum, self.eps, self.negative_slope, self.sync, residual, pre_bias)
 
 
 class InstanceNormLeakyReLU(nn.Module):

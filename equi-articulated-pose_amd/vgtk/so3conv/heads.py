@@ -237,12 +237,16 @@ def compute_rotation_matrix_from_angle(anchors, angles, defined_axis=None):
     return torch.stack(rows, -1).reshape(*ang.shape, 3, 3)
 
 
-def _conv1x1(conv, x):
+def pointwise_conv(conv, x, add_bias=True):
     """nn.Conv2d(c, o, 1) on x [b,c,n,a] as the path's contraction (no vendor convolution, no layout transposes; narrow
-    outputs -- 3 translation components, 1 attention logit -- are a single streaming read of x)."""
+    outputs -- 3 translation components, 1 attention logit -- are a single streaming read of x).  add_bias=False: the
+    caller folds the bias into the BatchNorm that follows (BatchNormLeakyReLU.forward(..., pre_bias=conv.bias))."""
     b, c, n, a = x.shape
     y = L.so3_contract(conv.weight.view(conv.out_channels, c), x.reshape(b, c, n * a)).view(b, conv.out_channels, n, a)
-    return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+    return y if (conv.bias is None or not add_bias) else y + conv.bias.view(1, -1, 1, 1)
+
+
+_conv1x1 = pointwise_conv
 
 
 def _dense_on_pooled_and_shared(d0, pooled, shared):

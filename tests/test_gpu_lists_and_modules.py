@@ -794,3 +794,47 @@ def test_split_contraction_presplit_weights_is_bit_identical(dev):
     assert _hip.lib.eap_gemm_bf16x3_presplit(-1) == 1, 'pre-split weights are the default'
     for a, b in zip(outs[2], outs[0]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('c,o', [(1, 64), (256, 3), (24, 1), (64, 128)])
+def test_pointwise_conv_equals_conv2d(dev, c, o):
+    """vgtk.so3conv.pointwise_conv (the contraction kernels behind every 1x1 conv of blocks and heads, narrow and single-channel
+    shapes included) against nn.Conv2d: output and all three gradients; with the bias folded into BatchNormLeakyReLU
+    (pre_bias) against conv -> BatchNorm2d -> leaky_relu."""
+    import vgtk.so3conv as sptk
+    torch.manual_seed(c * 7 + o)
+    conv = torch.nn.Conv2d(c, o, 1).to(dev)
+    x = torch.randn(2, c, 37, 60, device=dev)
+    g = torch.randn(2, o, 37, 60, device=dev)
+    res = []
+    for fn in (lambda t: conv(t), lambda t: sptk.pointwise_conv(conv, t)):
+        xi = x.clone().requires_grad_(True)
+        y = fn(xi)
+        grads = torch.autograd.grad(y, [xi, conv.weight, conv.bias], g)
+        res.append((y.detach(),) + grads)
+    for name, a, b in zip(('y', 'dx', 'dW', 'dbias'), res[1], res[0]):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, name
+    # bias folded into the fused BatchNorm + leaky_relu
+    bn_ref = torch.nn.BatchNorm2d(o).to(dev)
+    bn = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-0.3, 0.3)
+    bn.load_state_dict(bn_ref.state_dict())
+    for training in (True, False):
+        bn_ref.train(training); bn.train(training)
+        xi = x.clone().requires_grad_(True)
+        ref = torch.nn.functional.leaky_relu(bn_ref(conv(xi)), 0.01)
+        gr = torch.autograd.grad(ref, [xi, conv.weight], g)
+        xj = x.clone().requires_grad_(True)
+        got = bn(sptk.pointwise_conv(conv, xj, add_bias=False), pre_bias=conv.bias)
+        gg = torch.autograd.grad(got, [xj, conv.weight], g)
+        # c = 1: a channel is w * x + bias with |w| down to 1e-3 -- adding the bias first (the reference order) rounds the values
+        # at 6e-8 while their spread is 1e-3, i.e. the REFERENCE order carries ~1e-4 of noise into the normalised output
+        tol = 3e-4 if c == 1 else 1e-5
+        assert rel_err(got.detach().cpu().numpy(), ref.detach().cpu().numpy()) < tol, training
+        for name, a, b in zip(('dx', 'dW'), gg, gr):
+            if c == 1 and training and name == 'dW':
+                continue        # BatchNorm is invariant to the scale of its input channel: with one input channel dW is zero up to eps, all noise
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5 * tol, (training, name)
+        assert rel_err(bn.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy()) < 1e-5
+        assert rel_err(bn.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy()) < 1e-5
