@@ -539,6 +539,38 @@ def intra_so3conv(feats, W, intra_idx):
     return _IntraConv.apply(feats, W, intra_idx.to(torch.int32).contiguous())
 
 
+class _NarrowContract(torch.autograd.Function):
+    """_Contract for at most four output channels (the pose head's translation components, the attention logit): no matrix
+    core has work for 1-4 rows, the op is a streaming pass over x in each direction (csrc/narrow_contract.hip)."""
+
+    @staticmethod
+    def forward(ctx, W, x):
+        W, x = W.contiguous(), x.contiguous()
+        b, c, n = x.shape
+        o = W.shape[0]
+        y = torch.empty(b, o, n, dtype=torch.float32, device=x.device)
+        _hip.call('eap_narrow_contract_fwd_f32', x, b, o, c, _hip._I64(n), _hip._ptr(W), _hip._ptr(x), _hip._ptr(y))
+        ctx.save_for_backward(W, x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, x = ctx.saved_tensors
+        gy = gy.contiguous()
+        b, c, n = x.shape
+        o = W.shape[0]
+        gW = gx = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.empty_like(x)
+            _hip.call('eap_narrow_contract_dx_f32', x, b, o, c, _hip._I64(n), _hip._ptr(W), _hip._ptr(gy), _hip._ptr(gx))
+        if ctx.needs_input_grad[0]:
+            slabs = int(_hip.lib.eap_narrow_contract_dw_slabs(_hip._I64(n)))
+            part = torch.empty(slabs * b, o, c, dtype=torch.float32, device=x.device)
+            _hip.call('eap_narrow_contract_dw_f32', x, b, o, c, _hip._I64(n), _hip._ptr(gy), _hip._ptr(x), _hip._ptr(part))
+            gW = part.sum(0, dtype=torch.float64).float()
+        return gW, gx
+
+
 def so3_contract(W, x):
     """W [O, C*K], x [b, C*K, P*A] -> [b, O, P*A]."""
     _hip.check_input(x)
@@ -546,6 +578,8 @@ def so3_contract(W, x):
         raise RuntimeError('so3_contract: float32 only')
     if not W.is_cuda:
         raise RuntimeError('so3_contract: W must be a device tensor')
+    if W.shape[0] <= 4 and _hip.lib.eap_narrow_contract_supported(x.shape[0], W.shape[0], x.shape[1], _hip._I64(x.shape[2])):
+        return _NarrowContract.apply(W, x)
     return _Contract.apply(W, x)
 
 

@@ -414,6 +414,19 @@ int eap_bn_act_cloud_bwd_apply_f32(int b, int c, int64_t n, int na, float slope,
                                    const float *scale, const float *shift, const float *mean, const float *invstd,
                                    const float *k2, const float *k3, const float *mask, float *gx, eap_stream_t stream);
 
+/* ---- pointwise contraction with 1-4 output channels (csrc/narrow_contract.hip) --------------------------------- */
+/* y[b,o,n] = sum_c W[o,c] x[b,c,n], o <= 4, c <= 2048, n a multiple of 4: the last layer of the pose head's dense translation
+ * branch (nn.Conv2d(c, 3 * num_heads, 1), SPConvNets/models/model_utils.py:L537-552) and the attention logit of
+ * InvPPOutBlockOurs (nn.Conv2d(c, 1, 1), SPConvNets/utils/base_so3conv.py:L905-912) as streaming passes over x. */
+int eap_narrow_contract_supported(int b, int o, int c, int64_t n);
+int eap_narrow_contract_fwd_f32(int b, int o, int c, int64_t n, const float *W, const float *x, float *y, eap_stream_t stream);
+/* dx[b,c,n] = sum_o W[o,c] g[b,o,n] */
+int eap_narrow_contract_dx_f32(int b, int o, int c, int64_t n, const float *W, const float *g, float *dx, eap_stream_t stream);
+/* dW[o,c] = sum_{b,n} g[b,o,n] x[b,c,n] as eap_narrow_contract_dw_slabs(n) * b partials [slab][b][o][c] for the caller to sum
+ * in order (deterministic) */
+int eap_narrow_contract_dw_slabs(int64_t n);
+int eap_narrow_contract_dw_f32(int b, int o, int c, int64_t n, const float *g, const float *x, float *partial, eap_stream_t stream);
+
 /* ---- heads on the backbone's [b,c,n,na] feature map ------------------------ */
 /* Anchor attention pooling, InvPPOutBlockOurs.forward (SPConvNets/utils/base_so3conv.py:L905-912):
  * conf[b,n,a] = softmax_a(logits[b,n,a] * temperature), out[b,c,n] = sum_a x[b,c,n,a] conf[b,n,a].  na % 4 == 0, <= 64.

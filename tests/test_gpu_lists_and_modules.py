@@ -838,3 +838,28 @@ def test_pointwise_conv_equals_conv2d(dev, c, o):
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5 * tol, (training, name)
         assert rel_err(bn.running_mean.cpu().numpy(), bn_ref.running_mean.cpu().numpy()) < 1e-5
         assert rel_err(bn.running_var.cpu().numpy(), bn_ref.running_var.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('b,o,c,n', [(2, 3, 40, 42000), (1, 4, 17, 8196), (3, 1, 256, 2220), (2, 2, 5, 4)])
+def test_narrow_contraction_equals_the_gemm_path(dev, b, o, c, n):
+    """csrc/narrow_contract.hip (1-4 output channels, streaming) against the general contraction and fp64: forward, dX, dW over
+    several column slabs, a ragged channel group, a single 4-column row."""
+    import vgtk.so3conv.functional as L
+    gen = torch.Generator().manual_seed(b + o + c + n)
+    W = torch.randn(o, c, generator=gen).to(dev)
+    x = torch.randn(b, c, n, generator=gen).to(dev)
+    g = torch.randn(b, o, n, generator=gen).to(dev)
+    res = []
+    for fn in (L._NarrowContract, L._Contract):
+        Wi, xi = W.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        y = fn.apply(Wi, xi)
+        gW, gx = torch.autograd.grad(y, [Wi, xi], g)
+        res.append((y.detach(), gW, gx))
+    ref = (torch.matmul(W.double().cpu(), x.double().cpu()),
+           torch.einsum('bon,bcn->oc', g.double().cpu(), x.double().cpu()),
+           torch.matmul(W.double().cpu().t(), g.double().cpu()))
+    for name, a, bb, r in zip(('y', 'dW', 'dx'), res[0], res[1], ref):
+        assert rel_err(a.cpu().numpy(), r.numpy()) < 3e-6, name
+        assert rel_err(a.cpu().numpy(), bb.cpu().numpy()) < 5e-6, name
+    y = L.so3_contract(W, x)
+    assert torch.equal(y, res[0][0]), 'so3_contract must take the streaming kernels for <= 4 output channels'
