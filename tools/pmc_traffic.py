@@ -25,8 +25,8 @@ def key_of(name):
         out += ch
     if out.startswith('gemm_dma_f32_kernel'):
         out = re.sub(r',\s*0>$', '>', out)      # trailing default template argument of the GEMM (ablation switch)
-    m = re.match(r'gemm_bf16x3_kernel<(\d+), (\d+), \d+, (\d+)>$', out)
-    if m:                                       # <MI, WN, ablation switch, B layout> -> the name eap_last_kernel() reports
+    m = re.match(r'gemm_bf16x3_kernel<(\d+), (\d+), \d+, (\d+)(?:, (?:true|false))?>$', out)
+    if m:                                       # <MI, WN, ablation switch, B layout, pre-split weights> -> the name eap_last_kernel() reports
         out = 'gemm_bf16x3_kernel<%s, %s%s>' % (m.group(1), m.group(2), ('', ', nn', ', gather')[int(m.group(3))])
     return out if any(w in out for w in WANT) else None
 
