@@ -227,6 +227,38 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
     float *s_o = s_f;
     float *ob = out + (size_t)bi * c * ks * p * na + (size_t)pi * na;
     const size_t o_ks = (size_t)p * na, o_cs = (size_t)ks * p * na;
+    // transposed output [point*na + a][c*ks + k] (what the contraction reads k-contiguous): the LDS tile is laid out
+    // [anchor][8 channels x ks] so that an anchor's 8 * ks values of a pass leave as ONE contiguous run of its output row
+    // (768 bytes at ks = 24; round 2 wrote them as 4-byte stores 12 KB apart)
+    if (blocked == 2 && (ks & 3) == 0 && (c & 7) == 0) {
+        const int run = 8 * ks, pitch = run + 4;                        // floats; 16-byte aligned rows, off the bank period
+        const size_t CK = (size_t)c * ks;
+        float *obt = out + (size_t)bi * c * o_cs + (size_t)pi * na * CK + (size_t)c0 * ks;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            if (lk < ks) {
+#pragma unroll
+                for (int ai = 0; ai < APW; ++ai) {
+                    if (ai < a_cnt) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            s_o[(size_t)(a_beg + ai) * pitch + (rr + 4 * lh) * ks + lk] = acc[ai][ps * 4 + rr];
+                    }
+                }
+            }
+            __syncthreads();
+            if (c0 + ps * 8 < c) {                                       // block-uniform (c is a multiple of 8)
+                const int q4 = run >> 2;                                 // float4 per anchor
+                for (int f = t; f < na * q4; f += TM) {
+                    const int a = f / q4, j = f - a * q4;
+                    *reinterpret_cast<float4 *>(obt + (size_t)a * CK + (size_t)ps * run + 4 * j) =
+                        *reinterpret_cast<const float4 *>(s_o + (size_t)a * pitch + 4 * j);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         if (lk < ks) {
@@ -286,7 +318,7 @@ int eap::group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, floa
         return eap::hip_fail(hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * c * ks * p * na, s), "so3_inter_group_fwd memset");
     const int nn_pad = (nn + NBK - 1) / NBK * NBK;
     size_t shmem = sizeof(float) * 2 * NBK * CB * FP_ + 20 * (size_t)nn_pad + (mult ? (size_t)na * na : 0);
-    const size_t epi = sizeof(float) * 8 * (size_t)ks * na;
+    const size_t epi = sizeof(float) * (8 * (size_t)ks + 4) * na;      // the transposed epilogue pads its rows by 4 floats
     if (epi > sizeof(float) * 2 * NBK * CB * FP_) return eap::bad_arg("so3_inter_group_fwd_mfma: epilogue tile too large");
     dim3 grid(p, (c + CB - 1) / CB, b);
     const float4 *g4 = reinterpret_cast<const float4 *>(gx);
