@@ -96,6 +96,9 @@ int zpconv_index_check(int b, int np, int per_point, int nn, const int32_t *idx,
 int inter_zpconv_bwd_flagged(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx, const float *w,
                              const float *grad, float *gfeats, const int32_t *only_flagged, hipStream_t s);
 // csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped
+int group_fwd_perm_lists(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats, const int32_t *idx,
+                         const float *gx, const float *rk, const uint8_t *mult, const int32_t *nonident, int blocked, float *out,
+                         hipStream_t s);      // csrc/so3_inter_inv.hip; -1 = shape not taken
 int group_fwd_mfma(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                    const int32_t *idx, const float *gx, const float *rk, const uint8_t *mult,
                    const int32_t *nonident, int skip_plain, int blocked, float *out, hipStream_t s);

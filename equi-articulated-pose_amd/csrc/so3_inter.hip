@@ -357,6 +357,9 @@ static int group_fwd_dispatch(int blocked, int b, int c, int p, int n, int nn, i
                         ? eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream))
                         : eap::group_lists_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream));
             if (e || !mult) return e;
+            // the permuted clouds: the entry-list kernel of csrc/so3_inter_inv.hip in its forward mode, else the register-staged one
+            e = eap::group_fwd_perm_lists(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, blocked, out, eap::S(stream));
+            if (e >= 0) return e;
             return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 1, blocked, out, eap::S(stream));
         }
         return eap::group_fwd_mfma(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult, nonident, 0, 0, out, eap::S(stream));

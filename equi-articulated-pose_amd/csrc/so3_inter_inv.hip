@@ -61,13 +61,19 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // DMA = true: dY rows go global -> LDS directly (row pitch = na, no padding possible), issued
 // between the MFMA steps of the previous chunk; DMA = false: register-staged rows with a padded
 // pitch (anchor counts whose pitch would be a multiple of 32 banks).
-template <bool HAS_MULT, bool DMA>
+// FWD = true: the same kernel as the FORWARD grouping of clouds with per-neighbour anchor permutations (round 3; it
+// replaces csrc/so3_inter_mfma.hip's register-staged kernel there): row ri = query point ri, its entries = its nn
+// neighbours (ent_p = idx, shadow indices >= p carry weight 0), the table is `mult`, the offset vectors are NOT rotated
+// (the weight of output anchor a uses a itself), clouds whose flag says "all identity" are left to the entry-list kernel,
+// and the output is X in the reference layout (blocked = 0) or transposed [row*na + a][c*ks + k] (blocked = 2).
+template <bool HAS_MULT, bool DMA, bool FWD = false>
 __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     int o, int p, int nn, int na, int ks, int rcap, float inv_sigma, int identity_anchor,
     const float *__restrict__ gy,
     const int32_t *__restrict__ rows, const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx, const float *__restrict__ rk,
-    const uint8_t *__restrict__ multinv, const float *__restrict__ anchors, float *__restrict__ out) {
+    const uint8_t *__restrict__ multinv, const float *__restrict__ anchors, float *__restrict__ out,
+    int blocked, const int32_t *__restrict__ nonident) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int FP = DMA ? na : (na <= 60 ? 60 : FPMAX), FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
@@ -94,15 +100,16 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     }
     const int c0 = cy * CB;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int q = rows[(size_t)bi * rcap + ri];
-    const int n_ent = q >= 0 ? cnt[(size_t)bi * rcap + ri] : 0;
-    const size_t e0 = (size_t)bi * p * nn + (q >= 0 ? off[(size_t)bi * rcap + ri] : 0);
+    if (FWD && nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) == 0) return;   // identity cloud: the entry-list kernel's
+    const int q = FWD ? ri : rows[(size_t)bi * rcap + ri];
+    const int n_ent = FWD ? nn : (q >= 0 ? cnt[(size_t)bi * rcap + ri] : 0);
+    const size_t e0 = FWD ? ((size_t)bi * rcap + ri) * nn : (size_t)bi * p * nn + (q >= 0 ? off[(size_t)bi * rcap + ri] : 0);
 
     if (HAS_MULT) {
         const int words = (na * na) >> 2;
         for (int i = t; i < words; i += TM)
             reinterpret_cast<uint32_t *>(s_mult)[i] = reinterpret_cast<const uint32_t *>(multinv)[i];
-        for (int i = t; i < 3 * na; i += TM) s_A[i] = make_float4(anchors[3 * i], anchors[3 * i + 1], anchors[3 * i + 2], 0.f);
+        if (!FWD) for (int i = t; i < 3 * na; i += TM) s_A[i] = make_float4(anchors[3 * i], anchors[3 * i + 1], anchors[3 * i + 2], 0.f);
         __syncthreads();
     }
     // Anchor permutation.  An entry with relative-rotation anchor r pairs the accumulator's anchor a' with the dY
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     // wave's OWN anchors -- per-lane register constants, as without permutation (round 1 looked the constants of
     // every (entry, anchor) pair up in an LDS table: a 16-byte LDS read and an address computation per weight).
     auto rotate_entry = [&](float4 g) {
-        if (HAS_MULT) {
+        if (HAS_MULT && !FWD) {
             const int r = __float_as_int(g.w);
             if (r != identity_anchor && (unsigned)r < (unsigned)na && g.x < 1e17f) {
                 const float4 r0 = s_A[3 * r], r1 = s_A[3 * r + 1], r2 = s_A[3 * r + 2];
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             const int nl = (u * (TM / 16) + rgrp) / CB;
             next_p[u] = ent_p[e0 + min(j0 + nl, max(n_ent - 1, 0))];
             if (j0 + nl >= n_ent) next_p[u] = -1;
+            if (FWD && (unsigned)next_p[u] >= (unsigned)p) next_p[u] = -1;       // shadow neighbour: zero features
         }
     };
     unsigned row_off[NST];                            // 32-bit element offsets, channel part precomputed
@@ -230,6 +238,10 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             idx_p = ent_p[e];
             idx_g = ent_gx[e];
             if (j >= n_ent) idx_g = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+            if (FWD && (unsigned)idx_p >= (unsigned)p) {                           // shadow neighbour: any valid row, weight 0
+                idx_p = 0;
+                idx_g = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+            }
         }
     };
     auto store_idx = [&](int slot) {
@@ -440,6 +452,41 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     float *s_o = s_f;
     float *ob = out + (size_t)bi * o * ks * rcap * na + (size_t)ri * na;
     const size_t o_ks = (size_t)rcap * na, o_cs = (size_t)ks * rcap * na;
+    if (FWD && blocked == 2) {
+        // transposed output [row*na + a][c*ks + k]: LDS tile [anchor][8 channels x ks], an anchor's 8 * ks values of a pass leave
+        // as one contiguous run of its output row (as csrc/so3_inter_mfma.hip; the launcher checks ks % 4 == 0, o % 8 == 0)
+        __syncthreads();                                   // the last chunk's operand reads are done before the tile is overwritten
+        const int run = 8 * ks, pitch = run + 4;
+        const size_t CK = (size_t)o * ks;
+        float *obt = out + (size_t)bi * o * o_cs + (size_t)ri * na * CK + (size_t)c0 * ks;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            if (lk < ks) {
+#pragma unroll
+                for (int ai = 0; ai < APW; ++ai) {
+                    if (ai < a_cnt) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            s_o[(size_t)(a_beg + ai) * pitch + (rr + 4 * lh) * ks + lk] = acc[ai][ps * 4 + rr];
+                    }
+                }
+            }
+            __syncthreads();
+            if (c0 + ps * 8 < o) {
+                const int q4 = run >> 2;                                 // float4 per anchor
+                const int da = TM / q4, dj = TM - da * q4;               // (anchor, piece) advance incrementally: no division in the loop
+                int a = t / q4, j = t - a * q4;
+                while (a < na) {
+                    *reinterpret_cast<float4 *>(obt + (size_t)a * CK + (size_t)ps * run + 4 * j) =
+                        *reinterpret_cast<const float4 *>(s_o + (size_t)a * pitch + 4 * j);
+                    a += da; j += dj;
+                    if (j >= q4) { j -= q4; ++a; }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         if (lk < ks) {
@@ -472,6 +519,36 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
 }
 
 }  // namespace
+
+// forward grouping of the clouds WITH per-neighbour anchor permutations on the kernel above (FWD = true); identity clouds
+// (nonident[b] == 0) are skipped.  feats [b,c,n,na], idx [b,p,nn], gx [b,p,nn,4]; out: X [b,c,ks,p,na] (blocked = 0) or
+// transposed (blocked = 2).  -1: this shape is not taken (the caller falls back to csrc/so3_inter_mfma.hip).
+static int g_perm_fwd_lists = 1;      // eap_so3_group_perm_fwd(0): the round-1 register-staged kernel (csrc/so3_inter_mfma.hip), for A/B runs
+
+extern "C" int eap_so3_group_perm_fwd(int on) {
+    const int was = g_perm_fwd_lists;
+    if (on == 0 || on == 1) g_perm_fwd_lists = on;
+    return was;
+}
+
+int eap::group_fwd_perm_lists(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats, const int32_t *idx,
+                              const float *gx, const float *rk, const uint8_t *mult, const int32_t *nonident, int blocked, float *out,
+                              hipStream_t s) {
+    if (!g_perm_fwd_lists) return -1;
+    if (!mult || !nonident || (blocked != 0 && blocked != 2) || (na & 7) != 4 || na > 64 || ks > 32) return -1;
+    if (blocked == 2 && ((ks & 3) != 0 || (c & 7) != 0)) return -1;
+    if ((long long)c * n * na >= (1ll << 31)) return -1;
+    const size_t stage_b = sizeof(float) * 2 * NBK * CB * na;
+    if (sizeof(float) * (8 * (size_t)ks + 4) * na > stage_b) return -1;
+    const size_t shmem = stage_b + 16 * 3 * NBK + 16 * NBK + 16 * 3 * (size_t)na + (size_t)na * na;
+    if (shmem > 160 * 1024) return -1;
+    auto kern = so3_inter_group_inv_kernel<true, true, true>;
+    if (int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_fwd (permuted) shared memory")) return e;
+    hipLaunchKernelGGL(kern, dim3(p, (c + CB - 1) / CB, b), dim3(TM), shmem, s, c, n, nn, na, ks, p, 1.0f / sigma, -1, feats,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, idx, reinterpret_cast<const float4 *>(gx), rk,
+                       mult, (const float *)nullptr, out, blocked, nonident);
+    return eap::check_launch("so3_inter_group_fwd (permuted clouds, entry-list kernel)");
+}
 
 // gy rows padded to `gy_pitch` floats (a multiple of 4, >= na; e.g. 64: every row starts a 256-byte line):
 // same result, only the entry-list kernel (no anchor permutation) takes it
@@ -523,7 +600,8 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     auto launch = [&](auto kern) {
         int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
         if (e) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, anchors, z);
+        hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, anchors, z,
+                           0, (const int32_t *)nullptr);
         return 0;
     };
     int e;

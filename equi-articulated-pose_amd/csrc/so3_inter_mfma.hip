@@ -249,10 +249,13 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_fwd_mfma_kernel(
             __syncthreads();
             if (c0 + ps * 8 < c) {                                       // block-uniform (c is a multiple of 8)
                 const int q4 = run >> 2;                                 // float4 per anchor
-                for (int f = t; f < na * q4; f += TM) {
-                    const int a = f / q4, j = f - a * q4;
+                const int da = TM / q4, dj = TM - da * q4;               // (anchor, piece) advance incrementally: no division in the loop
+                int a = t / q4, j = t - a * q4;
+                while (a < na) {
                     *reinterpret_cast<float4 *>(obt + (size_t)a * CK + (size_t)ps * run + 4 * j) =
                         *reinterpret_cast<const float4 *>(s_o + (size_t)a * pitch + 4 * j);
+                    a += da; j += dj;
+                    if (j >= q4) { j -= q4; ++a; }
                 }
             }
             __syncthreads();

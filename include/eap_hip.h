@@ -196,6 +196,10 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
  * (csrc/so3_inter_lists3.hip; an experiment: correct, slower on real neighbour lists); 0 = query.  Returns the value in force.  1 and 2 agree bit for bit, 3 with them to fp32
  * rounding (tests compare them). */
 int eap_so3_group_lists_tiles(int tiles);
+/* forward grouping of clouds WITH anchor permutations: 1 (default) = the entry-list kernel of csrc/so3_inter_inv.hip in its
+ * forward mode (global -> LDS DMA rows), 0 = the register-staged kernel of csrc/so3_inter_mfma.hip (round 1); returns the
+ * previous setting, any other argument only queries.  Same results to rounding; for A/B runs and tests. */
+int eap_so3_group_perm_fwd(int on);
 /* Block -> XCD map of the two-tile kernel: mode 1 = an XCD (one L2) owns whole (channel slice, cloud) pairs, 2 = whole
  * (channel slice, cloud, anchor group) triples; which = 0 forward, 1 backward; mode 0 = query.  Same results either way. */
 int eap_so3_group_lists_xcd_map(int which, int mode);
