@@ -230,7 +230,24 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
     grad = torch.randn(clouds, channels, KS, points, NA, device=dev)
     ms_b = timed(lambda: Z.inter_zpconv_backward(idx, w, grad, points))
     gbs = byts / ms / 1e6
-    return {'bound': 'hbm', 'kernel': 'zpconv_index_check_kernel + zpconv_mfma_kernel (v_mfma_f32_32x32x2_f32, streamed weights)',
+    # fabric-side bytes of the kernels behind the two entries, from the committed counter passes (profiles/r03_pmc_traffic.json,
+    # per launch): the index check reads the 5-D index once per call (its launches are split by cloud chunk in the backward),
+    # the backward runs its product / sum kernels once per scratch chunk
+    traffic = None
+    pmc = {k: pmc_of_kernel(k) for k in ('zpconv_index_check_kernel', 'zpconv_mfma_kernel', 'zpconv_bwd_t_kernel<true>', 'zpconv_bwd_sum_kernel')}
+    if all(pmc.values()) and clouds == 8 and points == 4096 and channels == 64:
+        tot = lambda k: pmc[k]['fetch'] + pmc[k]['write']
+        idx_bytes = 4.0 * clouds * points * NA * KS * NN
+        chunks = max(1, -(-int(4 * clouds * points * NN * channels * NA) // int(Z.BWD_WORKSPACE_BYTES)))
+        fwd_b = idx_bytes + tot('zpconv_mfma_kernel')
+        bwd_b = idx_bytes + chunks * (tot('zpconv_bwd_t_kernel<true>') + tot('zpconv_bwd_sum_kernel'))
+        traffic = {'forward_bytes': fwd_b, 'forward_GBps': fwd_b / ms / 1e6, 'forward_frac_of_peak': fwd_b / ms / 1e6 / 8000.0,
+                   'backward_bytes': bwd_b, 'backward_GBps': bwd_b / ms_b / 1e6, 'backward_frac_of_peak': bwd_b / ms_b / 1e6 / 8000.0,
+                   'backward_scratch_chunks': chunks,
+                   'per_launch': {k: {'fetch': v['fetch'], 'write': v['write'], 'l2_hit': v.get('l2_hit')} for k, v in pmc.items()},
+                   'note': 'FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes; the backward figure includes the per-(point, '
+                           'neighbour) products it writes and re-reads, which the algorithmic bytes leave out'}
+    return {'bound': 'hbm', 'traffic': traffic, 'kernel': 'zpconv_index_check_kernel + zpconv_mfma_kernel (v_mfma_f32_32x32x2_f32, streamed weights)',
             'entry': 'eap_inter_zpconv_fwd_ws_f32', 'achieved': gbs,
             'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'ms': ms, 'bytes': byts,
             'backward': {'entry': 'eap_inter_zpconv_bwd_ws_f32',
