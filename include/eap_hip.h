@@ -92,6 +92,12 @@ int64_t eap_inter_zpconv_fwd_workspace(int b, int np, int ann);
 int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c,
                                 const int32_t *idx, const float *w, const float *feats, float *out,
                                 void *workspace, eap_stream_t stream);
+/* matrix kernel of eap_inter_zpconv_fwd_ws_f32: 1 (default) = csrc/zpconv_mfma.hip; 2 = csrc/zpconv_mfma2.hip (32-neighbour
+ * weight blocks: every 128-byte line of w consumed in one visit -- a third less traffic, measured not faster) where the
+ * neighbour count is 64 or 128.
+ * Returns the previous setting; other values only query.  Same results to rounding (the neighbour sums associate
+ * differently); for A/B runs and tests. */
+int eap_inter_zpconv_fwd_kernel(int which);
 /* inter_zpconv_backward: zpconv_cuda.cpp:L58-75, kernel .cu:L77-116.
  * grad [b,c,ks,np,na] -> gfeats [b,c,nq,na]. */
 int eap_inter_zpconv_bwd_f32(int b, int np, int nq, int na, int ks, int ann, int c,
