@@ -87,7 +87,9 @@ bool inter_zpconv_rows_supported(int np, int nq, int na, int ks, int nn, int c);
 int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx, const float *w,
                           const float *feats, float *out, const int32_t *only_flagged, hipStream_t s);
 // csrc/zpconv_mfma.hip: the same op on the matrix cores for clouds with one neighbour list per point (skip[b] == 0)
+int zp_fwd_kernel();                                                                   // eap_inter_zpconv_fwd_kernel's setting
 bool inter_zpconv_mfma2_supported(int np, int nq, int na, int ks, int nn, int c);     // csrc/zpconv_mfma2.hip
+
 int inter_zpconv_mfma2_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx0, const float *w,
                            const float *feats, const int32_t *skip, float *out, hipStream_t s);
 bool inter_zpconv_mfma_supported(int np, int nq, int na, int ks, int nn, int c);

@@ -421,8 +421,9 @@ extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks
     if (e) return e;
     e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, idx0, nullptr, flag, s);
     if (e) return e;
-    e = eap::inter_zpconv_mfma2_supported(np, nq, na, ks, ann, c) ? eap::inter_zpconv_mfma2_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s)
-                                                                  : eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
+    const int which = eap::zp_fwd_kernel();
+    if (which == 2 && eap::inter_zpconv_mfma2_supported(np, nq, na, ks, ann, c)) e = eap::inter_zpconv_mfma2_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
+    else e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
     if (e) return e;
     return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, flag, s);
 }

@@ -20,7 +20,9 @@
 // bandwidth-bound: the matrix pipe is busy a third of the time in both (0.33 / 0.35), the rest is the per-stage
 // barrier + DMA round trip (twice as many stages here, 16 MFMAs each instead of 32) and the row-end exchange, during
 // which nothing else runs on a CU that holds ONE workgroup.  Correct and tested (tests/test_gpu_parity.py), kept behind
-// eap_inter_zpconv_fwd_kernel(2); the first kernel stays the default.
+// eap_inter_zpconv_fwd_kernel(2); the first kernel stays the default.  A third cut -- the first kernel's scheme in 4-wave
+// workgroups of 16 anchors, TWO per CU so that one's row end overlaps the other's matrix work -- was bit-identical and
+// slower still (11.1 ms, 36.4 GB fetched + 15.7 GB written in 64-byte pieces, matrix pipe 0.32): not kept.
 #include "common.h"
 #include <type_traits>
 #include <utility>
@@ -328,8 +330,10 @@ int g_zp_fwd_kernel = 1;      // eap_inter_zpconv_fwd_kernel: 1 = csrc/zpconv_mf
 
 namespace eap {
 
+int zp_fwd_kernel() { return g_zp_fwd_kernel; }
+
 bool inter_zpconv_mfma2_supported(int np, int nq, int na, int ks, int nn, int c) {
-    return g_zp_fwd_kernel == 2 && inter_zpconv_mfma_supported(np, nq, na, ks, nn, c) && (nn == 64 || nn == 128) &&
+    return inter_zpconv_mfma_supported(np, nq, na, ks, nn, c) && (nn == 64 || nn == 128) &&
            (long long)na * ks * nn * 4 * RPB < (1ll << 40);
 }
 

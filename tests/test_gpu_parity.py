@@ -757,23 +757,24 @@ def test_inter_zpconv_matrix_path_edges(dev):
     import vgtk.cuda.zpconv as Z
     from vgtk import _hip as _h
     rng = np.random.default_rng(11)
-    _h.lib.eap_inter_zpconv_fwd_kernel(2)          # shapes with 64 / 128 neighbours take csrc/zpconv_mfma2.hip, the others the first kernel
-    for (b, p, q, a, k, ann, c) in ((1, 1, 5, 60, 24, 64, 64), (2, 5, 9, 60, 24, 16, 80), (1, 11, 3, 28, 24, 32, 16),
-                                  (1, 1, 1, 4, 24, 4, 16), (3, 3, 5, 60, 24, 12, 16),       # scratch chunks far from 256-byte multiples
-                                  # csrc/zpconv_mfma2.hip (64 / 128 neighbours): runs of 8 + 8 + 3 points with a partial second
-                                  # channel slice; 28 anchors (a wave without anchors) at 128 neighbours; 17 kernel points
-                                  (2, 19, 40, 60, 24, 64, 80), (1, 9, 30, 28, 24, 128, 16), (2, 8, 50, 60, 17, 64, 64)):
-        idx = np.broadcast_to(rng.integers(0, q, (b, p, 1, 1, ann)), (b, p, a, k, ann)).astype(np.int32).copy()
-        if p == 5:
-            idx[:] = 2                                          # all entries reference support point 2
-        w = rng.random((b, p, a, k, ann)).astype(np.float32)
-        feats = rng.standard_normal((b, c, q, a)).astype(np.float32)
-        out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
-        ref = native.inter_zpconv_forward(idx, w, feats)
-        assert rel_err(out, ref) < 2e-6, (b, p, q, a, k, ann, c)
-        g = rng.standard_normal(ref.shape).astype(np.float32)
-        got = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q).cpu().numpy()
-        assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 1e-5, (b, p, q, a, k, ann, c)
+    for which_fwd in (1, 2):       # 2: 64 / 128 neighbours take csrc/zpconv_mfma2.hip (the others the first kernel)
+        _h.lib.eap_inter_zpconv_fwd_kernel(which_fwd)
+        for (b, p, q, a, k, ann, c) in ((1, 1, 5, 60, 24, 64, 64), (2, 5, 9, 60, 24, 16, 80), (1, 11, 3, 28, 24, 32, 16),
+                                      (1, 1, 1, 4, 24, 4, 16), (3, 3, 5, 60, 24, 12, 16),       # scratch chunks far from 256-byte multiples
+                                      # csrc/zpconv_mfma2.hip (64 / 128 neighbours): runs of 8 + 8 + 3 points with a partial second
+                                      # channel slice; 28 anchors (a wave without anchors) at 128 neighbours; 17 kernel points
+                                      (2, 19, 40, 60, 24, 64, 80), (1, 9, 30, 28, 24, 128, 16), (2, 8, 50, 60, 17, 64, 64)):
+            idx = np.broadcast_to(rng.integers(0, q, (b, p, 1, 1, ann)), (b, p, a, k, ann)).astype(np.int32).copy()
+            if p == 5:
+                idx[:] = 2                                          # all entries reference support point 2
+            w = rng.random((b, p, a, k, ann)).astype(np.float32)
+            feats = rng.standard_normal((b, c, q, a)).astype(np.float32)
+            out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
+            ref = native.inter_zpconv_forward(idx, w, feats)
+            assert rel_err(out, ref) < 2e-6, (b, p, q, a, k, ann, c)
+            g = rng.standard_normal(ref.shape).astype(np.float32)
+            got = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q).cpu().numpy()
+            assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 1e-5, (b, p, q, a, k, ann, c)
     _h.lib.eap_inter_zpconv_fwd_kernel(1)
     # the two matrix kernels against each other at a benchmark-like shape, and a batch that mixes a broadcast-index cloud
     # with an arbitrary 5-D index (served by csrc/zpconv_rows.hip)
