@@ -6,36 +6,40 @@ import chamfer
 
 
 class ChamferFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, xyz1, xyz2):
-        xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
-        dist1, dist2, idx1, idx2 = chamfer.forward(xyz1, xyz2)
-        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
-        return dist1, dist2
+    """(a [B,N,3], b [B,M,3]) -> (squared distance of every a-point to its nearest b-point [B,N], and the converse [B,M]);
+    the nearest-neighbour indices are kept for the backward (csrc/chamfer.hip)."""
 
     @staticmethod
-    def backward(ctx, grad_dist1, grad_dist2):
-        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-        grad_xyz1, grad_xyz2 = chamfer.backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
-        return grad_xyz1, grad_xyz2
+    def forward(ctx, xyz1, xyz2):
+        a, b = xyz1.contiguous(), xyz2.contiguous()
+        d_ab, d_ba, nearest_ab, nearest_ba = chamfer.forward(a, b)
+        ctx.save_for_backward(a, b, nearest_ab, nearest_ba)
+        return d_ab, d_ba
+
+    @staticmethod
+    def backward(ctx, g_ab, g_ba):
+        a, b, nearest_ab, nearest_ba = ctx.saved_tensors
+        return tuple(chamfer.backward(a, b, nearest_ab, nearest_ba, g_ab, g_ba))
 
 
 class ChamferDistance(torch.nn.Module):
+    """mean(d_ab) + mean(d_ba) (or the two raw distance maps).  ignore_zeros: for a single pair of clouds, points whose
+    coordinates sum to zero (padding) are dropped first, as the reference does."""
+
     def __init__(self, ignore_zeros=False):
-        super(ChamferDistance, self).__init__()
+        super().__init__()
         self.ignore_zeros = ignore_zeros
 
+    @staticmethod
+    def _without_padding(cloud):
+        keep = cloud.sum(dim=2).ne(0)                  # [1, n]
+        return cloud[keep].unsqueeze(0)
+
     def forward(self, xyz1, xyz2, return_raw=False):
-        batch_size = xyz1.size(0)
-        if batch_size == 1 and self.ignore_zeros:
-            non_zeros1 = torch.sum(xyz1, dim=2).ne(0)
-            non_zeros2 = torch.sum(xyz2, dim=2).ne(0)
-            xyz1 = xyz1[non_zeros1].unsqueeze(dim=0)
-            xyz2 = xyz2[non_zeros2].unsqueeze(dim=0)
-        dist1, dist2 = ChamferFunction.apply(xyz1, xyz2)
-        if return_raw:
-            return dist1, dist2
-        return torch.mean(dist1) + torch.mean(dist2)
+        if self.ignore_zeros and xyz1.size(0) == 1:
+            xyz1, xyz2 = self._without_padding(xyz1), self._without_padding(xyz2)
+        d_ab, d_ba = ChamferFunction.apply(xyz1, xyz2)
+        return (d_ab, d_ba) if return_raw else d_ab.mean() + d_ba.mean()
 
 
 MASKED_DISTANCE = 99999.0     # the constant the reference writes into masked entries of the distance tensor

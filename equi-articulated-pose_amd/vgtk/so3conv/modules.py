@@ -13,21 +13,35 @@ from . import functional as L
 KERNEL_CONDENSE_RATIO = 0.7
 
 
+def _kernel_points(radius, kernel_size):
+    """The spherical kernel-point set of a layer, scaled to KERNEL_CONDENSE_RATIO of its ball radius."""
+    return L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+
+
+def _const(module, **arrays):
+    """numpy constants as (contiguous) buffers of `module` under the reference's names."""
+    for name, value in arrays.items():
+        module.register_buffer(name, torch.from_numpy(np.ascontiguousarray(value)))
+
+
+def _attrs(module, **values):
+    """Plain attributes the reference classes expose (read by model code and by repr / checkpoints tooling)."""
+    for name, value in values.items():
+        setattr(module, name, value)
+
+
 class BasicSO3Conv(nn.Module):
     """[b, c1, k, p, a] -> [b, c2, p, a]  (modules.py:L21-55): W [c2, c1*k], no bias,
     xavier-normal with relu gain."""
 
     def __init__(self, dim_in, dim_out, kernel_size, debug=False):
-        super(BasicSO3Conv, self).__init__()
-        self.dim_in = dim_in
-        self.dim_out = dim_out
-        self.kernel_size = kernel_size
+        super().__init__()
+        _attrs(self, dim_in=dim_in, dim_out=dim_out, kernel_size=kernel_size)
         if debug:
             self.register_buffer('W', torch.ones(dim_out, dim_in * kernel_size))
         else:
-            W = torch.empty(dim_out, dim_in, kernel_size)
-            nn.init.xavier_normal_(W, gain=nn.init.calculate_gain('relu'))
-            self.register_parameter('W', nn.Parameter(W.view(dim_out, dim_in * kernel_size)))
+            init = nn.init.xavier_normal_(torch.empty(dim_out, dim_in, kernel_size), gain=nn.init.calculate_gain('relu'))
+            self.W = nn.Parameter(init.view(dim_out, dim_in * kernel_size))
 
     def forward(self, x):
         bs, np_, na = x.shape[0], x.shape[3], x.shape[4]
@@ -40,27 +54,21 @@ class KernelPropagation(nn.Module):
     centres (native initial_anchor_query, csrc/grouping.hip) -> BasicSO3Conv over the kernel axis."""
 
     def __init__(self, dim_in, dim_out, n_center, kernel_size, radius, sigma, kanchor=60):
-        super(KernelPropagation, self).__init__()
-        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
+        super().__init__()
         anchors = L.get_anchors(kanchor)
-        kernels = np.transpose(anchors @ kernels.T, (2, 0, 1))          # [ks, na, 3]
-        self.radius = radius
-        self.sigma = sigma
-        self.n_center = n_center
-        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
-        self.register_buffer('kernels', torch.from_numpy(np.ascontiguousarray(kernels)))
-        self.basic_conv = BasicSO3Conv(dim_in, dim_out, kernels.shape[0])
+        rotated = np.transpose(anchors @ _kernel_points(radius, kernel_size).T, (2, 0, 1))          # [ks, na, 3]
+        _attrs(self, radius=radius, sigma=sigma, n_center=n_center)
+        _const(self, anchors=anchors, kernels=rotated)
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, rotated.shape[0])
 
     def _subsample(self, clouds):
-        idx, sample_xyz = pctk.furthest_sample(clouds, self.n_center, False)
-        return sample_xyz
+        return pctk.furthest_sample(clouds, self.n_center, False)[1]
 
     def forward(self, frag, clouds):
         """frag [m,3], clouds [b,3,n] -> SphericalPointCloud(centers [b,3,nc], feats [b,c_out,nc,na])."""
         centers = clouds if clouds.shape[2] == self.n_center else self._subsample(clouds)
-        wts, nnctn = L.initial_anchor_query(frag, centers, self.kernels, self.radius, self.sigma)
-        wts = wts / (nnctn + 1.0)
-        feats = self.basic_conv(wts.unsqueeze(1))
+        weights, hits = L.initial_anchor_query(frag, centers, self.kernels, self.radius, self.sigma)
+        feats = self.basic_conv((weights / (hits + 1.0)).unsqueeze(1))
         return SphericalPointCloud(centers, feats, self.anchors)
 
 
@@ -69,21 +77,12 @@ class InterSO3Conv(nn.Module):
 
     def __init__(self, dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
                  lazy_sample=True, pooling=None, kanchor=60):
-        super(InterSO3Conv, self).__init__()
-        kernels = L.get_sphereical_kernel_points_from_ply(KERNEL_CONDENSE_RATIO * radius, kernel_size)
-        anchors = L.get_anchors(kanchor)
-        self.dim_in = dim_in
-        self.dim_out = dim_out
-        self.kernel_size = kernels.shape[0]
-        self.stride = stride
-        self.radius = radius
-        self.sigma = sigma
-        self.n_neighbor = n_neighbor
-        self.lazy_sample = lazy_sample
-        self.pooling = pooling
-        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
-        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
-        self.register_buffer('kernels', torch.from_numpy(kernels))
+        super().__init__()
+        points = _kernel_points(radius, kernel_size)
+        _attrs(self, dim_in=dim_in, dim_out=dim_out, kernel_size=points.shape[0], stride=stride, radius=radius, sigma=sigma,
+               n_neighbor=n_neighbor, lazy_sample=lazy_sample, pooling=pooling)
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, points.shape[0])
+        _const(self, anchors=L.get_anchors(kanchor), kernels=points)
 
     def forward(self, x, inter_idx=None, inter_w=None):
         if inter_idx is None and self.stride == 1:
@@ -94,12 +93,10 @@ class InterSO3Conv(nn.Module):
                                                               self.radius, self.sigma, False)
             sample_idx = torch.arange(xyz.shape[2], dtype=torch.long, device=xyz.device).unsqueeze(0).repeat(xyz.shape[0], 1)
             return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, feats, self.anchors)
-        inter_idx, inter_w, xyz, feats, sample_idx = \
-            L.inter_so3conv_grouping(x.xyz, x.feats, self.stride, self.n_neighbor, self.anchors,
-                                     self.kernels, self.radius, self.sigma, inter_idx, inter_w,
-                                     self.lazy_sample, pooling=self.pooling)
-        feats = self.basic_conv(feats)
-        return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, feats, self.anchors)
+        inter_idx, inter_w, xyz, grouped, sample_idx = L.inter_so3conv_grouping(
+            x.xyz, x.feats, self.stride, self.n_neighbor, self.anchors, self.kernels, self.radius, self.sigma, inter_idx, inter_w,
+            self.lazy_sample, pooling=self.pooling)
+        return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, self.basic_conv(grouped), self.anchors)
 
 
 class InterSO3PoseConv(InterSO3Conv):
@@ -112,8 +109,8 @@ class InterSO3PoseConv(InterSO3Conv):
                  use_art_mode=False):
         if use_2d or use_art_mode:
             raise NotImplementedError('use_2d / use_art_mode grouping variants are outside the accelerated path')
-        super(InterSO3PoseConv, self).__init__(dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
-                                               lazy_sample=lazy_sample, pooling=pooling, kanchor=kanchor)
+        super().__init__(dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor, lazy_sample=lazy_sample, pooling=pooling,
+                         kanchor=kanchor)
         self.permute_modes, self.use_2d, self.use_art_mode = permute_modes, use_2d, use_art_mode
 
     def forward(self, x, inter_idx=None, inter_w=None, seg=None):
@@ -141,15 +138,12 @@ class IntraSO3Conv(nn.Module):
     only valid for kanchor = 60."""
 
     def __init__(self, dim_in, dim_out):
-        super(IntraSO3Conv, self).__init__()
-        anchors = L.get_anchors()
-        intra_idx = L.get_intra_idx()
-        self.dim_in = dim_in
-        self.dim_out = dim_out
-        self.kernel_size = intra_idx.shape[1]
-        self.basic_conv = BasicSO3Conv(dim_in, dim_out, self.kernel_size)
-        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
-        self.register_buffer('intra_idx', torch.from_numpy(intra_idx).long())
+        super().__init__()
+        taps = L.get_intra_idx()                                              # [60, 12] neighbouring anchors of every anchor
+        _attrs(self, dim_in=dim_in, dim_out=dim_out, kernel_size=taps.shape[1])
+        self.basic_conv = BasicSO3Conv(dim_in, dim_out, taps.shape[1])
+        _const(self, anchors=L.get_anchors())
+        self.register_buffer('intra_idx', torch.from_numpy(taps).long())
 
     def forward(self, x):
         feats = x.feats
@@ -167,9 +161,8 @@ class IntraSO3Conv2D(IntraSO3Conv):
     buffers, the 12-tap gather acts on the 60-axis."""
 
     def forward(self, x):
-        feats = L.intra_so3conv_grouping_2D(self.intra_idx, x.feats)
-        feats = self.basic_conv(feats)
-        return SphericalPointCloud(x.xyz, feats, self.anchors)
+        out = self.basic_conv(L.intra_so3conv_grouping_2D(self.intra_idx, x.feats))
+        return SphericalPointCloud(x.xyz, out, self.anchors)
 
 
 class PointnetSO3Conv(nn.Module):
@@ -177,13 +170,10 @@ class PointnetSO3Conv(nn.Module):
     then max over points.  Dense torch layers (out of the HIP scope, SURVEY.md section 2 #12)."""
 
     def __init__(self, dim_in, dim_out, kanchor=60, return_raw=False):
-        super(PointnetSO3Conv, self).__init__()
-        anchors = L.get_anchors(kanchor)
-        self.dim_in = dim_in + 3
-        self.dim_out = dim_out
-        self.return_raw = return_raw
-        self.embed = nn.Conv2d(self.dim_in, self.dim_out, 1)
-        self.register_buffer('anchors', torch.from_numpy(np.ascontiguousarray(anchors)))
+        super().__init__()
+        _attrs(self, dim_in=dim_in + 3, dim_out=dim_out, return_raw=return_raw)      # + 3: the coordinates in the anchor's frame
+        self.embed = nn.Conv2d(dim_in + 3, dim_out, 1)
+        _const(self, anchors=L.get_anchors(kanchor))
 
     def forward(self, x):
         """x.xyz [b,3,n], x.feats [b,c,n,na] -> [b,dim_out,na] (or the per-point map with return_raw): every anchor sees
@@ -202,4 +192,4 @@ class PointnetSO3PoseConv(PointnetSO3Conv):
     """modules.py:L415-449 (same computation, always max-pooled)."""
 
     def __init__(self, dim_in, dim_out, kanchor=60):
-        super(PointnetSO3PoseConv, self).__init__(dim_in, dim_out, kanchor, return_raw=False)
+        super().__init__(dim_in, dim_out, kanchor, return_raw=False)
