@@ -119,10 +119,9 @@ class Config3Model(nn.Module):
         labels = scores.argmax(-1)
         anchors = self.backbone.convs[0].anchors
         recon, slot_R, slot_T, centre_reg = [], [], [], 0.0
-        for s_, head in enumerate(self.slot_heads):
-            member = (labels == s_)
-            member = member | (member.sum(1, keepdim=True) == 0)               # an empty slot falls back to the whole cloud
-            out = sptk.pose_head_over_subsets(head, feats, xyz, member, anchors)
+        # every slot's member points compacted (an empty slot falls back to the whole cloud): the heads work on P points per
+        # cloud in total, not on slots x P
+        for s_, out in enumerate(sptk.pose_head_over_slot_groups(self.slot_heads, feats, xyz, labels, anchors)):
             ang = (torch.sigmoid(out['R']) * np.pi * ROT_ANGLE_FACTOR).reshape(b, NA)
             Rm = sptk.compute_rotation_matrix_from_angle(anchors, ang, defined_axis=out['axis'].transpose(1, 2))   # [B,A,3,3]
             T = out['T'].transpose(1, 2)                                        # [B,A,3]

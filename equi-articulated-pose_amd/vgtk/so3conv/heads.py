@@ -588,3 +588,65 @@ def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
     if head.num_heads == 1:
         output = {k: (v.squeeze(1) if v is not None else None) for k, v in output.items()}
     return output
+
+
+class _GatherPoints(torch.autograd.Function):
+    """feats [b,c,n,a], rows int32 [b,m] (distinct point indices per cloud, -1 = padding) -> [b,c,m,a]; the backward scatters
+    the gradient back to the named points (csrc/inv_lists.hip: eap_rows_gather_f32 / eap_rows_scatter_f32)."""
+
+    @staticmethod
+    def forward(ctx, feats, rows):
+        feats = feats.contiguous()
+        ctx.save_for_backward(rows)
+        ctx.n = feats.shape[2]
+        return _hip.rows_gather(feats, rows, rows.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, = ctx.saved_tensors
+        g = g.contiguous()
+        return _hip.rows_scatter(g, rows, ctx.n), None
+
+
+def slot_point_groups(labels, n_slots, multiple=32):
+    """labels [B,P] (slot of every point) -> per slot the member points of every cloud, compacted: a list of int32 [B, cap_s]
+    (ascending point indices, -1 padded), cap_s = the largest membership of the slot over the clouds rounded up to `multiple`
+    (32 points x 60 anchors = whole 128-column tiles for the contraction kernels).  A slot nobody chose in a cloud falls back to
+    the whole cloud, as the model does.  ONE device -> host read (the capacities) for all slots."""
+    b, p = labels.shape
+    member = labels.unsqueeze(0) == torch.arange(n_slots, device=labels.device).view(n_slots, 1, 1)        # [S,B,P]
+    member = member | (member.sum(2, keepdim=True) == 0)
+    counts = member.sum(2)                                                                                  # [S,B]
+    caps = counts.max(1).values.tolist()
+    order = torch.sort(member.to(torch.int8), dim=2, descending=True, stable=True).indices                 # members first, ascending
+    groups = []
+    for s_, cap in enumerate(caps):
+        cap = min(-(-int(cap) // multiple) * multiple, -(-p // multiple) * multiple)
+        rows = order[s_, :, :min(cap, p)].to(torch.int32)
+        if cap > p:
+            rows = torch.cat([rows, rows.new_full((b, cap - p), -1)], 1)
+        live = torch.arange(cap, device=labels.device).view(1, cap) < counts[s_].view(b, 1)
+        groups.append(torch.where(live, rows, rows.new_full((), -1)).contiguous())
+    return groups
+
+
+def pose_head_over_slot_groups(heads, feats, xyz, labels, anchors, use_offset=True):
+    """The model's loop `for slot: for cloud: head_slot(points of the slot in the cloud)` (...pn_38_multi_stage.py:L706-830) with
+    the work of P points per cloud, not slots x P: every slot's member points are compacted into their own [B,C,cap_s,A]
+    tensor (slot_point_groups + one gather pass) and run through pose_head_over_subsets, whose per-cloud statistics and pooling
+    already ignore the padding.  heads: one module per slot; -> list of the heads' output dictionaries."""
+    outs = []
+    p = feats.shape[2]
+    for s_, (head, rows) in enumerate(zip(heads, slot_point_groups(labels, len(heads)))):
+        if rows.shape[1] * 10 >= p * 9:
+            # some cloud gives (nearly) all of its points to this slot -- or none, which falls back to the whole cloud: nothing to
+            # save, so no compacted copy of the feature map either: the masked form on the full clouds
+            member = labels == s_
+            outs.append(pose_head_over_subsets(head, feats, xyz, member | (member.sum(1, keepdim=True) == 0), anchors, use_offset))
+            continue
+        member = rows >= 0
+        sel = rows.clamp(min=0).long()
+        sub_feats = _GatherPoints.apply(feats, rows)
+        sub_xyz = torch.gather(xyz, 2, sel.unsqueeze(1).expand(-1, xyz.shape[1], -1)).contiguous()
+        outs.append(pose_head_over_subsets(head, sub_feats, sub_xyz, member, anchors, use_offset))
+    return outs

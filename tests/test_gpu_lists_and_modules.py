@@ -863,3 +863,56 @@ def test_narrow_contraction_equals_the_gemm_path(dev, b, o, c, n):
         assert rel_err(a.cpu().numpy(), bb.cpu().numpy()) < 5e-6, name
     y = L.so3_contract(W, x)
     assert torch.equal(y, res[0][0]), 'so3_contract must take the streaming kernels for <= 4 output channels'
+
+
+def test_pose_heads_over_slot_groups_equal_the_masked_form(dev):
+    """vgtk.so3conv.pose_head_over_slot_groups (every slot's member points compacted: work of P points per cloud) against
+    pose_head_over_subsets on the full clouds with the membership mask (slots x P): outputs, gradients of the feature map and
+    of the head parameters, running statistics; one cloud leaves a slot empty (fallback to the whole cloud), capacities are
+    padded past the cloud size."""
+    import copy
+    import vgtk.so3conv as sptk
+    import vgtk.so3conv.functional as L
+    torch.manual_seed(21)
+    B, C, N, A, S = 3, 16, 70, 60, 2
+    heads = [sptk.SO3OutBlockRTWithMaskSep({'dim_in': C, 'mlp': [32, 32], 'kanchor': A, 'temperature': 3.0}, norm=1, pooling_method='mean',
+                                           pred_axis=True, pred_central_points=True).to(dev) for _ in range(S)]
+    feats = torch.randn(B, C, N, A, device=dev)
+    xyz = torch.randn(B, 3, N, device=dev) * 0.3
+    labels = torch.randint(0, S, (B, N), device=dev)
+    labels[1] = 0                                                     # cloud 1: nobody chose slot 1
+    anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors(A))).to(dev)
+    groups = sptk.slot_point_groups(labels, S)
+    assert [tuple(g.shape) for g in groups] == [(B, 96), (B, 96)] and all(g.dtype == torch.int32 for g in groups)
+    for s_, g in enumerate(groups):
+        for b in range(B):
+            want = (labels[b] == s_).nonzero().squeeze(1)
+            want = want if want.numel() else torch.arange(N, device=dev)
+            got = g[b][g[b] >= 0].long()
+            assert torch.equal(got, want) and (g[b][want.numel():] == -1).all()
+    ref_heads, new_heads = copy.deepcopy(heads), copy.deepcopy(heads)
+    f_ref, f_new = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    outs_ref = []
+    for s_, head in enumerate(ref_heads):
+        member = labels == s_
+        member = member | (member.sum(1, keepdim=True) == 0)
+        outs_ref.append(sptk.pose_head_over_subsets(head, f_ref, xyz, member, anchors))
+    outs_new = sptk.pose_head_over_slot_groups(new_heads, f_new, xyz, labels, anchors)
+    keys = ('R', 'T', 'axis', 'central_points')
+    gen = torch.Generator().manual_seed(3)
+    loss_ref = loss_new = 0.0
+    for o_r, o_n in zip(outs_ref, outs_new):
+        for k in keys:
+            assert rel_err(o_n[k].detach().cpu().numpy(), o_r[k].detach().cpu().numpy()) < 1e-5, k
+            probe = torch.randn(o_r[k].shape, generator=gen).to(dev)
+            loss_ref = loss_ref + (o_r[k] * probe).sum()
+            loss_new = loss_new + (o_n[k] * probe).sum()
+    loss_ref.backward(); loss_new.backward()
+    assert rel_err(f_new.grad.cpu().numpy(), f_ref.grad.cpu().numpy()) < 2e-5
+    for hr, hn in zip(ref_heads, new_heads):
+        for (k, v), (_, w) in zip(hr.named_parameters(), hn.named_parameters()):
+            if v.grad is not None and float(v.grad.abs().max()) > 0:
+                assert rel_err(w.grad.cpu().numpy(), v.grad.cpu().numpy()) < 1e-4, k
+        for (k, v), (_, w) in zip(hr.state_dict().items(), hn.state_dict().items()):
+            if 'running' in k:
+                assert rel_err(w.cpu().numpy(), v.cpu().numpy()) < 1e-5, k
