@@ -213,3 +213,73 @@ def test_chamfer_config3_shape(dev):
     (u * T(g1).to(dev)).sum().add((v * T(g2).to(dev)).sum()).backward()
     r1, r2 = native.chamfer_backward(a, b, i1, i2, g1, g2)
     assert rel_err(t1.grad.cpu().numpy(), r1) < 1e-5 and rel_err(t2.grad.cpu().numpy(), r2) < 1e-5
+
+
+def test_bench_configuration_properties(dev):
+    """The benchmark configuration ITSELF (BASELINE config 1 at scale: 8 x 4096-point clouds, the 3-block inter backbone
+    1 -> 64 -> 128 -> 512 with its fused BatchNorm + leaky_relu epilogues, exactly bench.py's model) through size-independent
+    properties -- the oracle cannot run this size:
+      * equivariance: rotating every cloud by anchor A_j permutes the anchor axis of the final feature map
+        (out'[..., a] = out[..., pi(a)], A_pi(a) = A_j^T A_a), through all three layers and their batch statistics;
+      * the backward against central differences of the forward: directional derivatives of a random linear functional of
+        the output along random directions in the first and the last layer's weights (float64 accumulation of the loss);
+      * run-to-run bit reproducibility of forward and gradients (no atomics on the path)."""
+    import bench
+    import synth_clouds
+    import vgtk.so3conv.functional as L
+    from vgtk.functional import anchor_group_tables
+    B, P = 8, 4096
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, B, P)
+    xyz, pose = T(xyz_np).to(dev), T(pose_np).to(dev)
+    torch.manual_seed(2913)
+    model = bench.Backbone(P).to(dev)
+    anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors()))
+    mult, inv = anchor_group_tables(anchors.numpy())
+
+    with torch.no_grad():
+        base = model(xyz, pose)
+        assert tuple(base.shape) == (B, 512, P, 60) and torch.isfinite(base).all()
+        j = 17
+        rot = torch.einsum('ij,bjn->bin', anchors[j].to(dev), xyz).contiguous()
+        moved = model(rot, pose)
+        pi = torch.from_numpy(mult[inv[j]].astype(np.int64)).to(dev)
+        scale = float(base.abs().max())
+        worst = 0.0
+        for b in range(B):                       # cloud by cloud: the permuted copy of the 4 GB map is never materialised
+            worst = max(worst, float((moved[b] - base[b][..., pi]).abs().max()))
+        assert worst < 1e-4 * scale, (worst, scale)
+        del moved, rot
+
+    gen = torch.Generator().manual_seed(5)
+    probe = (torch.randn(B, 512, 1, 60, generator=gen) / (512 * 60)).to(dev)      # one weight per (cloud, channel, anchor), broadcast over points
+
+    def loss_of():
+        out = model(xyz, pose)
+        return (out.double() * probe.double()).sum() / P, out
+
+    grads = []
+    for trial in range(2):
+        model.zero_grad(set_to_none=True)
+        loss, out = loss_of()
+        loss.backward()
+        grads.append([None if p.grad is None else p.grad.clone() for p in model.parameters()] + [out.detach().clone() if trial == 0 else out.detach()])
+        del out
+    for a, b in zip(grads[0], grads[1]):          # (the stand-in pose head's layer is not reached by this functional: no gradient)
+        assert (a is None and b is None) or torch.equal(a, b), 'forward / backward of the benchmark configuration is not bit-reproducible'
+    del grads[1]
+    params = dict(model.named_parameters())
+    for name in ('convs.0.basic_conv.W', 'convs.2.basic_conv.W'):
+        w = params[name]
+        g = grads[0][list(params).index(name)]
+        d = torch.randn(w.shape, generator=gen).to(dev)
+        d = d / d.norm() * w.detach().norm()
+        analytic = float((g.double() * d.double()).sum())
+        eps = 2e-3
+        vals = []
+        with torch.no_grad():
+            for sgn in (1.0, -1.0):
+                w.add_(d, alpha=sgn * eps)
+                vals.append(float(loss_of()[0]))
+                w.add_(d, alpha=-sgn * eps)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(fd - analytic) < 3e-2 * max(abs(analytic), 1e-12), (name, fd, analytic)
