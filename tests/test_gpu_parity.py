@@ -883,3 +883,36 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
     # transposed layout holds the same numbers: [b, p*na + a, c*ks + k]
     xt = out[2][1].view(b, p * na, c * ks)
     assert torch.equal(xt.view(b, p, na, c, ks).permute(0, 3, 4, 1, 2), out[2][0])
+
+
+@pytest.mark.gpu
+def test_native_zpconv_at_the_bench_shape(dev):
+    """vgtk.cuda.zpconv.inter_zpconv_forward / _backward at the shape bench.py's `zpconv_roofline` times (8 x 4096 points,
+    C = 64, 60 anchors, 24 kernel points, 64 neighbours: 12 GB of indices, 12 GB of weights) -- the oracle cannot run this
+    size, so: a slab of points of two clouds against the C oracle (every output row depends on its own point's rows only),
+    the adjoint identity <fwd(f), g> = <f, bwd(g)> over the whole batch (forward and backward are different kernels), and
+    run-to-run bit equality of both."""
+    import synth_clouds
+    import vgtk.cuda.grouping as G
+    import vgtk.cuda.zpconv as Z
+    B, P, C, A, K, NN = 8, 4096, 64, 60, 24, 64
+    xyz = T(synth_clouds.laptop_batch(0, B, P)[0]).to(dev)
+    ball = G.ball_query(xyz, xyz, synth_clouds.backbone_layers(P)[1][2], NN)
+    idx = ball[:, :, None, None, :].expand(B, P, A, K, NN).contiguous()
+    gen = torch.Generator(device=dev).manual_seed(4)
+    w = torch.rand(B, P, A, K, NN, device=dev, generator=gen)
+    feats = torch.randn(B, C, P, A, device=dev, generator=gen)
+    out = Z.inter_zpconv_forward(idx, w, feats)
+    assert tuple(out.shape) == (B, C, K, P, A)
+    assert torch.equal(out, Z.inter_zpconv_forward(idx, w, feats))
+    for b, p0 in ((0, 0), (5, 2011)):
+        sl = slice(p0, p0 + 48)
+        ref = native.inter_zpconv_forward(idx[b:b + 1, sl].cpu().numpy(), w[b:b + 1, sl].cpu().numpy(), feats[b:b + 1].cpu().numpy())
+        assert rel_err(out[b:b + 1, :, :, sl].cpu().numpy(), ref) < 2e-6, (b, p0)
+    g = torch.randn(B, C, K, P, A, device=dev, generator=gen)
+    gf = Z.inter_zpconv_backward(idx, w, g, P)
+    assert tuple(gf.shape) == (B, C, P, A)
+    assert torch.equal(gf, Z.inter_zpconv_backward(idx, w, g, P))
+    lhs = float((out.double() * g.double()).sum())
+    rhs = float((feats.double() * gf.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), float(out.double().abs().sum()) * 1e-3), (lhs, rhs)
