@@ -139,6 +139,66 @@ __global__ __launch_bounds__(256) void slot_mean_bwd_kernel(int c, int n, int na
     }
 }
 
+// masked max over the points, the pose head's 'max' pooling on a point subset (`(x * mask).max(2)`: SO3OutBlockRWithMask /
+// SO3OutBlockRTWithMaskSep with pooling_method = 'max', SPConvNets/models/model_utils.py:L79-80, L470-484): out[b,c,a] = max_p
+// mask[b,p] * x[b,c,p,a] and the point that attains it (the lowest index among equals: deterministic).  One pass over x.
+// block = (channel, cloud); lane = (point group of 4, anchor quad); groups and waves are folded through LDS in a fixed order
+__global__ __launch_bounds__(256) void masked_max_fwd_kernel(int c, int n, int na, const float *__restrict__ x, const float *__restrict__ m,
+                                                             float *__restrict__ out, int32_t *__restrict__ arg) {
+    __shared__ float4 s_val[16][16];
+    __shared__ int4 s_idx[16][16];
+    const int ci = blockIdx.x, bi = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, quad = lane & 15, nq = na >> 2;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int4 at = make_int4(0, 0, 0, 0);
+    const float *xp = x + ((size_t)bi * c + ci) * n * na + 4 * min(quad, nq - 1);
+    const float *mp = m + (size_t)bi * n;
+    for (int p0 = wave * 4 + grp; p0 < n; p0 += 16) {                      // ascending within a lane: ">" keeps the first of equals
+        const float4 v = *reinterpret_cast<const float4 *>(xp + (size_t)p0 * na);
+        const float w = mp[p0];
+        const float a0 = w * v.x, a1 = w * v.y, a2 = w * v.z, a3 = w * v.w;
+        if (a0 > best.x) { best.x = a0; at.x = p0; }
+        if (a1 > best.y) { best.y = a1; at.y = p0; }
+        if (a2 > best.z) { best.z = a2; at.z = p0; }
+        if (a3 > best.w) { best.w = a3; at.w = p0; }
+    }
+    s_val[wave * 4 + grp][quad] = best;
+    s_idx[wave * 4 + grp][quad] = at;
+    __syncthreads();
+    if (threadIdx.x < nq) {
+        const int q = threadIdx.x;
+        float4 bv = s_val[0][q];
+        int4 bi4 = s_idx[0][q];
+        for (int j = 1; j < 16; ++j) {
+            const float4 u = s_val[j][q];
+            const int4 k = s_idx[j][q];
+            if (u.x > bv.x || (u.x == bv.x && k.x < bi4.x)) { bv.x = u.x; bi4.x = k.x; }
+            if (u.y > bv.y || (u.y == bv.y && k.y < bi4.y)) { bv.y = u.y; bi4.y = k.y; }
+            if (u.z > bv.z || (u.z == bv.z && k.z < bi4.z)) { bv.z = u.z; bi4.z = k.z; }
+            if (u.w > bv.w || (u.w == bv.w && k.w < bi4.w)) { bv.w = u.w; bi4.w = k.w; }
+        }
+        *reinterpret_cast<float4 *>(out + ((size_t)bi * c + ci) * na + 4 * q) = bv;
+        *reinterpret_cast<int4 *>(arg + ((size_t)bi * c + ci) * na + 4 * q) = bi4;
+    }
+}
+
+// dx[b,c,p,a] = (p == arg[b,c,a]) * mask[b,p] * g[b,c,a], written for every point (no memset + scatter)
+__global__ __launch_bounds__(256) void masked_max_bwd_kernel(int c, int n, int na, const float *__restrict__ g, const int32_t *__restrict__ arg,
+                                                             const float *__restrict__ m, float *__restrict__ dx) {
+    const int ci = blockIdx.x, bi = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, quad = lane & 15, nq = na >> 2;
+    if (quad >= nq) return;
+    const float4 gv = *reinterpret_cast<const float4 *>(g + ((size_t)bi * c + ci) * na + 4 * quad);
+    const int4 at = *reinterpret_cast<const int4 *>(arg + ((size_t)bi * c + ci) * na + 4 * quad);
+    float *dp = dx + ((size_t)bi * c + ci) * n * na + 4 * quad;
+    const float *mp = m + (size_t)bi * n;
+    for (int p0 = wave * 4 + grp; p0 < n; p0 += 16) {
+        const float w = mp[p0];
+        *reinterpret_cast<float4 *>(dp + (size_t)p0 * na) =
+            make_float4(p0 == at.x ? w * gv.x : 0.f, p0 == at.y ? w * gv.y : 0.f, p0 == at.z ? w * gv.z : 0.f, p0 == at.w ? w * gv.w : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int eap_anchor_attn_pool_fwd_f32(int b, int c, int n, int na, float temperature, const float *x, const float *logits,
@@ -175,4 +235,21 @@ extern "C" int eap_slot_masked_mean_bwd_f32(int b, int ns, int c, int n, int na,
         return eap::bad_arg("slot_masked_mean: anchors must be a multiple of 4, at most 64; at most 8 slots; b <= 65535");
     hipLaunchKernelGGL(slot_mean_bwd_kernel, dim3(c, b), dim3(256), 0, eap::S(stream), c, n, na, ns, g, mask, inv_den, dx);
     return eap::check_launch("slot_masked_mean_bwd");
+}
+
+extern "C" int eap_masked_max_fwd_f32(int b, int c, int n, int na, const float *x, const float *mask, float *out, int32_t *arg,
+                                      eap_stream_t stream) {
+    if (b <= 0 || c <= 0) return 0;
+    if (n <= 0) return eap::bad_arg("masked_max: no points");
+    if (na <= 0 || na > 64 || (na & 3) != 0 || b > 65535) return eap::bad_arg("masked_max: anchors must be a multiple of 4, at most 64; b <= 65535");
+    hipLaunchKernelGGL(masked_max_fwd_kernel, dim3(c, b), dim3(256), 0, eap::S(stream), c, n, na, x, mask, out, arg);
+    return eap::check_launch("masked_max_fwd");
+}
+
+extern "C" int eap_masked_max_bwd_f32(int b, int c, int n, int na, const float *g, const int32_t *arg, const float *mask, float *dx,
+                                      eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (na <= 0 || na > 64 || (na & 3) != 0 || b > 65535) return eap::bad_arg("masked_max: anchors must be a multiple of 4, at most 64; b <= 65535");
+    hipLaunchKernelGGL(masked_max_bwd_kernel, dim3(c, b), dim3(256), 0, eap::S(stream), c, n, na, g, arg, mask, dx);
+    return eap::check_launch("masked_max_bwd");
 }

@@ -166,6 +166,38 @@ class _SlotMaskedMean(torch.autograd.Function):
         return dx, None
 
 
+class _MaskedMax(torch.autograd.Function):
+    """(x * mask).max(2) with its arg-max in one pass over x (csrc/heads.hip): x [b,c,n,a], mask [b,n] 0/1 -> [b,c,a]."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        x, mask = x.contiguous(), mask.contiguous()
+        b, c, n, na = x.shape
+        out = torch.empty(b, c, na, dtype=torch.float32, device=x.device)
+        arg = torch.empty(b, c, na, dtype=torch.int32, device=x.device)
+        _hip.call('eap_masked_max_fwd_f32', x, b, c, n, na, _hip._ptr(x), _hip._ptr(mask), _hip._ptr(out), _hip._ptr(arg))
+        ctx.save_for_backward(arg, mask)
+        ctx.dims = (b, c, n, na)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, mask = ctx.saved_tensors
+        b, c, n, na = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty(b, c, n, na, dtype=torch.float32, device=g.device)
+        _hip.call('eap_masked_max_bwd_f32', g, b, c, n, na, _hip._ptr(g), _hip._ptr(arg), _hip._ptr(mask), _hip._ptr(dx))
+        return dx, None
+
+
+def masked_max(x, mask):
+    """x [b,c,n,a], mask [b,n] (0/1, treated as data) -> [b,c,a] = (x * mask[:, None, :, None]).max(2)[0]: the pose heads' 'max'
+    pooling over a point subset without the masked copy of x."""
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise RuntimeError('masked_max: float32 device tensors only')
+    return _MaskedMax.apply(x, mask.to(torch.float32))
+
+
 def slot_masked_mean(x, mask):
     """x [b,c,n,a], mask [b,s,n] (hard or soft slot weights, treated as data) ->
     [b,s,c,a] = sum_n mask x / clamp(sum_n mask, 1e-8): the masked point averages the pose head takes slot by slot
@@ -551,8 +583,8 @@ def pose_head_over_subsets(head, feats, xyz, member, anchors, use_offset=True):
 
     def pool(f):
         if head.pooling_method == 'max':
-            return (f * m).max(2)[0]
-        return slot_masked_mean(f, mask.view(b, 1, n))[:, 0]               # [B, c, A]: one pass over f (csrc/heads.hip)
+            return masked_max(f, mask)                                     # [B, c, A]: one pass over f (csrc/heads.hip)
+        return slot_masked_mean(f, mask.view(b, 1, n))[:, 0]
 
     x_out = pool(_masked_unary_stack(feats, mask, head.linear, head.norm))                       # [B, c, A]
     shared = _masked_unary_stack(feats, mask, head.trans_linear, head.trans_norm)              # [B, c, P, A]

@@ -451,6 +451,13 @@ int eap_slot_masked_mean_fwd_f32(int b, int ns, int c, int n, int na, const floa
                                  const float *inv_den, float *out, eap_stream_t stream);
 int eap_slot_masked_mean_bwd_f32(int b, int ns, int c, int n, int na, const float *g, const float *mask,
                                  const float *inv_den, float *dx, eap_stream_t stream);
+/* The pose heads' 'max' pooling on a point subset, `(x * mask).max(2)` (SPConvNets/models/model_utils.py:L79-80, L470-484):
+ * out[b,c,a] = max_p mask[b,p] * x[b,c,p,a], arg[b,c,a] = the lowest point index attaining it (int32); one pass over x.
+ * Backward: dx[b,c,p,a] = (p == arg[b,c,a]) * mask[b,p] * g[b,c,a], written for every point. */
+int eap_masked_max_fwd_f32(int b, int c, int n, int na, const float *x, const float *mask, float *out, int32_t *arg,
+                           eap_stream_t stream);
+int eap_masked_max_bwd_f32(int b, int c, int n, int na, const float *g, const int32_t *arg, const float *mask, float *dx,
+                           eap_stream_t stream);
 
 #ifdef __cplusplus
 }

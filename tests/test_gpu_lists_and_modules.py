@@ -916,3 +916,31 @@ def test_pose_heads_over_slot_groups_equal_the_masked_form(dev):
         for (k, v), (_, w) in zip(hr.state_dict().items(), hn.state_dict().items()):
             if 'running' in k:
                 assert rel_err(w.cpu().numpy(), v.cpu().numpy()) < 1e-5, k
+
+
+@pytest.mark.parametrize('shape', [(3, 8, 40, 60), (2, 5, 700, 60), (1, 4, 1, 12), (2, 3, 17, 64)])
+def test_masked_max_equals_torch(dev, shape):
+    """vgtk.so3conv.masked_max (csrc/heads.hip) against (x * mask).max(2): values (non-members contribute their zeros, so a
+    subset of negative values pools to 0), arg-max gradient, a cloud with a single member."""
+    import vgtk.so3conv as sptk
+    torch.manual_seed(sum(shape))
+    B, C, N, A = shape
+    x = torch.randn(B, C, N, A, device=dev)
+    x[0, 0] = -x[0, 0].abs() - 0.1                                    # channel 0 of cloud 0: all negative
+    member = torch.rand(B, N, device=dev) > 0.5
+    member[:, 0] = True
+    if N > 2:
+        member[-1] = False; member[-1, N // 2] = True                  # one member only
+    m = member.float()
+    g = torch.randn(B, C, A, device=dev)
+    xr = x.clone().requires_grad_(True)
+    ref = (xr * m.view(B, 1, N, 1)).max(2)[0]
+    gr, = torch.autograd.grad(ref, [xr], g)
+    xn = x.clone().requires_grad_(True)
+    got = sptk.masked_max(xn, member)
+    gn, = torch.autograd.grad(got, [xn], g)
+    assert torch.equal(got, ref)
+    if not bool(member.all()):
+        assert float(got[0, 0].max()) == 0.0
+    # where the maximum is attained by a member the gradients agree; where it is one of the non-members' zeros both are zero
+    assert torch.equal(gn, gr) or rel_err(gn.cpu().numpy(), gr.cpu().numpy()) == 0.0
