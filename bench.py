@@ -151,24 +151,23 @@ class StandInLoss(torch.autograd.Function):
         return g_f, g_w, g_b, None
 
 
-CPU_BASELINE_MAX_THREADS = 16   # torch CPU ops of this path slow down beyond ~8-16 threads (measured on the 256-core GPU host)
+CPU_BASELINE_THREADS = 16   # torch CPU ops of this path slow down beyond ~8-16 threads (measured on the 256-core GPU host)
 
 
-def cpu_baseline(points, slab=64):
-    """Oracle (oracle/so3_ref.py) fwd+bwd of the 3 layers on a slab of `slab` query points of one
-    `points`-point cloud, scaled to the whole cloud.  Faithful = with the reference's 60x60
-    anchor-permutation search; `short_circuit` = search skipped (identity poses)."""
+def cpu_baseline(points, slab=32):
+    """Oracle (oracle/so3_ref.py) fwd+bwd of the 3 layers on a slab of `slab` query points of one `points`-point cloud,
+    scaled to the whole cloud, by BASELINE.md section 2's protocol: 1 warm-up + 3 timed runs (median), at 16 threads AND at
+    os.cpu_count() threads (both stated; `value` / `cores` = the faster of the two).  Faithful = with the reference's 60x60
+    anchor-permutation search; `short_circuit` = search skipped (identity poses), at the faster thread count."""
     import synth_clouds
     from oracle import so3_ref
-    threads = min(os.cpu_count() or 1, CPU_BASELINE_MAX_THREADS)
-    torch.set_num_threads(threads)
     consts = np.load(os.path.join(PKG, 'vgtk', 'data', 'anchors', 'constants.npz'))
     import vgtk.so3conv.functional as L
     anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors()))
     xyz, _, pose = synth_clouds.laptop_batch(0, 1, points)
     xyz, pose = torch.from_numpy(xyz), torch.from_numpy(pose)
-    out = {}
-    for label, skip in (('faithful', False), ('short_circuit', True)):
+
+    def one_run(skip):
         total = 0.0
         gen = torch.Generator().manual_seed(2913)
         for (c, o, r, s) in synth_clouds.backbone_layers(points):
@@ -182,7 +181,18 @@ def cpu_baseline(points, slab=64):
             y = so3_ref.basic_so3conv(W, res[3])
             y.square().mean().backward()
             total += time.perf_counter() - t0
-        out[label] = 1.0 / (total * points / slab)
+        return total
+
+    def protocol(threads, skip):
+        torch.set_num_threads(threads)
+        one_run(skip)                                   # warm-up
+        runs = sorted(one_run(skip) for _ in range(3))
+        return {'threads': threads, 'clouds_per_sec': 1.0 / (runs[1] * points / slab), 'runs_s': [round(r, 3) for r in runs]}
+
+    ncpu = os.cpu_count() or 1
+    faithful = [protocol(t, False) for t in sorted({min(ncpu, CPU_BASELINE_THREADS), ncpu})]
+    best = max(faithful, key=lambda d: d['clouds_per_sec'])
+    short = protocol(best['threads'], True)
     model = 'unknown'
     try:
         for ln in open('/proc/cpuinfo'):
@@ -191,11 +201,13 @@ def cpu_baseline(points, slab=64):
                 break
     except OSError:
         pass
-    return {'value': out['faithful'], 'unit': 'point-clouds/sec', 'cores': threads, 'kind': 'port',
-            'host_logical_cpus': os.cpu_count(), 'host_cpu_model': model,
+    return {'value': best['clouds_per_sec'], 'unit': 'point-clouds/sec', 'cores': best['threads'], 'kind': 'port',
+            'host_logical_cpus': ncpu, 'host_cpu_model': model,
+            'protocol': 'BASELINE.md section 2: 1 warm-up + 3 timed runs, median; torch.set_num_threads at each listed count',
+            'by_threads': faithful,
             'sample': f'oracle fwd+bwd of the 3 backbone layers on {slab} of {points} query points of 1 cloud, '
                       f'scaled x{points // slab}; includes the reference\'s 60x60 anchor-permutation search',
-            'value_perm_search_short_circuited': out['short_circuit']}
+            'value_perm_search_short_circuited': short['clouds_per_sec'], 'short_circuit_runs_s': short['runs_s']}
 
 
 def zpconv_roofline(dev, points, clouds=8, channels=64):
@@ -288,16 +300,23 @@ def summarize_by_kernel(records):
     return by_kernel
 
 
+def pmc_file():
+    """The newest committed counter summary profiles/rNN_pmc_traffic.json (tools/pmc_traffic.py) -> (path, dict) or (None, {})."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
+    if not files:
+        return None, {}
+    return files[-1], json.load(open(files[-1]))
+
+
 def pmc_of_kernel(kname):
     """Fabric-side bytes per launch + matrix-pipe utilisation of a kernel from the committed rocprofv3 --pmc passes
-    (profiles/r03_pmc_traffic.json, tools/pmc_traffic.py; collected at the default workload)."""
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path)).get('per_kernel', {})
-    for pat, v in d.items():
+    (profiles/rNN_pmc_traffic.json, tools/pmc_traffic.py; collected at the default workload, NOT in this run: the entry
+    names its source file)."""
+    path, d = pmc_file()
+    for pat, v in d.get('per_kernel', {}).items():
         if kname.startswith(pat):
-            return v
+            return dict(v, source=os.path.relpath(path, ROOT), collected=d.get('collected'))
     return None
 
 
@@ -343,7 +362,7 @@ def summarize_kernels(records):
     return by_name, shapes
 
 
-def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, warmup=2):
+def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, warmup=2, partial=False):
     """One more configuration of the same step on this GPU, a few steps: -> dict(value, ms_per_step, ...)."""
     import synth_clouds
     from vgtk import _hip
@@ -351,7 +370,7 @@ def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, war
     model = Backbone(points, plan_points).to(dev)
     params = [p for p in model.parameters()]
     opt = torch.optim.Adam(params, lr=1e-4)
-    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, batch, points)
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, batch, points, partial=partial)
     xyz, pose = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(pose_np).to(dev)
 
     def step():
@@ -393,7 +412,8 @@ def other_configs(dev):
     return [
         dict(name='config 2: 8 x 4096, forward only', **quick_run(dev, 8, 4096, fwd_only=True)),
         dict(name='configs 3/4 per-GPU shape: 16 x 4096', **quick_run(dev, 16, 4096)),
-        dict(name='config 5 per-GPU shape: 8 x 8192', **quick_run(dev, 8, 8192)),
+        dict(name='config 5 per-GPU shape: 8 x 8192 partial (depth-buffer visible) clouds', **quick_run(dev, 8, 8192, partial=True)),
+        dict(name='8 x 8192 complete clouds', **quick_run(dev, 8, 8192)),
         dict(name='8 x 4096 with the 512-point radii (textbook-backward regime)', **quick_run(dev, 8, 4096, plan_points=512)),
     ]
 
@@ -446,7 +466,98 @@ def config3_step(dev, batch=16, points=4096, steps=2, warmup=1):
     return out
 
 
-def main():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher: start N ranks of this file through torch.distributed.run, one per
+    GPU over RCCL (the reference starts its 8 processes the same way, scripts/train/laptop_syn.sh:L23
+    `python -m torch.distributed.launch --nproc_per_node=8`).  On a box with fewer than N devices the ranks share the
+    devices round-robin and talk over gloo -- a functional check of the N > 1 path, flagged as such in the line
+    (`rccl_ranks: 0`, `functional_check_only`); it is not a scaling measurement.  -> exit code of the job."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    n_dev = torch.cuda.device_count()
+    if 'EAP_DIST_BACKEND' not in env:
+        env['EAP_DIST_BACKEND'] = 'nccl' if n_dev >= n else 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def dist_setup(args):
+    """Rank / world / device of this process from the launcher's environment; refuses a world size that is not --gpus
+    (a line whose n_gpus differs from the request would be a wrong scaling record)."""
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to print a line '
+                         f'whose n_gpus is not the request')
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get('EAP_DIST_BACKEND', 'nccl')
+    if n_dev == 0:
+        dev = torch.device('cpu')                     # --check-launch on a box without a GPU (tests/test_sharding_gloo.py)
+        backend = 'gloo'
+    else:
+        if backend == 'nccl' and world > n_dev:
+            raise SystemExit(f'bench.py: {world} RCCL ranks need {world} devices, {n_dev} visible (EAP_DIST_BACKEND=gloo runs the '
+                             f'functional check with shared devices)')
+        # (gloo + several ranks on one device: a functional check of the N > 1 path on a 1-GPU box only)
+        local = local % n_dev if backend != 'nccl' else local
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
+    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
+    return rank, world, dev, backend, n_dev
+
+
+def check_launch(args):
+    """`--check-launch`: the ranks rendezvous, run the path's two exchanges (pose-hypothesis all-gather over uneven shards,
+    hook-driven gradient all-reduce) on small tensors and rank 0 prints what was started.  Needs no GPU."""
+    from vgtk import sharding
+    rank, world, dev, backend, n_dev = dist_setup(args)
+    n_items = 2 * world + 1
+    start, stop = sharding.shard_range(n_items)
+    gen = torch.Generator().manual_seed(5)
+    R_all, T_all = torch.randn(n_items, SLOTS, NA, 3, 3, generator=gen), torch.randn(n_items, SLOTS, NA, 3, generator=gen)
+    R, Tt = sharding.all_gather_pose_hypotheses(R_all[start:stop].to(dev), T_all[start:stop].to(dev), n_items=n_items)
+    ok = torch.equal(R.cpu(), R_all) and torch.equal(Tt.cpu(), T_all)
+    torch.manual_seed(3)
+    lin = nn.Linear(6, 4).to(dev)
+    reducer = sharding.GradientReducer(list(lin.parameters()))
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
+    lin(x).square().sum().backward()
+    reducer.finish()
+    g = lin.weight.grad.detach().clone()
+    if world > 1:
+        g0 = g.clone()
+        dist.broadcast(g0, 0)
+        ok = ok and torch.equal(g0, g)
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        print(json.dumps({'launch_check': ok, 'n_gpus': world, 'requested_gpus': args.gpus, 'backend': backend,
+                          'rccl_ranks': world if backend == 'nccl' and world > 1 else 0, 'devices_visible': n_dev}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -455,24 +566,22 @@ def main():
     ap.add_argument('--points', type=int, default=4096)
     ap.add_argument('--fwd-only', action='store_true', help='BASELINE config 2 (forward only)')
     ap.add_argument('--separable', action='store_true', help='the separable (inter + intra + skip) glb_backbone instead of the inter backbone; implies --fwd-only as in the reference')
+    ap.add_argument('--partial', action='store_true', help='partial (depth-buffer visible) clouds: BASELINE config 5 with --points 8192')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plan-points', type=int, default=None, help='radii / sigmas of the backbone built for this input size (default: --points)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configurations (config 3 composite included)')
-    args = ap.parse_args()
+    ap.add_argument('--check-launch', action='store_true', help='start the ranks, run the two exchanges on small tensors, print what was started (no GPU needed)')
+    args = ap.parse_args(argv)
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    # (EAP_DIST_BACKEND=gloo + several ranks on one device: a functional check of the N > 1 path on a 1-GPU box only)
-    backend = os.environ.get('EAP_DIST_BACKEND', 'nccl')
-    local = local % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # no launcher around us: start the N ranks ourselves (the driver's N = 1 command form with --gpus N)
+        sys.exit(launch_ranks(args.gpus, argv))
+    if args.check_launch:
+        sys.exit(check_launch(args))
+
+    rank, world, dev, backend, n_dev = dist_setup(args)
+    if n_dev == 0:
+        raise SystemExit('bench.py: no GPU visible (this package has no CPU path)')
 
     import synth_clouds
     from vgtk import _hip, sharding
@@ -490,7 +599,7 @@ def main():
     # backward kernels still run (vgtk/sharding.py); a no-op on one GPU
     reducer = sharding.GradientReducer(conv_params)
     n_items = args.batch * world
-    xyz_np, _, pose_np = synth_clouds.laptop_batch(rank * args.batch, args.batch, args.points)
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(rank * args.batch, args.batch, args.points, partial=args.partial)
     xyz = torch.from_numpy(xyz_np).to(dev)
     pose = torch.from_numpy(pose_np).to(dev)
 
@@ -517,25 +626,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        """n steps between two barrier + synchronize pairs -> seconds, MAX over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
     for _ in range(args.warmup):
         step()
-    barrier()
+    # the headline loop: EXACTLY --steps steps, no per-launch events
+    dt = timed(args.steps)
+    # kernel attribution in a second, short loop: every C-ABI launch bracketed by two HIP events on the launch stream
+    attr_steps = min(args.steps, 3)
     _hip.KERNEL_TIMES = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt_attr = timed(attr_steps)
     records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    # same-run A/B of the forward contraction: the fp32-MFMA kernel instead of the 3 x bf16 split
+    ab = None
+    if not args.fwd_only and not args.separable and _hip.SPLIT_BF16_CONTRACTION:
+        _hip.SPLIT_BF16_CONTRACTION = False
+        step()
+        dt_ab = timed(attr_steps)
+        _hip.SPLIT_BF16_CONTRACTION = True
+        ab = {'value': args.batch * world * attr_steps / dt_ab, 'ms_per_step': dt_ab / attr_steps * 1e3, 'steps': attr_steps,
+              'note': 'same run, vgtk._hip.SPLIT_BF16_CONTRACTION = False: the forward contraction on the fp32 matrix pipe (csrc/gemm_dma_f32.hip)'}
 
     if rank == 0:
         kern, shapes = summarize_kernels(records)
         by_kernel = summarize_by_kernel(records)
-        default_cfg = args.points == 4096 and args.batch == 8 and not args.fwd_only and not args.separable and args.plan_points is None
+        default_cfg = args.points == 4096 and args.batch == 8 and not args.fwd_only and not args.separable and args.plan_points is None and not args.partial
         # the dominant KERNEL (template instantiation, as rocprofv3 lists them) among those doing matrix work
         dom_name = max((k for k in by_kernel if by_kernel[k]['flops'] > 0), key=lambda k: by_kernel[k]['ms'])
         total_kernel_ms = max(sum(k['ms'] for k in by_kernel.values()), 1e-9)
@@ -543,22 +670,26 @@ def main():
         roof['share_of_kernel_time'] = by_kernel[dom_name]['ms'] / total_kernel_ms
         roof['flops_definition'] = ('algorithmic: 2*M*N*K*batch for GEMMs; 2*channels*K(24)*P*NN*A*B for the grouping kernels '
                                     '(the MFMA tiles pad K 24->32 and the anchors 60->64, not counted)')
-        step_flops = sum(k['flops'] for k in by_kernel.values()) / args.steps
+        step_flops = sum(k['flops'] for k in by_kernel.values()) / attr_steps
         clouds = args.batch * world * args.steps
         line = {
             'metric': 'point-clouds/sec (4096 pts, 60 anchors) ' + ('fwd' if args.fwd_only else 'fwd+bwd'),
             'value': clouds / dt, 'unit': 'point-clouds/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'rccl_ranks': world if backend == 'nccl' and world > 1 else 0,
             'dtype_note': 'fp32 tensors, fp32 accumulation everywhere; the forward contraction forms its fp32 products on the bf16 '
                           'matrix cores from exact 3 x bf16 splits of both operands (as accurate as the fp32 MFMA: tests compare '
                           'both with fp64; vgtk._hip.SPLIT_BF16_CONTRACTION = False selects the fp32-MFMA kernel)',
-            'config': {'workload': f'{args.batch} x {args.points}-pt synthetic laptop clouds per GPU, 3-block '
+            'config': {'workload': f'{args.batch} x {args.points}-pt synthetic ' + ('partial (depth-buffer visible) ' if args.partial else '') + 'laptop clouds per GPU, 3-block '
                                    + ('separable (inter+intra+skip) glb_backbone' if args.separable else 'inter backbone')
                                    + f' 1->64->128->512 (NN=64,K=24,A=60), '
                                    + ('forward' if args.fwd_only else 'forward+backward+Adam'),
                        'clouds_per_gpu': args.batch, 'points': args.points, 'anchors': NA,
                        'sharding': f'clouds x{world}, pose all-gather + gradient all-reduce overlapped with the backward' if world > 1 else 'single GPU'},
+            'timing': {'headline_loop': 'no per-launch events', 'ms_per_step_with_launch_events': dt_attr / attr_steps * 1e3,
+                       'attribution_steps': attr_steps,
+                       'note': 'roofline / kernels / whole_step come from the second loop (two HIP events per C-ABI launch on the launch stream)'},
             'roofline': roof,
             # the same object for every kernel that takes more than 5 % of the kernel time and does matrix work
             'kernel_rooflines': [dict(roofline_object(n, k, default_cfg), share_of_kernel_time=k['ms'] / total_kernel_ms)
@@ -567,13 +698,18 @@ def main():
             'whole_step': {'algorithmic_flops_per_gpu': step_flops, 'achieved_TFLOPs_per_gpu': step_flops / (dt / args.steps) / 1e12,
                            'frac_of_fp32_mfma_peak': step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                            'note': 'algorithmic fp32 flops over the fp32-MFMA peak; part of them (the forward contraction) run as 3 x bf16 split products on the bf16 pipe',
-                           'kernel_time_share_of_step': total_kernel_ms / (dt * 1e3)},
-            'kernels': {n: {'ms_per_step': k['ms'] / args.steps, 'launches_per_step': k['launches'] / args.steps,
+                           'kernel_time_share_of_step': total_kernel_ms / (dt_attr * 1e3)},
+            'kernels': {n: {'ms_per_step': k['ms'] / attr_steps, 'launches_per_step': k['launches'] / attr_steps,
                             'tflops': (k['flops'] / (k['ms'] * 1e-3) / 1e12) if k['flops'] > 0 else None}
                         for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])},
             'dominant_kernel': dom_name,
             'launch_shapes': shapes[:8],
         }
+        if ab is not None:
+            line['fp32_mfma_contraction'] = ab
+        if world > 1 and backend != 'nccl':
+            line['functional_check_only'] = (f'{world} ranks over {backend} on {n_dev} device(s): the N > 1 code path runs, '
+                                             f'this is NOT a scaling measurement')
         if world == 1 and default_cfg and not args.no_other_configs:
             del model, opt, xyz, pose
             torch.cuda.empty_cache()
@@ -586,6 +722,7 @@ def main():
             line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -37,10 +37,32 @@ def _haar(rng):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
+def _visible_subset(rng, pts, label, n_points, cam=(0.0, 0.0, -1.8), yfov=math.radians(60.0), ph=480, cell=2, tol=0.012):
+    """Depth-buffer visibility from a pinhole camera at `cam` looking down +z -- the synthetic counterpart of the reference's
+    rendered partial views (SPConvNets/datasets/MotionHOIDatasetPartial.py:L134 create_partial_pts: camera mean pose (0, 0, -1.8),
+    yfov 60 degrees, 640 x 480 depth image back-projected to points): the raw surface samples are splatted into cells of
+    `cell` x `cell` pixels, a sample survives if its depth is within `tol` of its cell's nearest sample (so only the surfaces
+    facing the camera remain), and `n_points` of the survivors are drawn (without replacement when there are enough)."""
+    f = 0.5 * ph / math.tan(0.5 * yfov)
+    rel = pts - np.asarray(cam)
+    z = rel[:, 2]
+    u = np.floor(rel[:, 0] / z * f / cell).astype(np.int64)
+    v = np.floor(rel[:, 1] / z * f / cell).astype(np.int64)
+    key = (u - u.min()) * (v.max() - v.min() + 1) + (v - v.min())
+    order = np.argsort(key, kind='stable')
+    ks, zs = key[order], z[order]
+    first = np.r_[True, ks[1:] != ks[:-1]]
+    zmin = np.minimum.reduceat(zs, np.flatnonzero(first))[np.cumsum(first) - 1]
+    vis = order[zs <= zmin + tol]
+    vis.sort()
+    sel = rng.choice(vis, size=n_points, replace=len(vis) < n_points)
+    return pts[sel], label[sel]
+
+
 def laptop_cloud(index, n_points, partial=False):
     """-> (xyz float32 [3,N], label int64 [N], pose float32 [N,4,4])."""
     rng = np.random.default_rng(BASE_SEED + index)
-    n_raw = n_points * 4 if partial else n_points
+    n_raw = n_points * 8 if partial else n_points
     n_base = n_raw // 2
     base = _box_surface(rng, n_base, BOX)
     lid = _box_surface(rng, n_raw - n_base, BOX)
@@ -54,12 +76,8 @@ def laptop_cloud(index, n_points, partial=False):
     label = np.concatenate([np.zeros(n_base, np.int64), np.ones(n_raw - n_base, np.int64)])
     pts = pts - pts.mean(0, keepdims=True)
     pts = pts @ _haar(rng).T
-    if partial:  # keep points facing a camera at (0, 0, -1.8), resample to n_points
-        cam = np.array([0.0, 0.0, -1.8])
-        depth = np.linalg.norm(pts - cam, axis=1)
-        order = np.argsort(depth)[: max(n_points // 2, 1)]
-        sel = order[rng.integers(0, len(order), size=n_points)]
-        pts, label = pts[sel], label[sel]
+    if partial:
+        pts, label = _visible_subset(rng, pts, label, n_points)
         pts = pts - pts.mean(0, keepdims=True)
     perm = rng.permutation(n_points)
     pts, label = pts[perm], label[perm]

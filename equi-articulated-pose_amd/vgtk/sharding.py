@@ -94,19 +94,30 @@ def all_reduce_gradients(params, average=True, group=None):
 class GradientReducer:
     """Gradient all-reduce overlapped with the backward pass: the parameters are packed, in REVERSE registration order
     (the order their gradients become ready: the deepest layer first), into buckets of at most `bucket_bytes`; a
-    bucket's all-reduce is launched asynchronously the moment its last gradient has been accumulated
-    (Tensor.register_post_accumulate_grad_hook), so it travels over xGMI while the earlier layers' backward kernels still
-    run; finish() waits for the buckets and writes the averaged gradients back.  With the 3-block backbone the 6 MB
-    deepest-layer bucket is in flight during the ~15 ms of the two shallower layers' backward.
+    bucket's all-reduce is launched asynchronously once its last gradient has been accumulated
+    (Tensor.register_post_accumulate_grad_hook) AND every bucket before it has been launched, so it travels over xGMI
+    while the earlier layers' backward kernels still run; finish() waits for the buckets and writes the averaged
+    gradients back.  With the 3-block backbone the 6 MB deepest-layer bucket is in flight during the ~15 ms of the two
+    shallower layers' backward.
 
         reducer = GradientReducer(params)        # once
         loss.backward(); reducer.finish(); optimizer.step()
+
+    Every rank issues the SAME collectives in the SAME order whatever its autograd graph looked like this step (the
+    reference gets this from DistributedDataParallel, trainer_unsup_arti_align.py:L432-440): buckets launch strictly in
+    index order -- a complete bucket waits for its predecessors, which finish() launches if a data-dependent branch
+    left them incomplete on this rank.  A parameter without a gradient on this rank contributes zeros (whatever an
+    earlier step left in the buffer is cleared); each bucket carries one "fired" count per parameter, so a parameter
+    that received a gradient on ANY rank ends with the averaged gradient on EVERY rank (p.grad is materialised where it
+    was None -- the replicas stay identical), and one that no rank touched keeps p.grad = None.  A backward that reaches
+    a bucket whose all-reduce is still in flight (a second backward before finish()) raises.
 
     Single-process runs register nothing and finish() is a no-op."""
 
     def __init__(self, params, bucket_bytes=8 << 20, average=True, group=None):
         self.group, self.average = group, average
         self.buckets, self._handles = [], []
+        self._next = 0                               # index of the first bucket not launched yet in this step
         if not is_distributed():
             return
         params = [p for p in params if p.requires_grad]
@@ -122,41 +133,64 @@ class GradientReducer:
             self._add_bucket(cur)
 
     def _add_bucket(self, params):
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
-        bucket = {'params': params, 'flat': flat, 'pending': len(params), 'work': None, 'offsets': []}
+        n = sum(p.numel() for p in params)
+        # [gradients of the bucket's parameters | one "fired" flag per parameter]
+        flat = torch.zeros(n + len(params), dtype=params[0].dtype, device=params[0].device)
+        bucket = {'params': params, 'flat': flat, 'n': n, 'fired': [False] * len(params), 'work': None, 'offsets': []}
         off = 0
         for p in params:
             bucket['offsets'].append(off)
             off += p.numel()
-        for p, o in zip(params, bucket['offsets']):
-            self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket, o)))
+        for i, p in enumerate(params):
+            self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(len(self.buckets), i)))
         self.buckets.append(bucket)
 
-    def _make_hook(self, bucket, offset):
+    def _launch(self, bucket):
+        for i, (p, o) in enumerate(zip(bucket['params'], bucket['offsets'])):
+            if not bucket['fired'][i]:
+                bucket['flat'][o:o + p.numel()].zero_()
+                bucket['flat'][bucket['n'] + i].zero_()
+        bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _launch_complete_prefix(self):
+        while self._next < len(self.buckets) and all(self.buckets[self._next]['fired']):
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
+    def _make_hook(self, bucket_index, slot):
         def hook(p):
-            bucket['flat'][offset:offset + p.numel()].copy_(p.grad.reshape(-1))
-            bucket['pending'] -= 1
-            if bucket['pending'] == 0:
-                bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            bucket = self.buckets[bucket_index]
+            if bucket['work'] is not None:
+                raise RuntimeError('GradientReducer: a gradient arrived for a bucket whose all-reduce is in flight -- call finish() '
+                                   'after every backward (gradient accumulation over several backward passes: finish() after the last)')
+            o = bucket['offsets'][slot]
+            bucket['flat'][o:o + p.numel()].copy_(p.grad.reshape(-1))      # p.grad is the accumulated gradient: a second visit overwrites
+            bucket['flat'][bucket['n'] + slot].fill_(1.0)                  # device-side fill: no host -> device copy inside the backward
+            bucket['fired'][slot] = True
+            self._launch_complete_prefix()
         return hook
 
     def finish(self):
-        """Wait for every bucket and write the reduced gradients back.  A parameter that received no gradient in this
-        backward (unused in the step) contributes zeros: its bucket is reduced here, synchronously."""
+        """Launch what the hooks could not (in bucket order), wait for every bucket and write the reduced gradients back."""
         world = dist.get_world_size(self.group) if self.buckets else 1
+        for bucket in self.buckets[self._next:]:
+            self._launch(bucket)
+        self._next = len(self.buckets)
         for bucket in self.buckets:
-            if bucket['work'] is None:
-                for p, o in zip(bucket['params'], bucket['offsets']):
-                    if bucket['pending'] and p.grad is None:
-                        bucket['flat'][o:o + p.numel()].zero_()
-                bucket['work'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             bucket['work'].wait()
+            touched = bucket['flat'][bucket['n']:].tolist()
             if self.average:
-                bucket['flat'] /= world
-            for p, o in zip(bucket['params'], bucket['offsets']):
-                if p.grad is not None:
-                    p.grad.copy_(bucket['flat'][o:o + p.numel()].view_as(p.grad))
-            bucket['pending'], bucket['work'] = len(bucket['params']), None
+                bucket['flat'][:bucket['n']] /= world
+            for i, (p, o) in enumerate(zip(bucket['params'], bucket['offsets'])):
+                if touched[i] == 0:
+                    continue                                                # no rank produced a gradient: leave p.grad as it is
+                g = bucket['flat'][o:o + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+            bucket['fired'], bucket['work'] = [False] * len(bucket['params']), None
+        self._next = 0
 
     def remove(self):
         for h in self._handles:

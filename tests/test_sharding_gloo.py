@@ -162,3 +162,94 @@ def test_uneven_shards_and_overlapped_gradient_reduction(tmp_path):
         for k in range(6):
             np.testing.assert_allclose(r[i][f'g{k}'], 0.5 * (r[0][f'l{k}'] + r[1][f'l{k}']), rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(r[i][f'h{k}'], 0.5 * (r[0][f'm{k}'] + r[1][f'm{k}']), rtol=1e-6, atol=1e-7)
+
+
+def _divergent_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, os.path.join(root, 'equi-articulated-pose_amd'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vgtk import sharding
+    torch.manual_seed(3)
+    # registration order never, a, b, c, d  ->  buckets (deepest first) [d], [c], [b], [a], [never]: one parameter per bucket
+    a, b, c, d = (torch.nn.Parameter(torch.randn(5)) for _ in range(4))
+    never = torch.nn.Parameter(torch.randn(5))
+    params = [never, a, b, c, d]           # `never` registers first = the LAST bucket (an unused head bucket would hold every launch until finish())
+    reducer = sharding.GradientReducer(params, bucket_bytes=4 * 5)
+    w = torch.arange(1.0, 6.0) * (rank + 1)
+
+    def loss(use_c_on, use_b_on):
+        y = (a * w).sum() + (d * w * 2).sum()
+        if rank in use_c_on:
+            y = y + (c * w * 3).sum()      # data-dependent branch: c is used on SOME ranks only
+        if rank in use_b_on:
+            y = y + (b * w * 4).sum()
+        return y
+
+    # step 1: c only on rank 0, b on both.  Rank 1's bucket [c] never completes, bucket [b] does: launching from the completing
+    # hook alone would pair rank 0's [c] with rank 1's [b].
+    loss({0}, {0, 1}).backward()
+    reducer.finish()
+    s1 = {n: (None if p.grad is None else p.grad.clone()) for n, p in zip('nabcd', params)}
+    # step 2 with zero_grad(set_to_none=False): b unused everywhere this step -> its stale step-1 average must not be reduced again
+    for p in params:
+        if p.grad is not None:
+            p.grad.zero_()
+    loss({0, 1}, set()).backward()
+    reducer.finish()
+    s2 = {n: (None if p.grad is None else p.grad.clone()) for n, p in zip('nabcd', params)}
+    # a second backward while a bucket is in flight raises
+    for p in params:
+        p.grad = None
+    loss({0, 1}, {0, 1}).backward()
+    try:
+        loss({0, 1}, {0, 1}).backward()
+        raised = False
+    except RuntimeError:
+        raised = True
+    reducer.finish()
+    out = {'raised': raised, 'never_none': s1['n'] is None and s2['n'] is None}
+    for tag, s in (('s1', s1), ('s2', s2)):
+        for n in 'abcd':
+            out[f'{tag}_{n}'] = s[n].numpy()
+    np.savez(os.path.join(out_dir, f'd{rank}.npz'), **out)
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_with_rank_dependent_graphs(tmp_path):
+    """Ranks whose autograd graphs differ (a parameter used on one rank only) still issue the same collectives in the same
+    order, end with identical averaged gradients (materialised where p.grad was None), a parameter unused in a step adds
+    nothing even when zero_grad keeps the tensors, one that no rank touches keeps grad None, and a backward that meets an
+    in-flight bucket raises."""
+    world = 2
+    mp.spawn(_divergent_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [dict(np.load(tmp_path / f'd{i}.npz')) for i in range(world)]
+    w = np.arange(1.0, 6.0)
+    for i in range(world):
+        assert bool(r[i]['raised']) and bool(r[i]['never_none'])
+        np.testing.assert_allclose(r[i]['s1_a'], 1.5 * w)
+        np.testing.assert_allclose(r[i]['s1_d'], 3.0 * w)
+        np.testing.assert_allclose(r[i]['s1_c'], 0.5 * 3 * w)          # rank 0 only: (3w + 0) / 2, on BOTH ranks
+        np.testing.assert_allclose(r[i]['s1_b'], 1.5 * 4 * w)
+        np.testing.assert_allclose(r[i]['s2_c'], 1.5 * 3 * w)
+        np.testing.assert_allclose(r[i]['s2_b'], 0 * w)                 # zeroed by zero_grad, untouched by the reduction
+        np.testing.assert_allclose(r[i]['s2_a'], 1.5 * w)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts 2 ranks itself (the form the driver uses for N = 1) and refuses a
+    world size that is not the request; --check-launch runs the path's two exchanges on small tensors (gloo here, no GPU)."""
+    import json
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--check-launch'], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['launch_check'] is True and line['n_gpus'] == 2 and line['requested_gpus'] == 2
+    env.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--check-launch'], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and 'refusing' in bad.stderr
