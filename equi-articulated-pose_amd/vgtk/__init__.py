@@ -12,4 +12,4 @@ from . import point3d  # noqa: F401
 from . import pc  # noqa: F401
 from . import spconv  # noqa: F401
 from . import so3conv  # noqa: F401
-from .utils import batch_gather  # noqa: F401
+from .utils import batch_gather, batch_zip, LearningRateScheduler  # noqa: F401

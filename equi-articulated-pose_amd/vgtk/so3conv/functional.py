@@ -65,6 +65,35 @@ def get_canonical_relative():
     return canonical_relative
 
 
+def get_kernel_points_np(radius, aperature, kernel_size, multiplier=1):
+    """Kernel points [n,3] on a cone around +z (functional.py:L73-89): shell i of `kernel_size` shells sits at height
+    z_i = i * radius / (kernel_size - 1) and carries i * multiplier + 1 polar angles alpha (interior points of
+    [0, aperature / 2]); the j-th of them contributes a circle of 2 j + 1 points of radius z_i tan(alpha)."""
+    assert isinstance(kernel_size, int)
+    shells = []
+    for i, z in enumerate(np.linspace(0, radius, kernel_size, dtype=np.float32)):
+        for j, alpha in enumerate(zpconv.get_angular_kernel_points_np(aperature, i * multiplier + 1)):
+            n = 2 * j + 1
+            phi = np.linspace(0, 2 * np.pi, n, endpoint=False, dtype=np.float32)
+            rho = z * np.tan(alpha)
+            shells.append(np.stack([rho * np.cos(phi), rho * np.sin(phi), np.full(n, z)], axis=1))
+    return np.concatenate(shells, axis=0)
+
+
+def get_spherical_kernel_points_np(radius, kernel_size, multiplier=3):
+    """Kernel points [n,3] on concentric spheres (functional.py:L91-109): sphere i of radius i * radius / (kernel_size - 1)
+    carries an m x m longitude / colatitude grid, m = i * multiplier + 1 (longitudes without, colatitudes with end point)."""
+    assert isinstance(kernel_size, int)
+    spheres = []
+    for i, r in enumerate(np.linspace(0, radius, kernel_size, dtype=np.float32)):
+        m = i * multiplier + 1
+        lon = np.linspace(0, 2 * np.pi, m, endpoint=False, dtype=np.float32)[:, None]
+        col = np.linspace(0, np.pi, m, endpoint=True, dtype=np.float32)[None, :]
+        xyz = np.stack([r * np.cos(lon) * np.sin(col), r * np.sin(lon) * np.sin(col), np.broadcast_to(r * np.cos(col), (m, m))], axis=-1)
+        spheres.append(xyz.reshape(m * m, 3))
+    return np.concatenate(spheres, axis=0)
+
+
 def get_sphereical_kernel_points_from_ply(radius, kernel_size):
     """kernel_size 1/2/3 -> 24/30/66 kernel points rescaled so the max norm is `radius`."""
     assert 0 < kernel_size <= 3

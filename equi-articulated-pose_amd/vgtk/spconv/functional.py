@@ -201,3 +201,152 @@ def inter_zpposeconv_grouping_ball(xyz, pose, stride, radius, n_neighbor, lazy_s
     grouped_pose = batched_index_select_other(pose, ball_idx, dim=1)
     grouped_xyz = grouped_xyz - sample_xyz.unsqueeze(3)
     return grouped_xyz, ball_idx, idx, sample_xyz, grouped_pose, sampled_pose
+
+
+# ------------------------------------------------------------------------------------------------
+# S^2 ("ZP") convolution: anchor directions, kernel tables, anchor-to-anchor tables and the grouping entry of
+# vgtk.spconv.modules (functional.py:L20-61, L134-208, L503-607, L610-655).  Host-side tables are built once per
+# module; the contractions run in the HIP zpconv kernels through the *_naive entries above.
+# ------------------------------------------------------------------------------------------------
+_ANCHOR_TABLES = {}
+
+
+def _unit_rows(points):
+    """Rows of `points` [n,3] longer than 0.5, scaled to unit length (the icosphere files carry a centre vertex)."""
+    length = np.linalg.norm(points, axis=1)
+    long_enough = length > 0.5
+    return (points[long_enough] / length[long_enough, None]).astype(np.float32)
+
+
+def get_anchors(anchor):
+    """Directions on S^2 as a CPU tensor [na,3]: an int names an icosphere of the data set (12 / 42 / 92 / 162 vertices,
+    vgtk/data/anchors/constants.npz), a str is the path of a PLY file, a tensor is passed through (detached, on the host)."""
+    if torch.is_tensor(anchor):
+        return anchor.detach().cpu()
+    if isinstance(anchor, str):
+        return torch.from_numpy(_unit_rows(pctk.load_ply(anchor).astype(np.float32)))
+    if not isinstance(anchor, int):
+        raise ValueError(f'Not recognized anchor type {type(anchor)}')
+    if anchor not in _ANCHOR_TABLES:
+        import os
+        import vgtk
+        table = np.load(os.path.join(vgtk.__path__[0], 'data', 'anchors', 'constants.npz'))
+        name = f'sphere{anchor:d}_vertices'
+        if name not in table.files:
+            raise ValueError(f'no icosphere with {anchor} vertices in the anchor data (12, 42, 92, 162)')
+        _ANCHOR_TABLES[anchor] = _unit_rows(table[name].astype(np.float32))
+    return torch.from_numpy(_ANCHOR_TABLES[anchor].copy())
+
+
+def get_kernel_rings_np(radius, aperature, kernel_size, multiplier=1):
+    """Kernel positions of the inter ZP conv as (distance from the centre, polar angle) rows, float32 [ks,2].
+    int kernel_size: ring i of `kernel_size` rings sits at the i-th interior point of [0, radius] and carries
+    multiplier * i + 1 polar angles; a pair (n_r, n_w): the full grid of n_r distances radius/n_r .. radius and n_w angles."""
+    if isinstance(kernel_size, int):
+        ring_radius = np.linspace(0, radius, kernel_size + 2, dtype=np.float32)[1:-1]
+        rows = [(ring_radius[i], w) for i in range(kernel_size)
+                for w in get_angular_kernel_points_np(aperature, multiplier * i + 1)]
+        return np.asarray(rows, dtype=np.float32).reshape(-1, 2)
+    n_r, n_w = kernel_size
+    ring_radius = np.linspace(radius / n_r, radius, n_r, dtype=np.float32)
+    angles = get_angular_kernel_points_np(aperature, n_w)
+    grid = np.stack(np.meshgrid(ring_radius, angles, indexing='ij'), axis=-1)
+    return grid.reshape(-1, 2).astype(np.float32)
+
+
+def get_intra_kernels(aperature, kernel_size):
+    """kernel_size angular bins covering [0, aperature / 2], end points included."""
+    return torch.from_numpy(np.linspace(0, 0.5 * aperature, kernel_size, dtype=np.float32))
+
+
+def acos_safe(x, eps=1e-4):
+    """arccos continued linearly outside [-(1 - eps), 1 - eps] with the slope arccos(1 - eps) / eps, so that its gradient
+    stays finite at +-1."""
+    edge = 1.0 - eps
+    slope = np.arccos(edge) / eps
+    s = torch.sign(x)
+    outside = torch.acos(s * edge) - slope * s * (x.abs() - 1 + eps)     # (|x| - 1) + eps in fp32, the reference's rounding order
+    return torch.where(x.abs() <= edge, torch.acos(x), outside)
+
+
+def anchor_knn(a_src, a_tgt, k=3, metric="spherical"):
+    """The k anchors of a_src [n,3] nearest to every anchor of a_tgt [m,3] -> (values [m,k], indices [m,k]).
+    'spherical': largest <s,t> - 1; 'angular': smallest acos_safe(<s,t>); anything else: smallest squared distance."""
+    if metric in ('spherical', 'angular'):
+        cosine = (a_tgt[:, None, :] * a_src[None, :, :]).sum(2)
+        if metric == 'spherical':
+            return (cosine - 1.0).topk(k=k, dim=1, largest=True)
+        return acos_safe(cosine).topk(k=k, dim=1, largest=False)
+    return (a_src[None, :, :] - a_tgt[:, None, :]).pow(2).sum(2).topk(k=k, dim=1, largest=False)
+
+
+def get_intra_kernel_weights(anchor_in, anchor_out, kernels, ann, aperature, sigma=1e-1, use_suppression=False):
+    """Tables of the intra ZP conv: for every output anchor its `ann` angularly nearest input anchors, idx int32 [a_out,ann],
+    and the influence of each on every angular bin, [a_out,ks,ann] = relu(1 - |angle - bin| / pi / (3 sqrt(sigma / 2)))
+    (optionally zero beyond half the aperture)."""
+    if anchor_out is None:
+        anchor_out = anchor_in
+    angle, idx = anchor_knn(anchor_in, anchor_out, k=ann, metric='angular')                 # [a_out,ann]
+    width = 3.0 * (sigma / 2.0) ** 0.5
+    gap = (angle[:, None, :] - kernels[None, :, None]).abs() / np.pi                         # [a_out,ks,ann]
+    influence = torch.relu(1.0 - gap / width)
+    if use_suppression:
+        influence = influence * angle.le(0.5 * aperature)[:, None, :].float()
+    return idx.int().contiguous(), influence.contiguous()
+
+
+def compute_anchor_weights(anchor_in, anchor_out, k=3, sigma=1e-1, interpolation="inv"):
+    """k-nearest-anchor interpolation table from anchor_in [a1,3] to anchor_out [a2,3] -> idx [a2,k], w [a2,k] (rows sum to 1).
+    'spherical': softmax((<i,o> - 1) / sigma); 'euclidean': softmax(-d^2 / sigma); 'inv': 1 / (sigma d^2 + 1e-6), normalised."""
+    if interpolation == 'spherical':
+        val, idx = anchor_knn(anchor_in, anchor_out, k=k, metric='spherical')
+        return idx, torch.softmax(val / sigma, dim=1)
+    val, idx = anchor_knn(anchor_in, anchor_out, k=k, metric='euclidean')
+    if interpolation == 'euclidean':
+        return idx, torch.softmax(-val / sigma, dim=1)
+    if interpolation != 'inv':
+        raise ValueError(f'unknown interpolation {interpolation!r}')
+    closeness = 1.0 / (sigma * val + 1e-6)
+    return idx, closeness / closeness.sum(1, keepdim=True)
+
+
+def anchor_prop(x, idx, w):
+    """Features [b,c,p,a1] carried to another anchor set: out[..., j] = sum_k w[j,k] x[..., idx[j,k]] -> [b,c,p,a2]."""
+    a2, k = idx.shape
+    picked = x.index_select(3, idx.reshape(-1).long()).reshape(*x.shape[:3], a2, k)
+    return (picked * w).sum(-1)
+
+
+def inter_zpconv_grouping_anchor(grouped_xyz, ball_idx, sample_idx, anchors, kernels, anchor_nn, n_support,
+                                 radius, aperture, sigma):
+    """Kernel weights of the inter ZP conv (the reference's live "linear kernel" branch): for the neighbour offsets
+    grouped_xyz [b,3,p,nn], anchor directions [a,3] and kernel rows (rho_k, theta_k):
+        w[b,p,a,k,n] = relu(1 - (|r - rho_k| + |r (theta - theta_k)| / 3) / sqrt(sigma)),
+    r = |offset| + 1e-6, theta = acos_safe(<offset, anchor> / r).  -> (ball_idx unchanged [b,p,nn], w [b,p,a,ks,nn])."""
+    r = grouped_xyz.pow(2).sum(1).sqrt() + 1e-6                                               # [b,p,nn]
+    along = torch.einsum('bdpn,ad->bpan', grouped_xyz, anchors.to(grouped_xyz))              # [b,p,a,nn]
+    theta = acos_safe(along / r[:, :, None, :])[:, :, :, None, :]                             # [b,p,a,1,nn]
+    r5 = r[:, :, None, None, :]
+    rho = kernels[:, 0].reshape(1, 1, 1, -1, 1)
+    theta_k = kernels[:, 1].reshape(1, 1, 1, -1, 1)
+    spread = (r5 - rho).abs() + (r5 * (theta - theta_k)).abs() / 3.0
+    return ball_idx, torch.relu(1.0 - spread / sigma ** 0.5)
+
+
+def inter_zpconv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, anchor_nn, radius, aperture, sigma,
+                          inter_idx=None, inter_w=None, lazy_sample=True, radius_expansion=1.0):
+    """Ball grouping + kernel weights (unless handed in) + the grouped contraction -> inter_idx [b,p,nn], inter_w,
+    new_xyz, new_feats [b,c,k,p,a].  As in the reference the freshly built weights are stored with their anchor and
+    kernel axes swapped ([b,p,ks,a,nn]) and the contraction reads axis 2 as the anchor axis, a singleton there being
+    broadcast over the feature's anchors."""
+    if inter_idx is None:
+        grouped_xyz, ball_idx, centre_idx, new_xyz = inter_zpconv_grouping_ball(xyz, stride, radius * radius_expansion,
+                                                                                n_neighbor, lazy_sample)
+        inter_idx, inter_w = inter_zpconv_grouping_anchor(grouped_xyz, ball_idx, centre_idx, anchors, kernels, anchor_nn,
+                                                          xyz.shape[2], radius, aperture, sigma)
+        inter_w = inter_w.transpose(2, 3).contiguous()
+    else:
+        new_xyz = xyz
+    padded = add_shadow_feature(feats)
+    w = inter_w if inter_w.shape[2] == padded.shape[3] else inter_w.expand(-1, -1, padded.shape[3], -1, -1)
+    return inter_idx, inter_w, new_xyz, inter_zpconv_grouping_naive(inter_idx, w, padded)

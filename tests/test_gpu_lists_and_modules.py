@@ -944,3 +944,49 @@ def test_masked_max_equals_torch(dev, shape):
         assert float(got[0, 0].max()) == 0.0
     # where the maximum is attained by a member the gradients agree; where it is one of the non-members' zeros both are zero
     assert torch.equal(gn, gr) or rel_err(gn.cpu().numpy(), gr.cpu().numpy()) == 0.0
+
+
+def test_zp_layers_match_the_reference(dev, golden):
+    """vgtk.spconv.modules (IntraZPConv, InterZPConv incl. a strided call, AnchorProp) on the HIP zpconv kernels + the
+    contraction GEMM against outputs and autograd gradients of the reference's own classes run on CPU
+    (tests/golden/make_golden_zp.py -> zp_layer.npz; reference vgtk/vgtk/spconv/modules.py:L17-161)."""
+    import vgtk.spconv as zptk
+    g = golden('zp_layer.npz')
+    xyz = T(g['xyz']).to(dev)
+
+    intra = zptk.IntraZPConv(6, 9, 3, 1.2, 0.1, 4, 12)
+    np.testing.assert_array_equal(intra.intra_idx.numpy(), g['intra_idx'])
+    assert rel_err(intra.intra_w.numpy(), g['intra_w']) < 1e-6
+    intra.load_state_dict({'basic_conv.W': T(g['intra_W']), 'basic_conv.bias': T(g['intra_bias'])}, strict=False)
+    intra = intra.to(dev)
+    fi = T(g['intra_in']).to(dev).requires_grad_(True)
+    y = intra(zptk.SphericalPointCloud(xyz, fi, None)).feats
+    gin, gW, gb = torch.autograd.grad(y, [fi, intra.basic_conv.W, intra.basic_conv.bias], T(g['intra_gy']).to(dev))
+    for got, want in ((y, 'intra_out'), (gin, 'intra_gin'), (gW, 'intra_gW'), (gb, 'intra_gbias')):
+        assert rel_err(got.detach().cpu().numpy(), g[want]) < 1e-5, want
+
+    inter = zptk.InterZPConv(6, 5, 1, 1, 0.25, 1.2, 0.05, 12, 12, 4)
+    assert rel_err(inter.kernels.numpy(), g['inter_kernels']) == 0
+    inter.load_state_dict({'basic_conv.W': T(g['inter_W']), 'basic_conv.bias': T(g['inter_bias'])}, strict=False)
+    inter = inter.to(dev)
+    fe = T(g['inter_in']).to(dev).requires_grad_(True)
+    iidx, iw, cloud = inter(zptk.SphericalPointCloud(xyz, fe, None))
+    np.testing.assert_array_equal(iidx.cpu().numpy(), g['inter_idx'])
+    assert tuple(iw.shape) == g['inter_w'].shape and np.abs(iw.cpu().numpy() - g['inter_w']).max() < 1e-5
+    gin, gW, gb = torch.autograd.grad(cloud.feats, [fe, inter.basic_conv.W, inter.basic_conv.bias], T(g['inter_gy']).to(dev))
+    for got, want in ((cloud.feats, 'inter_out'), (gin, 'inter_gin'), (gW, 'inter_gW'), (gb, 'inter_gbias')):
+        assert rel_err(got.detach().cpu().numpy(), g[want]) < 2e-5, want
+    # tables handed back in: the second call skips ball query and weights
+    _, _, again = inter(zptk.SphericalPointCloud(xyz, fe.detach(), None), iidx, iw)
+    assert torch.equal(again.feats, cloud.feats)
+
+    inter2 = zptk.InterZPConv(6, 5, 1, 2, 0.25, 1.2, 0.05, 12, 12, 4)
+    inter2.load_state_dict({'basic_conv.W': T(g['inter2_W']), 'basic_conv.bias': T(g['inter2_bias'])}, strict=False)
+    i2, w2, c2 = inter2.to(dev)(zptk.SphericalPointCloud(xyz, fe.detach(), None))
+    np.testing.assert_array_equal(i2.cpu().numpy(), g['inter2_idx'])
+    np.testing.assert_array_equal(c2.xyz.cpu().numpy(), g['inter2_xyz'])
+    assert rel_err(c2.feats.detach().cpu().numpy(), g['inter2_out']) < 2e-5
+
+    prop = zptk.AnchorProp(12, 42, 0.1).to(dev)
+    got = prop(zptk.SphericalPointCloud(xyz, fi.detach(), None)).feats
+    assert got.shape == (2, 6, 64, 42) and rel_err(got.cpu().numpy(), g['aprop_out']) < 1e-6
