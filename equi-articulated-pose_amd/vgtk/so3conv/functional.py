@@ -570,13 +570,21 @@ def intra_so3conv(feats, W, intra_idx):
     return _IntraConv.apply(feats, W, intra_idx.to(torch.int32).contiguous())
 
 
+def _aligned16(t):
+    """A contiguous tensor whose first element sits on a 16-byte boundary: `t` itself when it already does, else a copy (a
+    contiguous VIEW into a larger storage -- a slice of autograd's gradient buffer, say -- can start at any 4-byte offset,
+    and the streaming kernels move 16-byte words)."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 class _NarrowContract(torch.autograd.Function):
     """_Contract for at most four output channels (the pose head's translation components, the attention logit): no matrix
     core has work for 1-4 rows, the op is a streaming pass over x in each direction (csrc/narrow_contract.hip)."""
 
     @staticmethod
     def forward(ctx, W, x):
-        W, x = W.contiguous(), x.contiguous()
+        W, x = W.contiguous(), _aligned16(x)
         b, c, n = x.shape
         o = W.shape[0]
         y = torch.empty(b, o, n, dtype=torch.float32, device=x.device)
@@ -587,7 +595,7 @@ class _NarrowContract(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         W, x = ctx.saved_tensors
-        gy = gy.contiguous()
+        gy = _aligned16(gy)
         b, c, n = x.shape
         o = W.shape[0]
         gW = gx = None

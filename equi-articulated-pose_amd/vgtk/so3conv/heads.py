@@ -143,6 +143,13 @@ def orbit_slot_distances(minn_dist_ori_to_recon_all_pts, minn_dist_ori_to_recon,
             wmean(minn_dist_ori_to_recon_all_pts, attn_ori))
 
 
+def _anchor_rows_vectorise(na):
+    """The head kernels of csrc/heads.hip and the per-cloud epilogue of csrc/bn_act.hip move 16-byte words along the anchor
+    axis and keep a point's anchors in one wavefront: anchor counts that are a multiple of 4, at most 64 (12, 20, 60 ...).
+    Other counts (kanchor = 1, 3) take the same expressions as device torch ops."""
+    return na % 4 == 0 and 0 < na <= 64
+
+
 class _SlotMaskedMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask):
@@ -171,7 +178,7 @@ class _MaskedMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask):
-        x, mask = x.contiguous(), mask.contiguous()
+        x, mask = L._aligned16(x), mask.contiguous()                 # 16-byte loads along the anchor axis
         b, c, n, na = x.shape
         out = torch.empty(b, c, na, dtype=torch.float32, device=x.device)
         arg = torch.empty(b, c, na, dtype=torch.int32, device=x.device)
@@ -195,6 +202,8 @@ def masked_max(x, mask):
     pooling over a point subset without the masked copy of x."""
     if x.dtype != torch.float32 or not x.is_cuda:
         raise RuntimeError('masked_max: float32 device tensors only')
+    if not _anchor_rows_vectorise(x.shape[3]):
+        return (x * mask.to(x.dtype).view(x.shape[0], 1, x.shape[2], 1)).max(2)[0]
     return _MaskedMax.apply(x, mask.to(torch.float32))
 
 
@@ -208,6 +217,9 @@ def slot_masked_mean(x, mask):
     if mask.requires_grad:
         raise RuntimeError('slot_masked_mean: the slot weights are treated as data (no gradient reaches them); detach the mask or '
                            'use torch ops for a differentiable soft mask')
+    if not _anchor_rows_vectorise(x.shape[3]) or mask.shape[1] > 8:
+        m = mask.to(torch.float32)
+        return torch.einsum('bcna,bsn->bsca', x, m) / m.sum(-1).clamp(min=1e-8)[:, :, None, None]
     return _SlotMaskedMean.apply(x, mask.to(torch.float32))
 
 
@@ -540,6 +552,29 @@ class _SubsetBNAct(torch.autograd.Function):
         return g_y, g_bias, None, sgx.sum(0).float(), sg.sum(0).float(), None, None, None, None, None, None
 
 
+def _subset_batchnorm_act_torch(y, bias, mask, bn, slope):
+    """_SubsetBNAct as device torch ops, for anchor counts the 16-byte kernels do not take (see _anchor_rows_vectorise)."""
+    b, c, p, na = y.shape
+    if bias is not None:
+        y = y + bias.view(1, c, 1, 1)
+    if bn.training:
+        m = mask.view(b, 1, p, 1)
+        cnt = (mask.sum(1) * na).view(b, 1)
+        ym = y * m
+        mean = ym.sum((2, 3)) / cnt
+        var = ((ym * ym).sum((2, 3)) / cnt - mean * mean).clamp_min(0.0)
+        with torch.no_grad():
+            unb = var * (cnt / (cnt - 1.0).clamp_min(1.0))
+            for i in range(b):                                              # the loop's B momentum updates, in cloud order
+                bn.running_mean.mul_(1.0 - bn.momentum).add_(mean[i], alpha=bn.momentum)
+                bn.running_var.mul_(1.0 - bn.momentum).add_(unb[i], alpha=bn.momentum)
+        mean, var = mean[:, :, None, None], var[:, :, None, None]
+    else:
+        mean, var = bn.running_mean.view(1, c, 1, 1), bn.running_var.view(1, c, 1, 1)
+    z = (y - mean) * torch.rsqrt(var + bn.eps) * bn.weight.view(1, c, 1, 1) + bn.bias.view(1, c, 1, 1)
+    return F.leaky_relu(z, slope) if slope else F.relu(z)
+
+
 def _subset_batchnorm_act(y, bias, mask, bn, slope):
     """act(bn(y + bias)) per cloud subset; y [B,C,P,A] raw contraction output, mask [B,P] float 0/1, slope 0 = relu."""
     if bn.training:
@@ -547,6 +582,8 @@ def _subset_batchnorm_act(y, bias, mask, bn, slope):
             bn.num_batches_tracked.add_(y.shape[0])
     if bn.momentum is None:
         raise NotImplementedError('pose_head_over_subsets: cumulative-average BatchNorm (momentum=None) is not batched')
+    if not _anchor_rows_vectorise(y.shape[3]):
+        return _subset_batchnorm_act_torch(y, bias, mask, bn, slope)
     return _SubsetBNAct.apply(y, bias, mask, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, slope)
 
 

@@ -506,7 +506,7 @@ def test_subset_batchnorm_act_matches_torch(dev, shape, slope):
 
 
 @pytest.mark.parametrize('pooling', ['max', 'mean'])
-def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling):
+def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling, A=60):
     """vgtk.so3conv.pose_head_over_subsets (one call per slot) against the model's inner loop: the head called once per
     cloud, batch 1, on the gathered point subset with mask=None (...pn_38_multi_stage.py:L706-830) -- outputs and
     the BatchNorm running statistics after the pass, training and eval mode."""
@@ -515,7 +515,7 @@ def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling):
     import vgtk.spconv as zptk
     import vgtk.so3conv.functional as L
     torch.manual_seed(3)
-    B, C, N, A = 3, 16, 40, 60
+    B, C, N = 3, 16, 40
     head = sptk.SO3OutBlockRTWithMaskSep({'dim_in': C, 'mlp': [32, 32], 'kanchor': A, 'temperature': 3.0}, norm=1, pooling_method=pooling,
                                          pred_axis=True, pred_pv_points=True, pred_central_points=True).to(dev)
     feats = torch.randn(B, C, N, A, device=dev)
@@ -990,3 +990,38 @@ def test_zp_layers_match_the_reference(dev, golden):
     prop = zptk.AnchorProp(12, 42, 0.1).to(dev)
     got = prop(zptk.SphericalPointCloud(xyz, fi.detach(), None)).feats
     assert got.shape == (2, 6, 64, 42) and rel_err(got.cpu().numpy(), g['aprop_out']) < 1e-6
+
+
+@pytest.mark.parametrize('pooling', ['mean', 'max'])
+def test_pose_head_over_subsets_with_a_single_anchor(dev, pooling):
+    """kanchor = 1 (one anchor per point: rows of 1 float, which the 16-byte head kernels do not take): the batched head
+    falls back to the same expressions as device torch ops and still equals the per-cloud loop."""
+    test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling, A=1)
+
+
+def test_streaming_kernels_take_operands_at_any_4_byte_offset(dev):
+    """The narrow contraction and the masked max move 16-byte words: a contiguous VIEW that starts 4 bytes into its storage
+    (what autograd can hand a backward as its gradient) must give the same results as an aligned copy."""
+    import vgtk.so3conv as sptk
+    import vgtk.so3conv.functional as L
+    gen = torch.Generator().manual_seed(5)
+    b, o, c, n = 2, 3, 24, 240
+    W = torch.randn(o, c, generator=gen).to(dev)
+    store_x = torch.randn(1 + b * c * n, generator=gen).to(dev)
+    store_g = torch.randn(1 + b * o * n, generator=gen).to(dev)
+    x_off, g_off = store_x[1:].view(b, c, n), store_g[1:].view(b, o, n)
+    assert x_off.is_contiguous() and x_off.data_ptr() % 16 == 4 and g_off.data_ptr() % 16 == 4
+    res = []
+    for x, g in ((x_off, g_off), (x_off.clone(), g_off.clone())):
+        Wi, xi = W.clone().requires_grad_(True), x.detach().requires_grad_(True)      # detach() keeps the view's storage offset
+        assert xi.data_ptr() == x.data_ptr()
+        y = L.so3_contract(Wi, xi)
+        gW, gx = torch.autograd.grad(y, [Wi, xi], g)
+        res.append((y.detach(), gW, gx))
+    for a, bb in zip(res[0], res[1]):
+        assert torch.equal(a, bb)
+    f = torch.randn(1 + 2 * 8 * 16 * 60, generator=gen).to(dev)
+    mask = (torch.rand(2, 16, generator=gen) > 0.4).float().to(dev)
+    mask[:, 0] = 1.0
+    v = f[1:].view(2, 8, 16, 60)
+    assert torch.equal(sptk.masked_max(v, mask), sptk.masked_max(v.clone(), mask))
