@@ -383,8 +383,12 @@ def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, war
         StandInLoss.apply(feats, model.pose_head.weight, model.pose_head.bias).backward()
         opt.step()
 
-    for _ in range(warmup):
+    import vgtk.so3conv.functional as L
+    for _ in range(warmup - 1):
         step()
+    L.BACKWARD_LOG = []
+    step()
+    regimes, L.BACKWARD_LOG = L.BACKWARD_LOG, None
     torch.cuda.synchronize()
     _hip.KERNEL_TIMES = []
     t0 = time.perf_counter()
@@ -395,7 +399,8 @@ def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, war
     records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
     kern, _ = summarize_kernels(records)
     top = sorted(kern.items(), key=lambda kv: -kv[1]['ms'])[:4]
-    out = {'clouds_per_gpu': batch, 'points': points, 'pass': 'fwd' if fwd_only else 'fwd+bwd+Adam',
+    out = {'clouds_per_gpu': batch, 'points': points, 'clouds': 'partial (depth-buffer visible)' if partial else 'complete',
+           'backward_regimes': regimes, 'pass': 'fwd' if fwd_only else 'fwd+bwd+Adam',
            'radii_of_input_size': plan_points or points, 'value': batch * steps / dt, 'unit': 'point-clouds/sec',
            'ms_per_step': dt / steps * 1e3, 'steps': steps,
            'top_kernels_ms_per_step': {n: round(k['ms'] / steps, 2) for n, k in top}}

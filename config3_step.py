@@ -138,7 +138,7 @@ class Config3Model(nn.Module):
         entropy = -(torch.softmax(scores, -1) * torch.log_softmax(scores, -1)).sum(-1).mean()
         loss = d1.mean() + d2.mean() + 0.01 * entropy + 1e-3 * centre_reg
         return loss, {'labels': labels, 'slot_R': torch.stack(slot_R, 1), 'slot_T': torch.stack(slot_T, 1), 'glb_orbit': glb_orbit,
-                      'recon': recon, 'conf': conf}
+                      'recon': recon, 'conf': conf, 'scores': scores}
 
 
 def algorithmic_flops(batch, points, plan, head_width=256):

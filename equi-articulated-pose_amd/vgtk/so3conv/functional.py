@@ -407,6 +407,9 @@ def _contract_into(W, x, y, layout):
         _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
 
 
+BACKWARD_LOG = None      # a list while someone wants to know the backward regime of every inter conv (bench.py, tests)
+
+
 class _InterConv(torch.autograd.Function):
     """Fused inter conv  y = W . group(feats)  (functional.py:L1221-1261 + modules.py:L48-55)
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
@@ -477,6 +480,9 @@ class _InterConv(torch.autograd.Function):
             rcap, any_nonident = head.decide()
             if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
                 head = None
+        if BACKWARD_LOG is not None:      # diagnostics for bench.py / tests: which regime each layer's backward took
+            BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(rcap),
+                                 'regime': 'inverse lists' if head is not None else 'textbook dX'})
         Wp = ctx.W_param()
         if Wp is not None:
             _set_keep_x_hint(Wp, head is None)            # the next forward of this layer keeps X iff this backward needed it

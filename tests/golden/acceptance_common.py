@@ -8,8 +8,8 @@ import torch
 NN = 64
 SLOTS = 2                      # --nmasks=2
 ROT_ANGLE_FACTOR = 0.5         # options.py:L210
-CLOUD_SEED = {'cfg1_512': 0, 'p4096': 7}
-SAMPLE_STRIDE = {'cfg1_512': 16, 'p4096': 64}   # every n-th point of the per-point feature maps is kept in the fixture
+CLOUD_SEED = {'cfg1_512': 0, 'p4096': 7, 'parts_512': 21, 'random_512': 22}
+SAMPLE_STRIDE = {'cfg1_512': 16, 'p4096': 64, 'parts_512': 16, 'random_512': 16}   # every n-th point of the per-point feature maps is kept in the fixture
 CH_STRIDE = 16                 # channels kept of the backbone feature map in the fixture
 PARAM_SEED = 2913              # the reference's default seed (options.py:L17)
 
@@ -64,4 +64,33 @@ def seed_scorer(scorer, seed):
     return seed_module(scorer, torch.Generator().manual_seed(int(seed)))
 
 
-MIN_MARGIN = {'cfg1_512': 2e-3, 'p4096': 5e-4}      # 8x more points: the closest pair of scores is 8x closer
+MIN_MARGIN = {'cfg1_512': 2e-3, 'p4096': 5e-4, 'parts_512': 2e-3, 'random_512': 2e-3}      # 8x more points: the closest pair of scores is 8x closer
+
+POINTS = {'cfg1_512': 512, 'p4096': 4096, 'parts_512': 512, 'random_512': 512}
+POSE_KIND = {'cfg1_512': 'identity', 'p4096': 'identity', 'parts_512': 'parts', 'random_512': 'random'}
+POSE_SEED = 4242
+
+
+def _unit_quaternion_rotations(gen, n):
+    q = torch.randn(n, 4, generator=gen)
+    w, x, y, z = (q / q.norm(dim=-1, keepdim=True)).unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).view(n, 3, 3)
+
+
+def case_poses(name, part_labels):
+    """Per-point poses [1,P,4,4] of an acceptance case: identity (what the shipped model feeds), 'parts' = one Haar rotation
+    per rigid part (the articulated-object case: neighbours across the hinge see a non-trivial relative rotation, so the
+    anchor-permutation kernels run), 'random' = one Haar rotation per point.  Seeded; the same on both sides."""
+    import numpy as np
+    p = part_labels.shape[1]
+    pose = torch.eye(4).repeat(1, p, 1, 1)
+    kind = POSE_KIND[name]
+    gen = torch.Generator().manual_seed(POSE_SEED)
+    if kind == 'parts':
+        R = _unit_quaternion_rotations(gen, int(part_labels.max()) + 1)
+        pose[0, :, :3, :3] = R[torch.from_numpy(np.asarray(part_labels[0]))]
+    elif kind == 'random':
+        pose[0, :, :3, :3] = _unit_quaternion_rotations(gen, p)
+    return pose

@@ -16,8 +16,13 @@ produced by RUNNING THE REFERENCE CLASSES on CPU in the build container (through
     R          model_utils.py:L1000-1043 compute_rotation_matrix_from_angle on sigmoid(angle) * pi * rot_angle_factor
                (...pn_38...:L1103-1112)
 
-Two cases:
+Four cases:
   cfg1_512   BASELINE config 1: one 512-point cloud, everything above from the reference classes.
+  parts_512  the same chain on a 512-point cloud whose two rigid parts carry different rotations (per-point pose = the
+             part's rotation): neighbours across the hinge have a non-identity relative rotation, so the reference's 60x60
+             anchor-permutation search (so3conv/functional.py:L1199-1204, 4.2 GB here) returns real permutations --
+             everything from the reference classes.
+  random_512 one Haar rotation per POINT: every neighbour pair is permuted.
   p4096      one 4096-point cloud at full widths.  The reference's grouping materialises a [P,64,60,60,3,3]
              intermediate (34 GB at P = 4096), so the three conv layers of THIS case come from oracle/so3_ref.py
              (the slab-wise restatement, itself pinned against the reference by tests/test_oracle_golden.py) with the
@@ -75,6 +80,7 @@ def run_case(name, P, plan_points):
     from oracle import so3_ref
     t0 = time.time()
     xyz, part, pose = synth_clouds.laptop_batch(AC.CLOUD_SEED[name], 1, P)
+    pose = AC.case_poses(name, part).numpy()
     xyz_t, pose_t = torch.from_numpy(xyz), torch.from_numpy(pose)
     layers = synth_clouds.backbone_layers(plan_points)
 
@@ -93,7 +99,7 @@ def run_case(name, P, plan_points):
         h.train()
 
     with torch.no_grad():
-        if name == 'cfg1_512':
+        if P <= 512:
             x = BLK.preprocess_input(xyz_t, 60, pose_t, False)
             feats = backbone(x).feats
         else:
@@ -134,7 +140,7 @@ def run_case(name, P, plan_points):
             out[f'slot{s_}_central_points'] = res['central_points'].numpy().copy()
     print(f'{name}: labels {np.bincount(labels.numpy().ravel(), minlength=AC.SLOTS).tolist()}, min score margin {margin:.3e}, '
           f'|feats| max {feats.abs().max().item():.3f}, {time.time() - t0:.0f} s')
-    arrs = {'xyz': xyz, 'pose_is_identity': np.array(1), 'labels': labels.numpy().astype(np.int64), 'scores': scores.numpy(),
+    arrs = {'xyz': xyz, 'pose_is_identity': np.array(int(AC.POSE_KIND[name] == 'identity')), 'pose_rotations': pose[:, :, :3, :3].copy(), 'labels': labels.numpy().astype(np.int64), 'scores': scores.numpy(),
             'min_margin': np.array(margin), 'scorer_seed': np.array(scorer_seed), 'ppinv_sample': ppinv[:, :, ::AC.SAMPLE_STRIDE[name]].numpy().copy(),
             'conf_sample': conf[:, ::AC.SAMPLE_STRIDE[name]].numpy().copy(),
             'feats_sample': feats[:, ::AC.CH_STRIDE, ::AC.SAMPLE_STRIDE[name]].numpy().copy(),
@@ -146,6 +152,6 @@ def run_case(name, P, plan_points):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['cfg1_512', 'p4096']
+    which = sys.argv[1:] or ['cfg1_512', 'p4096', 'parts_512', 'random_512']
     for n in which:
-        run_case(n, {'cfg1_512': 512, 'p4096': 4096}[n], {'cfg1_512': 512, 'p4096': 4096}[n])
+        run_case(n, AC.POINTS[n], AC.POINTS[n])

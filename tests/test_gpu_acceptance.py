@@ -6,7 +6,9 @@ pose matrices within 1e-4 rel on the same synthetic clouds"), end to end through
     csrc/heads.hip) -> per-point invariant features -> linear slot scorer -> arg-max labels
     (...pn_38_multi_stage.py:L608-626)   and   -> SO3OutBlockRTWithMaskSep per slot -> angle -> R, T (L1103-1123).
 
-Expected values: tests/golden/acceptance_{cfg1_512,p4096}.npz, produced by tests/golden/make_golden_acceptance.py by
+Expected values: tests/golden/acceptance_{cfg1_512,p4096,parts_512,random_512}.npz (the last two: a 512-point cloud whose two
+rigid parts / whose points carry different rotations, so the reference's 60x60 anchor-permutation search returns real
+permutations and the product's permuted-pose kernels run end to end), produced by tests/golden/make_golden_acceptance.py by
 running the REFERENCE classes on CPU in the build container (cfg1_512: every stage; p4096: conv layers from the pinned
 slab-wise oracle because the reference's own grouping needs 34 GB there, everything else the reference classes).
 Bars: labels torch.equal; R, T, axis, central points <= 1e-4 (max error / max magnitude); the sampled intermediate
@@ -52,15 +54,21 @@ class _Backbone(torch.nn.Module):
         return x.feats
 
 
-@pytest.mark.parametrize('name,P', [('cfg1_512', 512), ('p4096', 4096)])
-def test_labels_exact_and_poses_within_1e4(golden, name, P):
+@pytest.mark.parametrize('name', ['cfg1_512', 'p4096', 'parts_512', 'random_512'])
+def test_labels_exact_and_poses_within_1e4(golden, name):
     import synth_clouds
     import vgtk.so3conv as sptk
     import vgtk.spconv as zptk
     dev = torch.device('cuda:0')
     g = golden(f'acceptance_{name}.npz')
-    xyz, _, pose = synth_clouds.laptop_batch(AC.CLOUD_SEED[name], 1, P)
+    P = AC.POINTS[name]
+    xyz, part, _ = synth_clouds.laptop_batch(AC.CLOUD_SEED[name], 1, P)
     assert np.array_equal(xyz, g['xyz']), 'synthetic cloud differs from the one the fixture was made on'
+    # identity poses (what the shipped model feeds), one rotation per rigid part, or one per point: the last two send the
+    # clouds through the anchor-permutation kernels (csrc/so3_inter_mfma.hip forward, csrc/so3_inter_inv.hip), end to end
+    pose = AC.case_poses(name, part).numpy()
+    if 'pose_rotations' in g:
+        assert np.array_equal(pose[:, :, :3, :3], g['pose_rotations']), 'seeded poses differ from the fixture generator\'s'
 
     backbone = _Backbone(sptk, synth_clouds.backbone_layers(P))
     inv = sptk.InvPPOutBlockOurs(AC.OUTBLOCK, norm=1, pooling_method='attention')

@@ -60,7 +60,7 @@ def make_poses(gen, kinds, labels, p):
 
 
 def slab_check(dev, monkeypatch, P, layer, kinds, mode, slabs, q=64, layout='transposed', seed=50,
-               plan_points=None, chans=None, tol=(2e-5, 2e-5, 5e-5)):
+               plan_points=None, chans=None, tol=(2e-5, 2e-5, 5e-5), partial=False):
     """Run layer `layer` of the P-point backbone on len(kinds) clouds on the GPU and compare the slabs
     `slabs` = [(cloud, first query point)] of `q` query points with the oracle: y, dF, dW."""
     import synth_clouds
@@ -73,7 +73,7 @@ def slab_check(dev, monkeypatch, P, layer, kinds, mode, slabs, q=64, layout='tra
     c, o, radius, sigma = synth_clouds.backbone_layers(plan_points or P)[layer]
     if chans is not None:
         c, o = chans
-    xyz_np, lab, _ = synth_clouds.laptop_batch(seed, B, P)
+    xyz_np, lab, _ = synth_clouds.laptop_batch(seed, B, P, partial=partial)
     gen = torch.Generator().manual_seed(seed)
     pose = make_poses(gen, kinds, lab, P)
     xyz = T(xyz_np)
@@ -142,10 +142,12 @@ def test_4096_batch16_deepest_layer(dev, monkeypatch):
     slab_check(dev, monkeypatch, 4096, 2, ['identity'] * 16, 'auto', [(0, 0), (15, 4032)], seed=60)
 
 
-# ---- config 5: 8192-point partial clouds ---------------------------------------------------------------
+# ---- config 5: 8192-point PARTIAL clouds (MotionHOIDatasetPartial shape: only the surfaces facing the camera, at twice
+# the density of a complete cloud) and, for comparison, complete clouds of the same size ---------------------------------
+@pytest.mark.parametrize('partial', [True, False])
 @pytest.mark.parametrize('layer', [0, 1, 2])
-def test_8192_layers(dev, monkeypatch, layer):
-    slab_check(dev, monkeypatch, 8192, layer, ['identity', 'parts'], 'auto', [(0, 5000), (1, 8128)], q=32, seed=70)
+def test_8192_layers(dev, monkeypatch, layer, partial):
+    slab_check(dev, monkeypatch, 8192, layer, ['identity', 'parts'], 'auto', [(0, 5000), (1, 8128)], q=32, seed=70, partial=partial)
 
 
 # ---- the 'dx' regime of the benchmark (512-point radii: more than a quarter of the rows referenced) -----
@@ -215,7 +217,8 @@ def test_chamfer_config3_shape(dev):
     assert rel_err(t1.grad.cpu().numpy(), r1) < 1e-5 and rel_err(t2.grad.cpu().numpy(), r2) < 1e-5
 
 
-def test_bench_configuration_properties(dev):
+@pytest.mark.parametrize('P,partial', [(4096, False), (8192, True)])
+def test_bench_configuration_properties(dev, P, partial):
     """The benchmark configuration ITSELF (BASELINE config 1 at scale: 8 x 4096-point clouds, the 3-block inter backbone
     1 -> 64 -> 128 -> 512 with its fused BatchNorm + leaky_relu epilogues, exactly bench.py's model) through size-independent
     properties -- the oracle cannot run this size:
@@ -228,8 +231,8 @@ def test_bench_configuration_properties(dev):
     import synth_clouds
     import vgtk.so3conv.functional as L
     from vgtk.functional import anchor_group_tables
-    B, P = 8, 4096
-    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, B, P)
+    B = 8                    # (8 x 4096 complete clouds: configs 2-4 per GPU; 8 x 8192 partial clouds: config 5 per GPU)
+    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, B, P, partial=partial)
     xyz, pose = T(xyz_np).to(dev), T(pose_np).to(dev)
     torch.manual_seed(2913)
     model = bench.Backbone(P).to(dev)
@@ -258,6 +261,7 @@ def test_bench_configuration_properties(dev):
         return (out.double() * probe.double()).sum() / P, out
 
     grads = []
+    L.BACKWARD_LOG = []
     for trial in range(2):
         model.zero_grad(set_to_none=True)
         loss, out = loss_of()
@@ -267,6 +271,10 @@ def test_bench_configuration_properties(dev):
     for a, b in zip(grads[0], grads[1]):          # (the stand-in pose head's layer is not reached by this functional: no gradient)
         assert (a is None and b is None) or torch.equal(a, b), 'forward / backward of the benchmark configuration is not bit-reproducible'
     del grads[1]
+    regimes, L.BACKWARD_LOG = L.BACKWARD_LOG, None
+    print(f'backward regimes at {B} x {P}' + (' partial' if partial else '') + ': ' +
+          '; '.join(f"{r['channels']}: {r['referenced_rows_max']} of {r['support_rows']} rows -> {r['regime']}" for r in regimes[:3]))
+    assert len(regimes) >= 4 and all(r['referenced_rows_max'] <= r['support_rows'] for r in regimes)
     params = dict(model.named_parameters())
     for name in ('convs.0.basic_conv.W', 'convs.2.basic_conv.W'):
         w = params[name]

@@ -59,6 +59,52 @@ def test_config3_composite_step_trains():
     np.testing.assert_allclose(losses[0], losses[1], rtol=5e-2)
 
 
+def test_config3_composite_step_at_full_size():
+    """BASELINE config 3 at ITS size -- 16 x 4096-point clouds, full widths (1 -> 64 -> 128 -> 512, head width 256): the step
+    bench.py times as `config3_step` (~0.9 s, ~92 GB).  Every trained parameter receives a finite gradient, the frozen
+    stage none, the forward is bit-reproducible down to the pre-arg-max slot scores and the pose hypotheses, the rotations are
+    orthonormal, and the loss falls over three optimiser steps."""
+    import synth_clouds
+    import config3_step as C3
+    dev = torch.device('cuda:0')
+    P, B = 4096, 16
+    xyz, _, pose = synth_clouds.laptop_batch(0, B, P)
+    xyz, pose = T(xyz).to(dev), T(pose).to(dev)
+    torch.manual_seed(2913)
+    model = C3.Config3Model(P).to(dev)
+    params = model.trained_parameters()
+    opt = torch.optim.Adam(params, lr=2e-3)
+    with torch.no_grad():
+        first = model(xyz, pose)
+        l0, o0 = float(first[0]), {k: first[1][k].clone() for k in ('scores', 'slot_R', 'slot_T', 'labels', 'recon')}
+        del first
+        # (training-mode BatchNorms only move their running statistics between the two calls; the batch statistics they
+        # normalise with are the same)
+        again = model(xyz, pose)
+        assert float(again[0]) == l0
+        for k, v in o0.items():
+            assert torch.equal(again[1][k], v), k
+        del again
+    RtR = torch.matmul(o0['slot_R'].transpose(-1, -2), o0['slot_R'])
+    assert (RtR - torch.eye(3, device=dev)).abs().max().item() < 1e-4
+    assert o0['labels'].shape == (B, P) and o0['slot_T'].shape == (B, C3.SLOTS, 60, 3)
+    hist = []
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss, out = model(xyz, pose)
+        loss.backward()
+        if it == 0:
+            missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+            assert not missing, missing
+            assert all(torch.isfinite(p.grad).all() for p in params)
+            assert all(p.grad is None for p in model.glb_backbone.parameters())
+        opt.step()
+        hist.append(loss.item())
+        del loss, out
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+    assert torch.cuda.max_memory_allocated(dev) < 200 * 2 ** 30
+
+
 def test_separable_block_at_4096_points_full_width_vs_oracle():
     """The deepest separable block (128 -> 512 inter conv, IntraSO3Conv at C = 512, InstanceNorm + leaky_relu, 1x1 skip
     + BatchNorm + leaky_relu, sum) on ONE 4096-point cloud: the inter and intra convolutions against the oracle on a slab
