@@ -67,7 +67,7 @@ int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, i
 // blocks); group_lists2_preferred: the channel count fills the wider blocks and the variant has not been switched off
 // with eap_so3_group_lists_tiles(1)
 bool group_lists2_preferred(int c, int na, int ks, int layout);
-// csrc/so3_inter_lists3.hip: the same on the bf16 matrix cores (3 x bf16 split operands, fp32 accumulate)
+#ifdef EAP_EXPERIMENTS   // tools/experiments/kernels/so3_inter_lists3.hip (`make EXPERIMENTS=1`): the same on the bf16 matrix cores (3 x bf16 split operands)
 bool group_lists3_preferred(int c, int na, int ks, int layout);
 int group_lists3_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                      const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
@@ -75,6 +75,7 @@ int group_lists3_fwd(int b, int c, int p, int n, int nn, int na, int ks, float s
 int group_lists3_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
                      const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
                      const float *ent_gx, const float *rk, float *z, hipStream_t s);
+#endif
 int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                      const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
                      hipStream_t s);
@@ -87,11 +88,13 @@ bool inter_zpconv_rows_supported(int np, int nq, int na, int ks, int nn, int c);
 int inter_zpconv_rows_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx, const float *w,
                           const float *feats, float *out, const int32_t *only_flagged, hipStream_t s);
 // csrc/zpconv_mfma.hip: the same op on the matrix cores for clouds with one neighbour list per point (skip[b] == 0)
+#ifdef EAP_EXPERIMENTS   // tools/experiments/kernels/zpconv_mfma2.hip
 int zp_fwd_kernel();                                                                   // eap_inter_zpconv_fwd_kernel's setting
 bool inter_zpconv_mfma2_supported(int np, int nq, int na, int ks, int nn, int c);     // csrc/zpconv_mfma2.hip
 
 int inter_zpconv_mfma2_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx0, const float *w,
                            const float *feats, const int32_t *skip, float *out, hipStream_t s);
+#endif
 bool inter_zpconv_mfma_supported(int np, int nq, int na, int ks, int nn, int c);
 int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, const int32_t *idx0, const float *w,
                           const float *feats, const int32_t *skip, float *out, hipStream_t s);

@@ -280,10 +280,14 @@ int launch(bool ta, bool tb, const GemmArgs &g, int zcount, hipStream_t s) {
     return eap::check_launch("gemm_f32");
 }
 
-int tile_config() {   // dev knob: EAP_GEMM_TILE = 0 (128x128) | 1 (256x128, default: +2% on the L2-layer shape) | 2 (128x256)
+int tile_config() {   // 0 (128x128) | 1 (256x128, default: +2% on the L2-layer shape) | 2 (128x256) | 3 (256x256)
+#ifdef EAP_ABLATION      // only in a library built with `make ABLATION=1`; a production build never reads the variable
     static int cfg = -1;
     if (cfg < 0) { const char *e = getenv("EAP_GEMM_TILE"); cfg = e ? atoi(e) : 1; }
     return cfg;
+#else
+    return 1;
+#endif
 }
 
 int run(bool ta, bool tb, GemmArgs g, int zcount, hipStream_t s) {

@@ -351,9 +351,12 @@ static int group_fwd_dispatch(int blocked, int b, int c, int p, int n, int nn, i
         // both kernels are launched and each skips the other's clouds -- no host round trip.
         const bool lists = eap::group_lists_supported(na, ks) && (long long)c * n * na < (1ll << 31);
         if (lists && (!mult || nonident)) {
-            int e = eap::group_lists3_preferred(c, na, ks, blocked)
-                        ? eap::group_lists3_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream))
-                        : eap::group_lists2_preferred(c, na, ks, blocked)
+            int e =
+#ifdef EAP_EXPERIMENTS
+                    eap::group_lists3_preferred(c, na, ks, blocked)
+                        ? eap::group_lists3_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream)) :
+#endif
+                    eap::group_lists2_preferred(c, na, ks, blocked)
                         ? eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream))
                         : eap::group_lists_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream));
             if (e || !mult) return e;

@@ -559,8 +559,10 @@ extern "C" int eap_so3_inter_group_inv_pitch_f32(int b, int o, int p, int nn, in
                                                  float *z, eap_stream_t stream) {
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (!eap::group_lists_supported(na, ks)) return eap::bad_arg("so3_inter_group_inv_pitch: unsupported anchor / kernel-point count");
+#ifdef EAP_EXPERIMENTS
     if (eap::group_lists3_preferred(o, na, ks, 0))
         return eap::group_lists3_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
+#endif
     if (eap::group_lists2_preferred(o, na, ks, 0))
         return eap::group_lists2_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
     return eap::group_lists_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
@@ -580,8 +582,10 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
     hipStream_t s = eap::S(stream);
     // no anchor permutation: the two-workgroups-per-CU kernel of csrc/so3_inter_lists.hip
     if (!multinv && eap::group_lists_supported(na, ks)) {
+#ifdef EAP_EXPERIMENTS
         if (eap::group_lists3_preferred(o, na, ks, 0))
             return eap::group_lists3_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
+#endif
         if (eap::group_lists2_preferred(o, na, ks, 0))
             return eap::group_lists2_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
         return eap::group_lists_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);

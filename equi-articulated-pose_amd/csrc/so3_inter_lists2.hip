@@ -420,10 +420,14 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
 static int g_tiles = 2;       // eap_so3_group_lists_tiles
 
 // A/B and test switch: 1 = always the one-tile kernel of csrc/so3_inter_lists.hip, 2 = two tiles where they pay (default),
-// 3 = the 3 x bf16 split kernel of csrc/so3_inter_lists3.hip where two tiles pay (measured slower on real neighbour lists: the
-// grouping is bound by the L2 -> LDS gather, not by the matrix pipe); 0 = query.  Returns the value in force.  Process-wide, not thread-safe (set it before launching).
+// (3 = the 3 x bf16 split kernel of tools/experiments/kernels/so3_inter_lists3.hip, in `make EXPERIMENTS=1` builds only: measured
+// slower on real neighbour lists, the grouping is bound by the L2 -> LDS gather, not by the matrix pipe); 0 = query.  Returns the value in force.  Process-wide, not thread-safe (set it before launching).
 extern "C" int eap_so3_group_lists_tiles(int tiles) {
+#ifdef EAP_EXPERIMENTS
     if (tiles >= 1 && tiles <= 3) g_tiles = tiles;
+#else
+    if (tiles >= 1 && tiles <= 2) g_tiles = tiles;
+#endif
     return g_tiles;
 }
 
@@ -445,9 +449,11 @@ bool group_lists2_preferred(int c, int na, int ks, int layout) {
     return c >= CB && (rem == 0 || rem > 32);
 }
 
-// mode 3 (eap_so3_group_lists_tiles): the 3 x bf16 split kernel of csrc/so3_inter_lists3.hip wherever the two-tile kernel
-// would run
+#ifdef EAP_EXPERIMENTS
+// mode 3 (eap_so3_group_lists_tiles, `make EXPERIMENTS=1` builds only): the 3 x bf16 split kernel of
+// tools/experiments/kernels/so3_inter_lists3.hip wherever the two-tile kernel would run
 bool group_lists3_preferred(int c, int na, int ks, int layout) { return g_tiles == 3 && group_lists2_preferred(c, na, ks, layout); }
+#endif
 
 int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                      const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,

@@ -421,9 +421,12 @@ extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks
     if (e) return e;
     e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, idx0, nullptr, flag, s);
     if (e) return e;
-    const int which = eap::zp_fwd_kernel();
-    if (which == 2 && eap::inter_zpconv_mfma2_supported(np, nq, na, ks, ann, c)) e = eap::inter_zpconv_mfma2_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
-    else e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
+#ifdef EAP_EXPERIMENTS   // `make EXPERIMENTS=1`: the 32-neighbour re-cut of tools/experiments/kernels/zpconv_mfma2.hip behind eap_inter_zpconv_fwd_kernel(2)
+    if (eap::zp_fwd_kernel() == 2 && eap::inter_zpconv_mfma2_supported(np, nq, na, ks, ann, c))
+        e = eap::inter_zpconv_mfma2_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
+    else
+#endif
+    e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
     if (e) return e;
     return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, flag, s);
 }

@@ -30,6 +30,7 @@ lib.eap_gemm_f32_reduce_workspace.restype = ctypes.c_int64
 lib.eap_so3_inter_group_bwd_workspace.restype = ctypes.c_int64
 lib.eap_inter_zpconv_fwd_workspace.restype = ctypes.c_int64
 lib.eap_inter_zpconv_bwd_workspace.restype = ctypes.c_int64
+lib.eap_inter_zpconv_bwd_hot_workspace.restype = ctypes.c_int64
 lib.eap_bn_act_segments.restype = ctypes.c_int
 
 _I64 = ctypes.c_int64

@@ -44,27 +44,63 @@ def inter_zpconv_backward(idx, w, grad, npoint):
     c = grad.shape[1]
     out = torch.empty(b, c, int(npoint), na, dtype=grad.dtype, device=grad.device)
     if grad.dtype == torch.float32 and b > 0:
-        # atomics-free path (csrc/zpconv_bwd.hip): scratch for the per-(point, neighbour) products, a few clouds at a time
-        per_cloud = int(_hip.lib.eap_inter_zpconv_bwd_workspace(1, np_, int(npoint), na, ann, c))
-        step = min(b, BWD_WORKSPACE_BYTES // max(per_cloud, 1))
-        ws = None
-        if step >= 1:
-            try:
-                ws = torch.empty((int(_hip.lib.eap_inter_zpconv_bwd_workspace(step, np_, int(npoint), na, ann, c)) + 3) // 4,
-                                 dtype=torch.int32, device=grad.device)
-            except torch.cuda.OutOfMemoryError:
-                ws = None
-        if ws is None:
-            _hip.call('eap_inter_zpconv_bwd_f32', out, b, np_, int(npoint), na, ks, ann, c,
-                      _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
+        # 1. scatter target on chip (csrc/zpconv_bwd_hot.hip): clouds whose lists reference few support rows, whole batch
+        #    in one launch, nothing but the operands moves; the per-cloud status comes back in one small read
+        todo = _backward_on_chip(idx, w, grad, out)
+        if not todo:
             return out
-        for b0 in range(0, b, step):
-            nb = min(step, b - b0)
-            _hip.call('eap_inter_zpconv_bwd_ws_f32', out, nb, np_, int(npoint), na, ks, ann, c, _hip._ptr(idx[b0:b0 + nb]),
-                      _hip._ptr(w[b0:b0 + nb]), _hip._ptr(grad[b0:b0 + nb]), _hip._ptr(out[b0:b0 + nb]), _hip._ptr(ws))
-        return out
+        if len(todo) < b:
+            for i in todo:
+                out[i:i + 1] = _backward_with_products(idx[i:i + 1], w[i:i + 1], grad[i:i + 1], int(npoint))
+            return out
+        return _backward_with_products(idx, w, grad, int(npoint), out)
     _hip.call('eap_inter_zpconv_bwd_' + _hip.suffix(grad), out, b, np_, int(npoint), na, ks, ann, c,
               _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
+    return out
+
+
+ON_CHIP_BACKWARD = True     # False: always the product pipeline of csrc/zpconv_bwd.hip (A/B runs, tests)
+
+
+def _backward_on_chip(idx, w, grad, out):
+    """-> clouds still to do (all of them when the shape is not taken)."""
+    b, np_, na, ks, ann = idx.shape
+    c, nq = grad.shape[1], out.shape[2]
+    nbytes = int(_hip.lib.eap_inter_zpconv_bwd_hot_workspace(b, np_, nq, na, ks, ann, c)) if ON_CHIP_BACKWARD else 0
+    if nbytes <= 0 or any(t.data_ptr() % 16 for t in (idx, w, grad, out)):
+        return list(range(b))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=grad.device)
+    status = torch.empty(b, dtype=torch.int32, device=grad.device)
+    _hip.call('eap_inter_zpconv_bwd_hot_f32', out, b, np_, nq, na, ks, ann, c, _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad),
+              _hip._ptr(out), _hip._ptr(ws), _hip._ptr(status))
+    return [i for i, s in enumerate(status.tolist()) if s != 0]
+
+
+def _backward_with_products(idx, w, grad, npoint, out=None):
+    """csrc/zpconv_bwd.hip: products in forward order + sorted sums (any number of referenced rows), scratch-free scatter
+    kernel when no scratch can be had."""
+    b, np_, na, ks, ann = idx.shape
+    c = grad.shape[1]
+    if out is None:
+        out = torch.empty(b, c, npoint, na, dtype=grad.dtype, device=grad.device)
+    # atomics-free path (csrc/zpconv_bwd.hip): scratch for the per-(point, neighbour) products, a few clouds at a time
+    per_cloud = int(_hip.lib.eap_inter_zpconv_bwd_workspace(1, np_, int(npoint), na, ann, c))
+    step = min(b, BWD_WORKSPACE_BYTES // max(per_cloud, 1))
+    ws = None
+    if step >= 1:
+        try:
+            ws = torch.empty((int(_hip.lib.eap_inter_zpconv_bwd_workspace(step, np_, int(npoint), na, ann, c)) + 3) // 4,
+                             dtype=torch.int32, device=grad.device)
+        except torch.cuda.OutOfMemoryError:
+            ws = None
+    if ws is None:
+        _hip.call('eap_inter_zpconv_bwd_f32', out, b, np_, int(npoint), na, ks, ann, c,
+                  _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad), _hip._ptr(out))
+        return out
+    for b0 in range(0, b, step):
+        nb = min(step, b - b0)
+        _hip.call('eap_inter_zpconv_bwd_ws_f32', out, nb, np_, int(npoint), na, ks, ann, c, _hip._ptr(idx[b0:b0 + nb]),
+                  _hip._ptr(w[b0:b0 + nb]), _hip._ptr(grad[b0:b0 + nb]), _hip._ptr(out[b0:b0 + nb]), _hip._ptr(ws))
     return out
 
 

@@ -92,12 +92,6 @@ int64_t eap_inter_zpconv_fwd_workspace(int b, int np, int ann);
 int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c,
                                 const int32_t *idx, const float *w, const float *feats, float *out,
                                 void *workspace, eap_stream_t stream);
-/* matrix kernel of eap_inter_zpconv_fwd_ws_f32: 1 (default) = csrc/zpconv_mfma.hip; 2 = csrc/zpconv_mfma2.hip (32-neighbour
- * weight blocks: every 128-byte line of w consumed in one visit -- a third less traffic, measured not faster) where the
- * neighbour count is 64 or 128.
- * Returns the previous setting; other values only query.  Same results to rounding (the neighbour sums associate
- * differently); for A/B runs and tests. */
-int eap_inter_zpconv_fwd_kernel(int which);
 /* inter_zpconv_backward: zpconv_cuda.cpp:L58-75, kernel .cu:L77-116.
  * grad [b,c,ks,np,na] -> gfeats [b,c,nq,na]. */
 int eap_inter_zpconv_bwd_f32(int b, int np, int nq, int na, int ks, int ann, int c,
@@ -115,6 +109,18 @@ int64_t eap_inter_zpconv_bwd_workspace(int b, int np, int nq, int na, int ann, i
 int eap_inter_zpconv_bwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c,
                                 const int32_t *idx, const float *w, const float *grad, float *gfeats,
                                 void *workspace, eap_stream_t stream);
+/* The same op (zpconv_cuda.cpp:L58-75) with the scatter target held in LDS -- no per-(point, neighbour) intermediate
+ * (csrc/zpconv_bwd_hot.hip): for clouds whose index is one neighbour list per point AND whose lists reference at most
+ * eap_inter_zpconv_bwd_hot_rows() distinct support rows (large balls under the reference's first-nsample-in-index-order
+ * ball query), every (cloud, anchor quad, 32 channels) accumulates its rows on chip and writes them once; sums in a fixed
+ * order, no atomics on global memory.  status[i] (device, int32 [b]) = 0: cloud i done; 1: untouched apart from being
+ * zeroed -- hand it to eap_inter_zpconv_bwd_ws_f32.  eap_inter_zpconv_bwd_hot_workspace returns 0 for shapes this
+ * path does not take (ks != 24, ann != 64, na or c not multiples of 4 / 32); workspace 256-byte aligned. */
+int eap_inter_zpconv_bwd_hot_rows(void);
+int64_t eap_inter_zpconv_bwd_hot_workspace(int b, int np, int nq, int na, int ks, int ann, int c);
+int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int ks, int ann, int c,
+                                 const int32_t *idx, const float *w, const float *grad, float *gfeats,
+                                 void *workspace, int32_t *status, eap_stream_t stream);
 /* intra_zpconv_forward: zpconv_cuda.cpp:L77-92, kernel .cu:L120-156.
  * idx [na_out,ann], w [na_out,ks,ann], feats [b,c,np,na_in] -> out [b,c,ks,np,na_out]. */
 int eap_intra_zpconv_fwd_f32(int b, int np, int na_in, int na_out, int ks, int ann, int c,
@@ -197,10 +203,10 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
 
 /* Which entry-list grouping kernel serves eap_so3_inter_group_fwd*_f32 / eap_so3_inter_group_inv*_f32 when no anchor
  * permutation is in play: 2 (default) = the fp32-MFMA kernel with two channel tiles per wave where the channel count fills
- * 64-channel blocks (csrc/so3_inter_lists2.hip), 1 = always the one-tile fp32-MFMA kernel (csrc/so3_inter_lists.hip),
- * 3 = products on the bf16 matrix cores from exact 3 x bf16 splits of the fp32 operands, fp32 accumulate
- * (csrc/so3_inter_lists3.hip; an experiment: correct, slower on real neighbour lists); 0 = query.  Returns the value in force.  1 and 2 agree bit for bit, 3 with them to fp32
- * rounding (tests compare them). */
+ * 64-channel blocks (csrc/so3_inter_lists2.hip), 1 = always the one-tile fp32-MFMA kernel (csrc/so3_inter_lists.hip);
+ * 0 = query.  Returns the value in force.  1 and 2 agree bit for bit (tests compare them).  (Measured-slower experiments --
+ * a 3 x bf16 split grouping kernel, a re-cut zpconv forward -- live in tools/experiments/kernels/ and are compiled in by
+ * `make EXPERIMENTS=1` only.) */
 int eap_so3_group_lists_tiles(int tiles);
 /* forward grouping of clouds WITH anchor permutations: 1 (default) = the entry-list kernel of csrc/so3_inter_inv.hip in its
  * forward mode (global -> LDS DMA rows), 0 = the register-staged kernel of csrc/so3_inter_mfma.hip (round 1); returns the

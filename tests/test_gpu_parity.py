@@ -757,8 +757,11 @@ def test_inter_zpconv_matrix_path_edges(dev):
     import vgtk.cuda.zpconv as Z
     from vgtk import _hip as _h
     rng = np.random.default_rng(11)
-    for which_fwd in (1, 2):       # 2: 64 / 128 neighbours take csrc/zpconv_mfma2.hip (the others the first kernel)
-        _h.lib.eap_inter_zpconv_fwd_kernel(which_fwd)
+    # (in a `make EXPERIMENTS=1` library the same cases also run on the 32-neighbour re-cut of tools/experiments/kernels/zpconv_mfma2.hip)
+    experiments = hasattr(_h.lib, 'eap_inter_zpconv_fwd_kernel')
+    for which_fwd in ((1, 2) if experiments else (1,)):
+        if experiments:
+            _h.lib.eap_inter_zpconv_fwd_kernel(which_fwd)
         for (b, p, q, a, k, ann, c) in ((1, 1, 5, 60, 24, 64, 64), (2, 5, 9, 60, 24, 16, 80), (1, 11, 3, 28, 24, 32, 16),
                                       (1, 1, 1, 4, 24, 4, 16), (3, 3, 5, 60, 24, 12, 16),       # scratch chunks far from 256-byte multiples
                                       # csrc/zpconv_mfma2.hip (64 / 128 neighbours): runs of 8 + 8 + 3 points with a partial second
@@ -775,24 +778,26 @@ def test_inter_zpconv_matrix_path_edges(dev):
             g = rng.standard_normal(ref.shape).astype(np.float32)
             got = Z.inter_zpconv_backward(T(idx).to(dev), T(w).to(dev), T(g).to(dev), q).cpu().numpy()
             assert rel_err(got, native.inter_zpconv_backward(idx, w, g, q)) < 1e-5, (b, p, q, a, k, ann, c)
-    _h.lib.eap_inter_zpconv_fwd_kernel(1)
-    # the two matrix kernels against each other at a benchmark-like shape, and a batch that mixes a broadcast-index cloud
-    # with an arbitrary 5-D index (served by csrc/zpconv_rows.hip)
+    if experiments:
+        _h.lib.eap_inter_zpconv_fwd_kernel(1)
+    # a benchmark-like shape, and a batch that mixes a broadcast-index cloud with an arbitrary 5-D index (served by
+    # csrc/zpconv_rows.hip)
     from vgtk import _hip
     b, p, q, a, k, ann, c = 2, 64, 64, 60, 24, 64, 128
     idx = np.broadcast_to(rng.integers(0, q, (b, p, 1, 1, ann)), (b, p, a, k, ann)).astype(np.int32).copy()
     w = rng.random((b, p, a, k, ann)).astype(np.float32)
     feats = rng.standard_normal((b, c, q, a)).astype(np.float32)
     outs = {}
-    for which in (2, 1):
-        was = _hip.lib.eap_inter_zpconv_fwd_kernel(which)
+    for which in ((2, 1) if experiments else (1,)):
+        was = _hip.lib.eap_inter_zpconv_fwd_kernel(which) if experiments else 1
         try:
             outs[which] = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
         finally:
-            _hip.lib.eap_inter_zpconv_fwd_kernel(was)
-    assert _hip.lib.eap_inter_zpconv_fwd_kernel(0) == 1
+            if experiments:
+                _hip.lib.eap_inter_zpconv_fwd_kernel(was)
     ref = native.inter_zpconv_forward(idx, w, feats)
-    assert rel_err(outs[2], ref) < 2e-6 and rel_err(outs[1], ref) < 2e-6 and rel_err(outs[2], outs[1]) < 2e-6
+    for got in outs.values():
+        assert rel_err(got, ref) < 2e-6
     idx[1, 3, 7, 5, :] = (idx[1, 3, 7, 5, :] + 1) % q                 # cloud 1: one (a, k) row differs -> arbitrary-index path
     out = Z.inter_zpconv_forward(T(idx).to(dev), T(w).to(dev), T(feats).to(dev)).cpu().numpy()
     assert rel_err(out, native.inter_zpconv_forward(idx, w, feats)) < 2e-6
@@ -862,7 +867,8 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
     out = {}
     assert _hip.lib.eap_so3_group_lists_tiles(0) == 2
     try:
-        for tiles in (1, 2, 3):
+        modes = (1, 2, 3) if _hip.lib.eap_so3_group_lists_tiles(3) == 3 else (1, 2)     # 3: `make EXPERIMENTS=1` libraries only
+        for tiles in modes:
             assert _hip.lib.eap_so3_group_lists_tiles(tiles) == tiles
             out[tiles] = (_hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma),
                           _hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma, blocked=2),
@@ -871,11 +877,12 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
         _hip.lib.eap_so3_group_lists_tiles(2)
     for a, bb, what in zip(out[1], out[2], ('forward', 'forward, transposed', 'backward Z')):
         assert torch.equal(a, bb), what
-    # mode 3 (csrc/so3_inter_lists3.hip: the same products on the bf16 matrix cores from exact 3 x bf16 splits of the fp32
+    # mode 3 (tools/experiments/kernels/so3_inter_lists3.hip: the same products on the bf16 matrix cores from exact 3 x bf16 splits of the fp32
     # operands, fp32 accumulation) agrees with the fp32-MFMA kernels to fp32 rounding
-    for a, bb, what in zip(out[2], out[3], ('forward', 'forward, transposed', 'backward Z')):
-        assert rel_err(bb.cpu().numpy(), a.cpu().numpy()) < 1e-6, what
-    assert rel_err(out[3][0].cpu().numpy(), ref_valu(feats, idx, gx, rk, sigma, b, c, p, n, nn, na, ks, dev).cpu().numpy()) < 5e-6
+    if 3 in out:
+        for a, bb, what in zip(out[2], out[3], ('forward', 'forward, transposed', 'backward Z')):
+            assert rel_err(bb.cpu().numpy(), a.cpu().numpy()) < 1e-6, what
+        assert rel_err(out[3][0].cpu().numpy(), ref_valu(feats, idx, gx, rk, sigma, b, c, p, n, nn, na, ks, dev).cpu().numpy()) < 5e-6
     ref = torch.empty_like(out[2][0])
     _hip.call('eap_so3_inter_group_fwd_valu_f32', ref, b, c, p, n, nn, na, ks, _hip._F32(sigma), _hip._ptr(feats),
               _hip._ptr(idx), _hip._ptr(gx), _hip._ptr(rk), _hip._ptr(None), _hip._ptr(ref))
@@ -916,3 +923,89 @@ def test_native_zpconv_at_the_bench_shape(dev):
     lhs = float((out.double() * g.double()).sum())
     rhs = float((feats.double() * gf.double()).sum())
     assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), float(out.double().abs().sum()) * 1e-3), (lhs, rhs)
+
+
+def test_native_zpconv_backward_with_rows_on_chip(dev):
+    """csrc/zpconv_bwd_hot.hip (scatter target in LDS, no per-(point, neighbour) intermediate) behind
+    vgtk.cuda.zpconv.inter_zpconv_backward: against the C oracle (zpconv_cuda_kernel.cu:L77-116 restated) at a size it
+    runs, against the product pipeline (csrc/zpconv_bwd.hip) at the bench shape with the batch whole (one point range per
+    cloud) and in a slice of two (four point ranges + the fixed-order partial sum), with a cloud whose lists reference more
+    rows than fit and a cloud whose 5-D index is not one list per point in the same batch (both reported and handed to the
+    other path), and bit equality run to run."""
+    import synth_clouds
+    import vgtk.cuda.grouping as G
+    import vgtk.cuda.zpconv as Z
+    from vgtk import _hip
+    A, K, NN = 60, 24, 64
+    gen = torch.Generator(device=dev).manual_seed(9)
+    cap = int(_hip.lib.eap_inter_zpconv_bwd_hot_rows())
+
+    def status_of(idx, w, g, nq):
+        b, p = idx.shape[:2]
+        c = g.shape[1]
+        nbytes = int(_hip.lib.eap_inter_zpconv_bwd_hot_workspace(b, p, nq, A, K, NN, c))
+        assert nbytes > 0
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+        st = torch.empty(b, dtype=torch.int32, device=dev)
+        out = torch.empty(b, c, nq, A, device=dev)
+        _hip.call('eap_inter_zpconv_bwd_hot_f32', out, b, p, nq, A, K, NN, c, _hip._ptr(idx), _hip._ptr(w), _hip._ptr(g), _hip._ptr(out),
+                  _hip._ptr(ws), _hip._ptr(st))
+        return st.tolist(), out
+
+    def products(idx, w, g, nq):
+        Z.ON_CHIP_BACKWARD = False
+        try:
+            return Z.inter_zpconv_backward(idx, w, g, nq)
+        finally:
+            Z.ON_CHIP_BACKWARD = True
+
+    # ---- 1. against the oracle: 2 x 256 points, C = 32, a ball that takes in most of the cloud (few referenced rows),
+    #         a shadow row (nq = P + 1)
+    B, P, C = 2, 256, 32
+    xyz = T(synth_clouds.laptop_batch(30, B, P)[0]).to(dev)
+    ball = G.ball_query(xyz, xyz, 0.45, NN)
+    rows = [len(torch.unique(ball[i])) for i in range(B)]
+    assert max(rows) <= cap, rows
+    idx = ball[:, :, None, None, :].expand(B, P, A, K, NN).contiguous()
+    w = torch.rand(B, P, A, K, NN, device=dev, generator=gen)
+    g = torch.randn(B, C, K, P, A, device=dev, generator=gen)
+    st, _ = status_of(idx, w, g, P + 1)
+    assert st == [0, 0]
+    got = Z.inter_zpconv_backward(idx, w, g, P + 1)
+    ref = native.inter_zpconv_backward(idx.cpu().numpy(), w.cpu().numpy(), g.cpu().numpy(), P + 1)
+    assert rel_err(got.cpu().numpy(), ref) < 2e-6
+    assert torch.equal(got, Z.inter_zpconv_backward(idx, w, g, P + 1))
+
+    # ---- 2. the bench shape, whole batch and a slice of two clouds, against the product pipeline
+    B, P, C = 8, 4096, 64
+    xyz = T(synth_clouds.laptop_batch(0, B, P)[0]).to(dev)
+    ball = G.ball_query(xyz, xyz, synth_clouds.backbone_layers(P)[1][2], NN)
+    idx = ball[:, :, None, None, :].expand(B, P, A, K, NN).contiguous()
+    w = torch.rand(B, P, A, K, NN, device=dev, generator=gen)
+    g = torch.randn(B, C, K, P, A, device=dev, generator=gen)
+    st, _ = status_of(idx, w, g, P)
+    assert st == [0] * B, (st, [len(torch.unique(ball[i])) for i in range(B)], cap)
+    got = Z.inter_zpconv_backward(idx, w, g, P)
+    assert torch.equal(got, Z.inter_zpconv_backward(idx, w, g, P))
+    want = products(idx, w, g, P)
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-6
+    two = Z.inter_zpconv_backward(idx[2:4], w[2:4], g[2:4], P)
+    assert rel_err(two.cpu().numpy(), want[2:4].cpu().numpy()) < 2e-6
+    assert torch.equal(two, Z.inter_zpconv_backward(idx[2:4], w[2:4], g[2:4], P))
+    del got, want, two
+
+    # ---- 3. one batch, three kinds of cloud: few rows (on chip), a small ball (more rows than fit), an index that differs
+    #         between kernel points (not one list per point)
+    B, P, C = 3, 1024, 32
+    xyz = T(synth_clouds.laptop_batch(40, B, P)[0]).to(dev)
+    big, small = G.ball_query(xyz, xyz, 0.6, NN), G.ball_query(xyz, xyz, 0.05, NN)
+    assert len(torch.unique(big[0])) <= cap < len(torch.unique(small[1]))
+    idx = torch.stack([big[0], small[1], big[2]])[:, :, None, None, :].expand(B, P, A, K, NN).contiguous()
+    idx[2, 17, 3, 5, :] = idx[2, 17, 3, 5, :].flip(0)
+    w = torch.rand(B, P, A, K, NN, device=dev, generator=gen)
+    g = torch.randn(B, C, K, P, A, device=dev, generator=gen)
+    st, _ = status_of(idx, w, g, P)
+    assert st == [0, 1, 1], st
+    got = Z.inter_zpconv_backward(idx, w, g, P)
+    ref = native.inter_zpconv_backward(idx.cpu().numpy(), w.cpu().numpy(), g.cpu().numpy(), P)
+    assert rel_err(got.cpu().numpy(), ref) < 3e-6
