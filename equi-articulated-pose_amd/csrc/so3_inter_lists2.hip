@@ -27,6 +27,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CT = 2;         // channel tiles (MFMA M tiles) per wave
 constexpr int CB = 32 * CT;   // channels per block
@@ -74,7 +75,12 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 
 // LISTS = true : rows / off / cnt describe variable-length entry lists (backward);
 // LISTS = false: row r of cloud b owns entries [ (b*R + r)*nn, +nn ) (forward: its neighbours).
-// LAYOUT of the output: 0 = [b,c,k,row,a] (reference), 2 = transposed [row*na+a][c*ks+k]
+// LAYOUT of the output: 0 = [b,c,k,row,a] (reference), 2 = transposed [row*na+a][c*ks+k], 3 = the same transposed matrix
+// computed with the MFMA operands exchanged (D = kernel points x channels: a lane then holds FOUR CONSECUTIVE kernel
+// points of one channel per accumulator quad, i.e. 16 contiguous bytes of an output row, so the row end is 24 dwordx4
+// stores per wave instead of 128 dword stores; both operands of v_mfma_f32_32x32x2_f32 use the same lane mapping, so the
+// k-loop is unchanged).  Needs ks % 4 == 0.
+#define EAP_MM(f, w, c, x, y, z) (LAYOUT == 3 ? __builtin_amdgcn_mfma_f32_32x32x2f32(w, f, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(f, w, c, 0, 0, 0))
 template <bool LISTS, int LAYOUT>
 __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, int AG, int RPB, int ag_major, int dbg, float inv_sigma,
@@ -246,29 +252,29 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
         __builtin_amdgcn_s_setprio(3);
         if (first) {
             const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[0], wv[0][0], zc, 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[1], wv[0][1], zc, 0, 0, 0);
+            acc[0][0] = EAP_MM(fa0[0], wv[0][0], zc, 0, 0, 0);
+            acc[0][1] = EAP_MM(fa0[1], wv[0][1], zc, 0, 0, 0);
             q0();
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[2], wv[1][0], zc, 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[3], wv[1][1], zc, 0, 0, 0);
+            acc[0][2] = EAP_MM(fa0[2], wv[1][0], zc, 0, 0, 0);
+            acc[0][3] = EAP_MM(fa0[3], wv[1][1], zc, 0, 0, 0);
             q1();
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[0], wv[0][0], zc, 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[1], wv[0][1], zc, 0, 0, 0);
+            acc[1][0] = EAP_MM(fa1[0], wv[0][0], zc, 0, 0, 0);
+            acc[1][1] = EAP_MM(fa1[1], wv[0][1], zc, 0, 0, 0);
             q2();
-            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[2], wv[1][0], zc, 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[3], wv[1][1], zc, 0, 0, 0);
+            acc[1][2] = EAP_MM(fa1[2], wv[1][0], zc, 0, 0, 0);
+            acc[1][3] = EAP_MM(fa1[3], wv[1][1], zc, 0, 0, 0);
         } else {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[0], wv[0][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[1], wv[0][1], acc[0][1], 0, 0, 0);
+            acc[0][0] = EAP_MM(fa0[0], wv[0][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = EAP_MM(fa0[1], wv[0][1], acc[0][1], 0, 0, 0);
             q0();
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[2], wv[1][0], acc[0][2], 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[3], wv[1][1], acc[0][3], 0, 0, 0);
+            acc[0][2] = EAP_MM(fa0[2], wv[1][0], acc[0][2], 0, 0, 0);
+            acc[0][3] = EAP_MM(fa0[3], wv[1][1], acc[0][3], 0, 0, 0);
             q1();
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[0], wv[0][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[1], wv[0][1], acc[1][1], 0, 0, 0);
+            acc[1][0] = EAP_MM(fa1[0], wv[0][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = EAP_MM(fa1[1], wv[0][1], acc[1][1], 0, 0, 0);
             q2();
-            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[2], wv[1][0], acc[1][2], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[3], wv[1][1], acc[1][3], 0, 0, 0);
+            acc[1][2] = EAP_MM(fa1[2], wv[1][0], acc[1][2], 0, 0, 0);
+            acc[1][3] = EAP_MM(fa1[3], wv[1][1], acc[1][3], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         q3();
@@ -281,6 +287,33 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     const unsigned lane_off = (unsigned)((size_t)(4 * lh) * o_cs + (size_t)min(lk, ks - 1) * o_ks) + (unsigned)al_beg;
     float *obb = out + (size_t)bi * C * o_cs;
     auto store_row = [&](int row) {
+        if (LAYOUT == 3) {
+            // D[i = kernel point][j = channel]: lane column = channel lk of the tile, accumulator quad q holds kernel points
+            // 8 q + 4 lh .. + 3 -- 16 contiguous bytes of out[b][row*na + a][c*ks + k]
+            if (active && !ABL(4)) {
+                const size_t CK = (size_t)C * ks;
+                float *rb = obb + ((size_t)row * na + a0 + al_beg) * CK + (size_t)c0 * ks;      // uniform
+                const unsigned lo_b = (unsigned)(lk * ks + 4 * lh) * 4u;
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // the accumulators were last written by MFMAs the asm cannot see
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bool whole = c0 + 32 * ct + 32 <= C;            // block-uniform
+                    if (whole || c0 + 32 * ct + lk < C) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (8 * q >= ks || 8 * q + 4 * lh >= ks) continue;       // (first test: uniform, drops the padding quad)
+#pragma unroll
+                            for (int ai = 0; ai < APW; ++ai) {
+                                const f32x4 v = {acc[ct][ai][4 * q], acc[ct][ai][4 * q + 1], acc[ct][ai][4 * q + 2], acc[ct][ai][4 * q + 3]};
+                                asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lo_b), "v"(v),
+                                             "s"(rb + (size_t)ai * CK + (size_t)(32 * ct) * ks + 8 * q) : "memory");
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
         if (active && lk < ks && !ABL(4)) {
             if (LAYOUT == 2) {
                 // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix the contraction GEMM reads)
@@ -388,6 +421,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 constexpr size_t SHMEM = 2 * BUF_BYTES + 16 * 3 * NBK + 16 * NBK;
 
 int g_xcd_map_fwd = 1, g_xcd_map_inv = 1;       // eap_so3_group_lists_xcd_map
+int g_store16 = 1;                              // eap_so3_group_lists_store16
 
 template <bool LISTS>
 int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
@@ -398,7 +432,8 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
         return eap::bad_arg("so3_group_lists2: 64 feature rows of a cloud exceed the 32-bit request offsets");
     if (((long long)ks * R * na * 4 + 64ll * R * na + 64) * 4 >= (1ll << 31) || (long long)CB * ks * 4 >= (1ll << 31))
         return eap::bad_arg("so3_group_lists2: output rows too far apart for 32-bit store offsets");
-    auto kern = layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>;
+    const bool wide = !LISTS && layout == 2 && g_store16 != 0 && (ks & 3) == 0;
+    auto kern = wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>;
     int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM), what);
     if (e) return e;
     const int AG = (na + GSZ - 1) / GSZ;
@@ -411,7 +446,7 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
 #endif
     hipLaunchKernelGGL(kern, grid, dim3(TM), SHMEM, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, (LISTS ? g_xcd_map_inv : g_xcd_map_fwd) == 2, dbg, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
-    eap::set_kernel(LISTS ? "so3_group_lists2_kernel<true, 0>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>");
+    eap::set_kernel(LISTS ? "so3_group_lists2_kernel<true, 0>" : wide ? "so3_group_lists2_kernel<false, 3>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>");
     return eap::check_launch(what);
 }
 
@@ -429,6 +464,15 @@ extern "C" int eap_so3_group_lists_tiles(int tiles) {
     if (tiles >= 1 && tiles <= 2) g_tiles = tiles;
 #endif
     return g_tiles;
+}
+
+// Row end of the forward kernel writing the transposed intermediate: 1 (default) = exchanged MFMA operands, 16-byte stores
+// (LAYOUT 3); 0 = dword stores in 96-byte runs (LAYOUT 2).  Bit-identical results (the same products summed in the same
+// order).  Returns the previous setting; other values only query.
+extern "C" int eap_so3_group_lists_store16(int on) {
+    const int was = g_store16;
+    if (on == 0 || on == 1) g_store16 = on;
+    return was;
 }
 
 // Which unit of work an XCD (one L2) owns in the two-tile kernel: 1 = whole (channel slice, cloud) pairs, 2 = whole

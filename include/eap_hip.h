@@ -208,6 +208,10 @@ int eap_so3_inter_group_bwd_slab_f32(int b, int c, int p, int n, int nn, int na,
  * a 3 x bf16 split grouping kernel, a re-cut zpconv forward -- live in tools/experiments/kernels/ and are compiled in by
  * `make EXPERIMENTS=1` only.) */
 int eap_so3_group_lists_tiles(int tiles);
+/* Row end of the two-tile forward kernel writing the transposed intermediate: 1 (default) = MFMA operands exchanged so that a
+ * lane holds four consecutive kernel points of a channel, 16-byte stores; 0 = dword stores in 96-byte runs.  Bit-identical
+ * results.  Returns the previous setting; other values only query. */
+int eap_so3_group_lists_store16(int on);
 /* forward grouping of clouds WITH anchor permutations: 1 (default) = the entry-list kernel of csrc/so3_inter_inv.hip in its
  * forward mode (global -> LDS DMA rows), 0 = the register-staged kernel of csrc/so3_inter_mfma.hip (round 1); returns the
  * previous setting, any other argument only queries.  Same results to rounding; for A/B runs and tests. */

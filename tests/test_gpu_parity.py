@@ -877,6 +877,13 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
         _hip.lib.eap_so3_group_lists_tiles(2)
     for a, bb, what in zip(out[1], out[2], ('forward', 'forward, transposed', 'backward Z')):
         assert torch.equal(a, bb), what
+    # the transposed forward with its row end as dword stores (MFMA operands not exchanged): the same bits
+    was = _hip.lib.eap_so3_group_lists_store16(0)
+    try:
+        narrow = _hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma, blocked=2)
+    finally:
+        _hip.lib.eap_so3_group_lists_store16(was)
+    assert was == 1 and torch.equal(narrow, out[2][1]), 'forward, transposed: 16-byte row-end stores differ from dword stores'
     # mode 3 (tools/experiments/kernels/so3_inter_lists3.hip: the same products on the bf16 matrix cores from exact 3 x bf16 splits of the fp32
     # operands, fp32 accumulation) agrees with the fp32-MFMA kernels to fp32 rounding
     if 3 in out:
