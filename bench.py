@@ -111,11 +111,11 @@ class SeparableBackbone(nn.Module):
         x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
         for i in range(len(self.inter)):
             skip = x.feats
-            _, _, _, y = self.inter[i](x)
-            y = zptk.SphericalPointCloud(y.xyz, self.inter_norm[i](y.feats), y.anchors)
-            y = self.intra[i](y)
-            f = self.intra_norm[i](y.feats)
-            f = self.skip_norm[i](sptk.pointwise_conv(self.skip[i], skip, add_bias=False), residual=f, pre_bias=self.skip[i].bias)        # relu(norm(skip)) + intra output, one pass; the skip conv on the contraction kernel
+            # (frozen stage: eval mode under no_grad -- the BatchNorms + activations (+ the skip sum) ride in the epilogues
+            # of their contractions; in training mode the same calls run conv and fused norm passes)
+            _, _, _, y = sptk.conv_norm_act(self.inter[i], self.inter_norm[i], x)
+            y = self.intra[i](zptk.SphericalPointCloud(y.xyz, y.feats, y.anchors))
+            f = sptk.pointwise_norm_act(self.skip[i], self.skip_norm[i], skip, residual=self.intra_norm[i](y.feats))
             x = zptk.SphericalPointCloudPose(x.xyz, f, y.anchors, x.pose)
         return x.feats
 
@@ -595,6 +595,8 @@ def main(argv=None):
     if args.separable:
         args.fwd_only = True
     model = (SeparableBackbone(args.points) if args.separable else Backbone(args.points, args.plan_points)).to(dev)
+    if args.separable:
+        model.eval()                    # the reference runs this stage frozen, in eval mode (trainer_unsup_arti_align.py:L594-597)
     for m in model.modules():           # the reference converts its BatchNorms to SyncBatchNorm for multi-GPU runs
         if hasattr(m, 'sync') and hasattr(m, 'negative_slope'):
             m.sync = world > 1

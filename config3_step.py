@@ -69,9 +69,11 @@ class SeparableBackbone(nn.Module):
         x = zptk.SphericalPointCloudPose(xyz, sptk.get_occupancy_features(xyz.transpose(1, 2), NA, False), None, pose)
         for i in range(len(self.inter)):
             skip = x.feats
-            _, _, _, y = self.inter[i](x)
-            y = self.intra[i](zptk.SphericalPointCloud(y.xyz, self.inter_norm[i](y.feats), y.anchors))
-            f = self.skip_norm[i](sptk.pointwise_conv(self.skip[i], skip, add_bias=False), residual=self.intra_norm[i](y.feats), pre_bias=self.skip[i].bias)
+            # frozen stage (eval mode, no_grad): the inter block's BatchNorm + leaky_relu and the skip branch's BatchNorm +
+            # leaky_relu + sum ride in the epilogues of their contractions (vgtk/so3conv/blocks.py)
+            _, _, _, y = sptk.conv_norm_act(self.inter[i], self.inter_norm[i], x)
+            y = self.intra[i](zptk.SphericalPointCloud(y.xyz, y.feats, y.anchors))
+            f = sptk.pointwise_norm_act(self.skip[i], self.skip_norm[i], skip, residual=self.intra_norm[i](y.feats))
             x = zptk.SphericalPointCloudPose(x.xyz, f, y.anchors, x.pose)
         return x.feats
 

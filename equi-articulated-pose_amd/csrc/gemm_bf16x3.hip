@@ -61,6 +61,9 @@ struct Args {
     const int *tbl; int na;             // BMODE 2: gather table [na][TAPS], anchors per point
     const unsigned *Apre;               // APRE: A split once by presplit_kernel, [M][K/4] pieces of 32 bytes (h0 h1 m0 m1 | l0 l1 - -)
     long long sA; int slabs, kslab;     // batch-reduce form (BMODE 0): z = item * slabs + slab; both operands start at k = slab * kslab
+    // row epilogue (the block layer's inference-mode BatchNorm + leaky_relu (+ skip sum) folded into the contraction,
+    // SPConvNets/utils/base_so3poseconv.py:L214-221, L319-328): C = lrelu(scale[row] * acc + shift[row]) (+ res); scale == nullptr: none
+    const float *ep_scale, *ep_shift, *ep_res; float ep_slope; long long sRes;
 };
 constexpr int TAPS = 12;                // intra_idx is [60, 12] (vgtk/so3conv/functional.py get_intra_idx)
 constexpr unsigned TBL_BYTES = 64 * TAPS * 4;
@@ -369,7 +372,15 @@ __global__ __launch_bounds__(128 * WN, WN / 2) void gemm_bf16x3_kernel(Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * MI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M && col < g.N) C[(long long)row * g.ldc + col] = acc[i][j][r];
+                if (row < g.M && col < g.N) {
+                    float v = acc[i][j][r];
+                    if (g.ep_scale != nullptr) {                      // kernel-uniform
+                        v = fmaf(v, g.ep_scale[row], g.ep_shift[row]);
+                        v = v >= 0.f ? v : v * g.ep_slope;
+                        if (g.ep_res != nullptr) v += g.ep_res[(long long)z * g.sRes + (long long)row * g.ldc + col];
+                    }
+                    C[(long long)row * g.ldc + col] = v;
+                }
             }
         }
 }
@@ -497,6 +508,26 @@ extern "C" int eap_gemm_bf16x3_f32(int M, int N, int K, const float *A, int64_t 
     g.B = B; g.ldb = ldb; g.sB = strideB;
     g.C = C; g.ldc = ldc; g.sC = strideC;
     return launch_split<0>(g, batch, eap::S(stream), "gemm_bf16x3_f32");
+}
+
+// eap_gemm_bf16x3_f32 / _nn_f32 with a per-row epilogue: C = leaky_relu(scale[row] * (A B) + shift[row], slope) (+ residual, laid
+// out like C): an inference-mode BatchNorm2d + activation (+ the separable block's skip sum) without a pass of their own.
+// transB = 1: B k-contiguous [N,K] (the inter conv's transposed intermediate); 0: B row-major [K,N] (pointwise contraction).
+extern "C" int eap_gemm_bf16x3_ep_f32(int transB, int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                                      float *C, int64_t ldc, int64_t strideC, int batch, const float *scale, const float *shift, float slope,
+                                      const float *residual, int64_t strideRes, eap_stream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (!scale || !shift) return eap::bad_arg("gemm_bf16x3_ep_f32: scale and shift are required");
+    const bool ok = transB ? eap_gemm_bf16x3_f32_supported(M, N, K, A, lda, B, ldb, strideB) : eap_gemm_bf16x3_nn_f32_supported(M, N, K, A, lda, B, ldb, strideB);
+    if (!ok) return eap::bad_arg("gemm_bf16x3_ep_f32: unsupported operands (ask eap_gemm_bf16x3_f32_supported / _nn_f32_supported)");
+    if (batch > 65535) return eap::bad_arg("gemm_bf16x3_ep_f32: batch exceeds 65535");
+    Args g{};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda;
+    g.B = B; g.ldb = ldb; g.sB = strideB;
+    g.C = C; g.ldc = ldc; g.sC = strideC;
+    g.ep_scale = scale; g.ep_shift = shift; g.ep_slope = slope; g.ep_res = residual; g.sRes = strideRes;
+    return transB ? launch_split<0>(g, batch, eap::S(stream), "gemm_bf16x3_ep_f32") : launch_split<1>(g, batch, eap::S(stream), "gemm_bf16x3_ep_f32");
 }
 
 // C_z[M,N] = A[M,K] * B_z[K,N]: A k-contiguous and shared by the batch, B row-major (the pointwise contraction

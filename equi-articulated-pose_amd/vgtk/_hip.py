@@ -133,6 +133,22 @@ def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, stri
          _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch, tag=tag)
 
 
+def gemm_epilogue(transB, M, N, K, A, lda, B, ldb, strideB, C, ldc, strideC, batch, scale, shift, slope, residual=None):
+    """C_z = leaky_relu(scale[row] * (A B_z) + shift[row], slope) (+ residual_z, laid out like C) on the split kernel
+    (eap_gemm_bf16x3_ep_f32): an inference-mode BatchNorm + activation folded into the contraction.  -> False when the
+    operands do not qualify for that kernel (nothing launched: the caller runs product and epilogue separately)."""
+    if not SPLIT_BF16_CONTRACTION:
+        return False
+    ok = (lib.eap_gemm_bf16x3_f32_supported if transB else lib.eap_gemm_bf16x3_nn_f32_supported)(
+        M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB))
+    if not ok:
+        return False
+    tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_epilogue', 0, int(transB), M, N, K, batch)}
+    call('eap_gemm_bf16x3_ep_f32', C, int(transB), M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc),
+         _I64(strideC), batch, _ptr(scale), _ptr(shift), _F32(slope), _ptr(residual), _I64(strideC), tag=tag)
+    return True
+
+
 def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch, b_blocked=False):
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)}
     if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and \

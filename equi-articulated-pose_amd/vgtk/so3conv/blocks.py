@@ -135,6 +135,51 @@ class BatchNormLeakyReLU(nn.BatchNorm2d):
         return _BNAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                             self.momentum, self.eps, self.negative_slope, self.sync, residual, pre_bias)
 
+    def folded(self, pre_bias=None, residual=None):
+        """The layer in inference mode as one per-channel affine map + activation ("inference-mode BN
+        folds into W"): leaky_relu(scale * x + shift) (+ residual), scale = gamma / sqrt(running_var + eps),
+        shift = beta - (running_mean - pre_bias) * scale, computed in float64 exactly as the eval-mode forward does."""
+        from .functional import FoldedEpilogue
+        if self.training:
+            raise RuntimeError('BatchNormLeakyReLU.folded: training-mode statistics depend on the data; call .eval() first')
+        scale64 = self.weight.detach().double() * torch.rsqrt(self.running_var.double() + self.eps)
+        mean = self.running_mean.double() if pre_bias is None else self.running_mean.double() - pre_bias.detach().double()
+        return FoldedEpilogue(scale64.float(), (self.bias.detach().double() - mean * scale64).float(), self.negative_slope, residual)
+
+
+def conv_norm_act(conv, norm, x, **conv_kwargs):
+    """The block layer's `x = conv(x); feat = relu(norm(x.feats))` (SPConvNets/utils/base_so3poseconv.py:L205-222) for an
+    InterSO3Conv / InterSO3PoseConv and a BatchNormLeakyReLU -> (inter_idx, inter_w, sample_idx, cloud with the activated
+    features).  In inference (norm in eval mode, gradients off) the normalisation and the activation ride in the
+    contraction's epilogue -- the feature map is written once, no pass of its own; otherwise conv and norm run as usual."""
+    from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose
+    fold = not norm.training and not torch.is_grad_enabled()
+    ep = norm.folded() if fold else None
+    if ep is not None:
+        conv_kwargs = dict(conv_kwargs, epilogue=ep)
+    inter_idx, inter_w, sample_idx, y = conv(x, **conv_kwargs)
+    feats = y.feats if (ep is not None and ep.applied) else norm(y.feats)
+    pose = getattr(y, 'pose', None)
+    out = SphericalPointCloudPose(y.xyz, feats, y.anchors, pose) if pose is not None else SphericalPointCloud(y.xyz, feats, y.anchors)
+    return inter_idx, inter_w, sample_idx, out
+
+
+def pointwise_norm_act(conv1x1, norm, x, residual=None):
+    """relu(norm(conv1x1(x))) (+ residual): the separable block's skip branch and sum (base_so3poseconv.py:L319-328) for an
+    nn.Conv2d(c, o, 1) and a BatchNormLeakyReLU.  The conv bias always rides in the norm's mean; in inference the whole
+    norm + activation + sum ride in the contraction's epilogue."""
+    from .functional import so3_contract
+    b, c, n, a = x.shape
+    W = conv1x1.weight.view(conv1x1.out_channels, c)
+    if not norm.training and not torch.is_grad_enabled():
+        ep = norm.folded(pre_bias=conv1x1.bias, residual=residual)
+        y = so3_contract(W, x.reshape(b, c, n * a), ep).view(b, conv1x1.out_channels, n, a)
+        if ep.applied:
+            return y
+        return norm(y, residual=residual, pre_bias=conv1x1.bias)
+    y = so3_contract(W, x.reshape(b, c, n * a)).view(b, conv1x1.out_channels, n, a)
+    return norm(y, residual=residual, pre_bias=conv1x1.bias)
+
 
 class InstanceNormLeakyReLU(nn.Module):
     """nn.InstanceNorm2d(affine=False) followed by leaky_relu, fused: the norm of the intra blocks

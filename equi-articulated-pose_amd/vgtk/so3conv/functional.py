@@ -285,13 +285,20 @@ class _Contract(torch.autograd.Function):
     """y[b,o,pa] = W[o,ck] x[b,ck,pa] on the matrix cores (BasicSO3Conv, modules.py:L48-55)."""
 
     @staticmethod
-    def forward(ctx, W, x):
+    def forward(ctx, W, x, epilogue=None):
         W = W.contiguous()
         x = x.contiguous()
         b, ck, pa = x.shape
         o = W.shape[0]
         y = torch.empty(b, o, pa, dtype=torch.float32, device=x.device)
-        _hip.gemm(0, 0, o, pa, ck, W, ck, 0, x, pa, ck * pa, y, pa, o * pa, b)
+        if epilogue is not None:
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                raise RuntimeError('a folded epilogue is an inference-time fusion: call under torch.no_grad()')
+            res = None if epilogue.residual is None else epilogue.residual.contiguous().view(b, o, pa)
+            epilogue.applied = _hip.gemm_epilogue(0, o, pa, ck, W, ck, x, pa, ck * pa, y, pa, o * pa, b, epilogue.scale, epilogue.shift,
+                                                  epilogue.slope, res)
+        if epilogue is None or not epilogue.applied:
+            _hip.gemm(0, 0, o, pa, ck, W, ck, 0, x, pa, ck * pa, y, pa, o * pa, b)
         ctx.save_for_backward(W, x)
         return y
 
@@ -312,7 +319,7 @@ class _Contract(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gW = torch.empty_like(W)          # sum_b gy_b x_b^T : [o,pa] [pa,ck]
             _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b)
-        return gW, gx
+        return gW, gx, None
 
 
 # Feature-gradient strategy of the fused inter convolution: "auto" picks the re-associated
@@ -397,10 +404,30 @@ def _set_keep_x_hint(W, keep):
     _KEEP_X_HINT[id(W)] = (weakref.ref(W), bool(keep))
 
 
-def _contract_into(W, x, y, layout):
-    """y[b,o,pa] = W . x for the intermediate in one of its three layouts."""
+class FoldedEpilogue:
+    """What an inference-mode BatchNorm2d + leaky_relu (+ skip sum) after a contraction amounts to: per output channel
+    y = leaky_relu(scale * (W x) + shift, slope) (+ residual) (vgtk.so3conv.blocks.BatchNormLeakyReLU.folded).  A
+    contraction that can apply it in its own epilogue (csrc/gemm_bf16x3.hip) sets `applied`; otherwise the caller runs
+    the norm as a pass of its own."""
+
+    def __init__(self, scale, shift, slope, residual=None):
+        self.scale, self.shift, self.slope, self.residual = scale.contiguous(), shift.contiguous(), float(slope), residual
+        self.applied = False
+
+
+def _contract_into(W, x, y, layout, epilogue=None, b0=0):
+    """y[b,o,pa] = W . x for the intermediate in one of its three layouts (epilogue: see FoldedEpilogue; b0 = first
+    cloud of this slab, for the residual)."""
     b, c, ks, p, na = x.shape
     o = W.shape[0]
+    if epilogue is not None and layout == 2:
+        res = None if epilogue.residual is None else epilogue.residual[b0:b0 + b]
+        if _hip.gemm_epilogue(1, o, p * na, c * ks, W, c * ks, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b,
+                              epilogue.scale, epilogue.shift, epilogue.slope, res):
+            epilogue.applied = True
+            return
+        if b0 > 0 and epilogue.applied:
+            raise RuntimeError('folded epilogue: the slabs of one contraction took different kernels')
     if layout == 2:                              # Y = W . (X^T)^T, both operands k-contiguous (csrc/gemm_dma_f32.hip)
         _hip.gemm(0, 1, o, p * na, c * ks, W, c * ks, 0, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b)
     else:
@@ -415,7 +442,7 @@ class _InterConv(torch.autograd.Function):
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None):
+    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None):
         feats = feats.contiguous()
         W = W_param.contiguous()
         ctx.anchors = anchors.detach().contiguous() if anchors is not None else None   # the rotations `mult` was built from
@@ -428,6 +455,8 @@ class _InterConv(torch.autograd.Function):
         b, c, n, na = feats.shape
         p, ks, o = idx.shape[1], rk.shape[1], W.shape[0]
         needs_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if epilogue is not None and needs_grad:
+            raise RuntimeError('a folded epilogue is an inference-time fusion: call under torch.no_grad()')
         lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)
         keep = needs_grad and (not lists_ok or _keep_x_hint(W_param))
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
@@ -441,7 +470,7 @@ class _InterConv(torch.autograd.Function):
                 b1 = min(b, b0 + step)
                 xs = _hip.so3_inter_group_fwd(feats[b0:b1], idx[b0:b1], gx[b0:b1], rk, mult, sigma,
                                               None if nonident is None else nonident[b0:b1], blocked=layout)
-                _contract_into(W, xs, y[b0:b1].view(b1 - b0, o, p * na), layout)
+                _contract_into(W, xs, y[b0:b1].view(b1 - b0, o, p * na), layout, epilogue, b0)
                 del xs
         ctx.layout = layout
         ctx.kept_x = x is not None
@@ -521,7 +550,7 @@ class _InterConv(torch.autograd.Function):
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
-        return gF, gW, None, None, None, None, None, None, None, None
+        return gF, gW, None, None, None, None, None, None, None, None, None
 
 
 INTRA_DW_SLICE = 64      # channels whose 12-tap gather is materialised at a time for the intra weight gradient
@@ -616,16 +645,16 @@ class _NarrowContract(torch.autograd.Function):
         return gW, gx
 
 
-def so3_contract(W, x):
-    """W [O, C*K], x [b, C*K, P*A] -> [b, O, P*A]."""
+def so3_contract(W, x, epilogue=None):
+    """W [O, C*K], x [b, C*K, P*A] -> [b, O, P*A] (epilogue: a FoldedEpilogue the product may apply, inference only)."""
     _hip.check_input(x)
     if x.dtype != torch.float32 or W.dtype != torch.float32:
         raise RuntimeError('so3_contract: float32 only')
     if not W.is_cuda:
         raise RuntimeError('so3_contract: W must be a device tensor')
-    if W.shape[0] <= 4 and _hip.lib.eap_narrow_contract_supported(x.shape[0], W.shape[0], x.shape[1], _hip._I64(x.shape[2])):
+    if epilogue is None and W.shape[0] <= 4 and _hip.lib.eap_narrow_contract_supported(x.shape[0], W.shape[0], x.shape[1], _hip._I64(x.shape[2])):
         return _NarrowContract.apply(W, x)
-    return _Contract.apply(W, x)
+    return _Contract.apply(W, x, epilogue)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -668,10 +697,11 @@ def _inter_group(xyz, pose, feats, n_neighbor, anchors, kernels, radius, sigma, 
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), new_feats
 
 
-def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute, q_xyz=None, q_pose=None):
+def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute, q_xyz=None, q_pose=None,
+                        epilogue=None):
     """ball query + prep + fused (grouping . contraction) -> (ball_idx, InterWeights, y [b,o,p,a]).
     What InterSO3PoseConv / InterSO3Conv.forward run; q_xyz / q_pose = the sampled centres of a strided conv
-    (default: every point is a centre)."""
+    (default: every point is a centre).  epilogue: a FoldedEpilogue the contraction may apply (inference only)."""
     if feats.dtype != torch.float32 or xyz.dtype != torch.float32 or W.dtype != torch.float32:
         raise RuntimeError('so3conv: float32 only')
     _hip.check_input(xyz)
@@ -693,7 +723,7 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
     gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
     y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident,
-                         anchors if mult is not None else None)
+                         anchors if mult is not None else None, epilogue)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 

@@ -84,13 +84,15 @@ class InterSO3Conv(nn.Module):
         self.basic_conv = BasicSO3Conv(dim_in, dim_out, points.shape[0])
         _const(self, anchors=L.get_anchors(kanchor), kernels=points)
 
-    def forward(self, x, inter_idx=None, inter_w=None):
+    def forward(self, x, inter_idx=None, inter_w=None, epilogue=None):
+        """epilogue (not in the reference): a vgtk.so3conv.functional.FoldedEpilogue the contraction may apply in
+        inference (vgtk.so3conv.blocks.conv_norm_act)."""
         if inter_idx is None and self.stride == 1:
             # fused path: grouping + contraction in one autograd node (re-associated backward)
             xyz = x.xyz
             inter_idx, inter_w, feats = L.inter_so3conv_fused(xyz, None, x.feats, self.basic_conv.W,
                                                               self.n_neighbor, self.anchors, self.kernels,
-                                                              self.radius, self.sigma, False)
+                                                              self.radius, self.sigma, False, epilogue=epilogue)
             sample_idx = torch.arange(xyz.shape[2], dtype=torch.long, device=xyz.device).unsqueeze(0).repeat(xyz.shape[0], 1)
             return inter_idx, inter_w, sample_idx, SphericalPointCloud(xyz, feats, self.anchors)
         inter_idx, inter_w, xyz, grouped, sample_idx = L.inter_so3conv_grouping(
@@ -113,7 +115,7 @@ class InterSO3PoseConv(InterSO3Conv):
                          kanchor=kanchor)
         self.permute_modes, self.use_2d, self.use_art_mode = permute_modes, use_2d, use_art_mode
 
-    def forward(self, x, inter_idx=None, inter_w=None, seg=None):
+    def forward(self, x, inter_idx=None, inter_w=None, seg=None, epilogue=None):
         if self.pooling is not None and self.stride > 1 and x.feats.shape[1] > 1:
             raise ValueError('xyz_pooling is not None?!!')             # functional.py:L913
         if inter_idx is None and self.stride > 1:
@@ -129,7 +131,7 @@ class InterSO3PoseConv(InterSO3Conv):
         # run as one autograd node (csrc/so3_inter_*.hip + gemm_dma_f32.hip)
         _, w, feats = L.inter_so3conv_fused(x.xyz, x.pose, x.feats, self.basic_conv.W, self.n_neighbor,
                                             self.anchors, self.kernels, self.radius, self.sigma,
-                                            self.permute_modes != 0)
+                                            self.permute_modes != 0, epilogue=epilogue)
         return inter_idx, w, None, SphericalPointCloudPose(x.xyz, feats, self.anchors, x.pose)
 
 

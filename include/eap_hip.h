@@ -318,6 +318,13 @@ int eap_gemm_bf16x3_nn_f32_supported(int M, int N, int K, const float *A, int64_
                                      int64_t strideB);
 int eap_gemm_bf16x3_nn_f32(int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
                            float *C, int64_t ldc, int64_t strideC, int batch, eap_stream_t stream);
+/* The two products above with a per-row epilogue: C = leaky_relu(scale[row] * (A B) + shift[row], slope) (+ residual [batch][M][ldc],
+ * may be null): an inference-mode nn.BatchNorm2d + activation (+ the separable block's skip sum,
+ * SPConvNets/utils/base_so3poseconv.py:L214-221, L319-328) folded into the contraction.  transB = 1: B k-contiguous (as
+ * eap_gemm_bf16x3_f32), 0: B row-major (as eap_gemm_bf16x3_nn_f32); same operand requirements. */
+int eap_gemm_bf16x3_ep_f32(int transB, int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                           float *C, int64_t ldc, int64_t strideC, int batch, const float *scale, const float *shift, float slope,
+                           const float *residual, int64_t strideRes, eap_stream_t stream);
 /* C[M,N] = sum_z A_z[M,K] B_z[N,K]^T on the split kernel (the weight gradient of the pointwise contraction, dW = sum over the
  * clouds of dY_z x_z^T): every (item, k-slab) pair writes its partial into `workspace` (eap_gemm_bf16x3_reduce_workspace
  * floats, 16-byte aligned), a second kernel sums them in a fixed order. */

@@ -1025,3 +1025,62 @@ def test_streaming_kernels_take_operands_at_any_4_byte_offset(dev):
     mask[:, 0] = 1.0
     v = f[1:].view(2, 8, 16, 60)
     assert torch.equal(sptk.masked_max(v, mask), sptk.masked_max(v.clone(), mask))
+
+
+def test_inference_mode_batchnorm_folds_into_the_contraction(dev):
+    """SURVEY.md 8(f) row 1, second half: in eval mode under no_grad the block layer's BatchNorm2d + leaky_relu (and the
+    separable block's skip branch with its sum, base_so3poseconv.py:L214-221, L319-328) ride in the epilogue of the
+    contraction that produces their input (csrc/gemm_bf16x3.hip).  Against conv + eval-mode norm as separate passes, and
+    the norm against nn.BatchNorm2d + F.leaky_relu; a layer too small for the split kernel takes the separate passes."""
+    import synth_clouds
+    import torch.nn.functional as F
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    from vgtk import _hip
+    torch.manual_seed(21)
+    B, P = 2, 512
+    xyz, _, pose = synth_clouds.laptop_batch(3, B, P)
+    xyz, pose = T(xyz).to(dev), T(pose).to(dev)
+    c, o = 64, 128
+    conv = sptk.InterSO3PoseConv(c, o, 1, 1, 0.3, 0.05, 64, kanchor=60, permute_modes=1).to(dev)
+    norm = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
+    skip, skip_norm = torch.nn.Conv2d(c, o, 1).to(dev), sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
+    with torch.no_grad():
+        for n_ in (norm, skip_norm):
+            n_.weight.uniform_(0.5, 1.5); n_.bias.uniform_(-0.3, 0.3); n_.running_mean.uniform_(-0.5, 0.5); n_.running_var.uniform_(0.5, 2.0)
+    feats = torch.randn(B, c, P, 60, device=dev)
+    x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
+    for m in (conv, norm, skip, skip_norm):
+        m.eval()
+    launched = []
+    _hip.KERNEL_TIMES = launched
+    try:
+        with torch.no_grad():
+            _, _, _, fused = sptk.conv_norm_act(conv, norm, x)
+            raw = conv(x)[3].feats
+            separate = norm(raw)
+            ref_bn = torch.nn.BatchNorm2d(o).to(dev).eval()
+            ref_bn.load_state_dict({k: v for k, v in norm.state_dict().items()})
+            torch_ref = F.leaky_relu(ref_bn(raw), 0.01)
+            res = torch.randn(B, o, P, 60, device=dev)
+            fused_skip = sptk.pointwise_norm_act(skip, skip_norm, feats, residual=res)
+            separate_skip = skip_norm(sptk.pointwise_conv(skip, feats, add_bias=False), residual=res, pre_bias=skip.bias)
+    finally:
+        _hip.KERNEL_TIMES = None
+    names = [n for n, *_ in launched]
+    assert names.count('eap_gemm_bf16x3_ep_f32') == 2, names           # both contractions took the epilogue kernel
+    assert rel_err(separate.cpu().numpy(), torch_ref.cpu().numpy()) < 2e-6
+    assert rel_err(fused.feats.cpu().numpy(), separate.cpu().numpy()) < 2e-6
+    assert rel_err(fused_skip.cpu().numpy(), separate_skip.cpu().numpy()) < 2e-6
+    # training mode or gradients on: nothing is folded, same API
+    norm.train()
+    _, _, _, tr = sptk.conv_norm_act(conv, norm, x)
+    assert tr.feats.requires_grad
+    # a first layer (1 -> 64 channels, K = 24): below the split kernel's tile -> conv and norm as separate passes, same result
+    conv0 = sptk.InterSO3PoseConv(1, 64, 1, 1, 0.3, 0.05, 64, kanchor=60, permute_modes=1).to(dev).eval()
+    norm0 = sptk.BatchNormLeakyReLU(64, negative_slope=0.01).to(dev).eval()
+    x0 = zptk.SphericalPointCloudPose(xyz, torch.ones(B, 1, P, 60, device=dev), None, pose)
+    with torch.no_grad():
+        a = sptk.conv_norm_act(conv0, norm0, x0)[3].feats
+        bsep = norm0(conv0(x0)[3].feats)
+    assert torch.equal(a, bsep)
