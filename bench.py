@@ -183,14 +183,21 @@ def cpu_baseline(points, slab=32):
             total += time.perf_counter() - t0
         return total
 
-    def protocol(threads, skip):
+    def protocol(threads, skip, give_up_after=None):
         torch.set_num_threads(threads)
-        one_run(skip)                                   # warm-up
+        warm = one_run(skip)                            # warm-up
+        if give_up_after is not None and warm > give_up_after:
+            # (torch's CPU ops of this path get slower, not faster, with hundreds of threads: one run instead of four keeps the
+            # default bench within its minutes)
+            return {'threads': threads, 'clouds_per_sec': 1.0 / (warm * points / slab), 'runs_s': [round(warm, 3)],
+                    'note': f'warm-up run only: slower than {give_up_after:.1f} s (3 x the {CPU_BASELINE_THREADS}-thread median)'}
         runs = sorted(one_run(skip) for _ in range(3))
         return {'threads': threads, 'clouds_per_sec': 1.0 / (runs[1] * points / slab), 'runs_s': [round(r, 3) for r in runs]}
 
     ncpu = os.cpu_count() or 1
-    faithful = [protocol(t, False) for t in sorted({min(ncpu, CPU_BASELINE_THREADS), ncpu})]
+    faithful = [protocol(min(ncpu, CPU_BASELINE_THREADS), False)]
+    if ncpu > CPU_BASELINE_THREADS:
+        faithful.append(protocol(ncpu, False, give_up_after=3.0 * faithful[0]['runs_s'][len(faithful[0]['runs_s']) // 2]))
     best = max(faithful, key=lambda d: d['clouds_per_sec'])
     short = protocol(best['threads'], True)
     model = 'unknown'
@@ -584,6 +591,7 @@ def main(argv=None):
     if args.check_launch:
         sys.exit(check_launch(args))
 
+    t_start = time.perf_counter()
     rank, world, dev, backend, n_dev = dist_setup(args)
     if n_dev == 0:
         raise SystemExit('bench.py: no GPU visible (this package has no CPU path)')
@@ -712,6 +720,10 @@ def main(argv=None):
             'dominant_kernel': dom_name,
             'launch_shapes': shapes[:8],
         }
+        def progress(what):
+            print(f'[bench {time.perf_counter() - t_start:7.1f} s] {what}', file=sys.stderr, flush=True)
+
+        progress('timed steps done')
         if ab is not None:
             line['fp32_mfma_contraction'] = ab
         if world > 1 and backend != 'nccl':
@@ -721,11 +733,15 @@ def main(argv=None):
             del model, opt, xyz, pose
             torch.cuda.empty_cache()
             line['other_configs'] = other_configs(dev)
+            progress('other configurations done')
             line['config3_step'] = config3_step(dev)
+            progress('config-3 composite done')
         if world == 1 and not args.fwd_only:
             line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
+            progress('native zpconv done')
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.points)
+            progress('cpu baseline done')
             line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
         print(json.dumps(line))
     if world > 1:

@@ -73,7 +73,7 @@ def test_config3_composite_step_at_full_size():
     torch.manual_seed(2913)
     model = C3.Config3Model(P).to(dev)
     params = model.trained_parameters()
-    opt = torch.optim.Adam(params, lr=2e-3)
+    opt = torch.optim.Adam(params, lr=1e-4)        # bench.py's rate; 2e-3 (the reduced-size test's) overshoots at full width
     with torch.no_grad():
         first = model(xyz, pose)
         l0, o0 = float(first[0]), {k: first[1][k].clone() for k in ('scores', 'slot_R', 'slot_T', 'labels', 'recon')}
@@ -89,7 +89,7 @@ def test_config3_composite_step_at_full_size():
     assert (RtR - torch.eye(3, device=dev)).abs().max().item() < 1e-4
     assert o0['labels'].shape == (B, P) and o0['slot_T'].shape == (B, C3.SLOTS, 60, 3)
     hist = []
-    for it in range(3):
+    for it in range(4):
         opt.zero_grad(set_to_none=True)
         loss, out = model(xyz, pose)
         loss.backward()
