@@ -249,31 +249,31 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
     grad = torch.randn(clouds, channels, KS, points, NA, device=dev)
     ms_b = timed(lambda: Z.inter_zpconv_backward(idx, w, grad, points))
     gbs = byts / ms / 1e6
-    # fabric-side bytes of the kernels behind the two entries, from the committed counter passes (profiles/r03_pmc_traffic.json,
-    # per launch): the index check reads the 5-D index once per call (its launches are split by cloud chunk in the backward),
-    # the backward runs its product / sum kernels once per scratch chunk
+    # fabric-side bytes of the kernels behind the two entries, from the committed counter passes (profiles/rNN_pmc_traffic.json,
+    # per launch; NOT measured in this run -- the object names its source file): the index check reads the 5-D index once per
+    # call; the backward keeps its scatter target on chip (csrc/zpconv_bwd_hot.hip), so its kernel moves the operands only
     traffic = None
-    pmc = {k: pmc_of_kernel(k) for k in ('zpconv_index_check_kernel', 'zpconv_mfma_kernel', 'zpconv_bwd_t_kernel<true>', 'zpconv_bwd_sum_kernel')}
+    pmc = {k: pmc_of_kernel(k) for k in ('zpconv_index_check_kernel', 'zpconv_mfma_kernel', 'zp_hot_kernel')}
     if all(pmc.values()) and clouds == 8 and points == 4096 and channels == 64:
         tot = lambda k: pmc[k]['fetch'] + pmc[k]['write']
         idx_bytes = 4.0 * clouds * points * NA * KS * NN
-        chunks = max(1, -(-int(4 * clouds * points * NN * channels * NA) // int(Z.BWD_WORKSPACE_BYTES)))
         fwd_b = idx_bytes + tot('zpconv_mfma_kernel')
-        bwd_b = idx_bytes + chunks * (tot('zpconv_bwd_t_kernel<true>') + tot('zpconv_bwd_sum_kernel'))
+        bwd_b = idx_bytes + tot('zp_hot_kernel')
         traffic = {'forward_bytes': fwd_b, 'forward_GBps': fwd_b / ms / 1e6, 'forward_frac_of_peak': fwd_b / ms / 1e6 / 8000.0,
                    'backward_bytes': bwd_b, 'backward_GBps': bwd_b / ms_b / 1e6, 'backward_frac_of_peak': bwd_b / ms_b / 1e6 / 8000.0,
-                   'backward_scratch_chunks': chunks,
+                   'source': pmc['zp_hot_kernel'].get('source'),
                    'per_launch': {k: {'fetch': v['fetch'], 'write': v['write'], 'l2_hit': v.get('l2_hit')} for k, v in pmc.items()},
-                   'note': 'FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes; the backward figure includes the per-(point, '
-                           'neighbour) products it writes and re-reads, which the algorithmic bytes leave out'}
+                   'note': 'FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes (committed file, not this run)'}
     return {'bound': 'hbm', 'traffic': traffic, 'kernel': 'zpconv_index_check_kernel + zpconv_mfma_kernel (v_mfma_f32_32x32x2_f32, streamed weights)',
             'entry': 'eap_inter_zpconv_fwd_ws_f32', 'achieved': gbs,
             'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'ms': ms, 'bytes': byts,
-            'backward': {'entry': 'eap_inter_zpconv_bwd_ws_f32',
-                         'kernels': 'zpconv_index_check_kernel + zpconv_bwd_t_kernel (MFMA) + inv_lists + zpconv_bwd_sum_kernel (atomics-free)',
+            'backward': {'entry': 'eap_inter_zpconv_bwd_hot_f32',
+                         'kernels': 'zpconv_index_check_kernel + inv_lists rows + zp_hot_kernel (v_mfma_f32_32x32x2_f32, scatter target in LDS: '
+                                    'no per-(point, neighbour) intermediate; the weights are read by the two channel halves of an anchor quad)',
                          'ms': ms_b, 'achieved': byts / ms_b / 1e6, 'frac': byts / ms_b / 1e6 / 8000.0,
-                         'bytes': byts, 'note': 'same algorithmic bytes as the forward (idx + w + grad read, gfeats written); the '
-                                                'per-(point, neighbour) products it writes and re-reads (4*P*NN*C*A bytes per cloud) are not counted'},
+                         'bytes': byts, 'intermediate_bytes': 0.0,
+                         'note': 'algorithmic bytes as the forward (idx + w + grad read, gfeats written); nothing else is written '
+                                 '(batches below 8 clouds add one accumulator image per point range, ~36 MB at 2 clouds)'},
             'workload': f'{clouds} x {points} points, C={channels}, A={NA}, K={KS}, NN={NN}, one neighbour list per point '
                         f'broadcast over (a,k) as the Python layer builds it, radius {radius}'}
 

@@ -27,6 +27,7 @@
 // A cloud whose referenced rows do not fit (or whose 5-D index is not one list per point) is reported in `status` and
 // left to csrc/zpconv_bwd.hip.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -37,12 +38,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int AQ = 4;                         // anchors per workgroup = waves
 constexpr int CH = 32;                        // channels per workgroup = MFMA N
 constexpr int KS = 24, NN = 64, KS2 = KS / 2;
-constexpr int TM = 64 * AQ;
+constexpr int NT = 2;                         // neighbour halves = MFMA M tiles of a point: one wave each
+constexpr int TM = 64 * AQ * NT;              // 8 waves: (anchor, neighbour half), two per SIMD
 constexpr int ROWB = AQ * CH * 4;             // bytes of accumulators per referenced row
 constexpr int STAGE_G = AQ * KS * CH * 4;     // grad stage [anchor][k][c]
 constexpr int STAGE_S = NN * 4;               // slot byte offsets of the point's 64 neighbours, [tile t][row m]: n = 2 m + t
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int RCAP = (LDS_BYTES - STAGE_G - STAGE_S) / ROWB - 1;      // 294 rows + one dump row for out-of-range indices
+
+// Timing ablations (WRONG RESULTS), compiled only with `make ABLATION=1` and selected by EAP_ZPHOT_DEBUG (bit mask): 1 no LDS
+// accumulation, 2 no grad requests after the prologue, 4 no weight requests after the prologue, 8 no matrix instructions,
+// 16 no flush, 32 no point loop, 64 no barriers in the loop, 128 no staging writes
+#ifdef EAP_ABLATION
+#define ABL(bit) ((dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
 
 template <typename V>
 __device__ __forceinline__ V ld_off(const float *ubase, unsigned voff) {
@@ -65,16 +76,28 @@ __global__ __launch_bounds__(1024) void zp_hot_slot_of_kernel(int nq, const int3
     }
 }
 
-// slot_off[b, p, t, m] = byte offset of the accumulator row of neighbour n = 2 m + t of point p
+// slot_off[b, p, n] = byte offset of the accumulator row of neighbour n of point p (tile t = n >> 5, row m = n & 31)
+// A list that names the same support row twice (the ball query pads short lists with their first hit) would make two lanes
+// of one accumulation step update the same word: such a cloud is reported (status 1) and left to the product pipeline.
 __global__ __launch_bounds__(256) void zp_hot_slot_off_kernel(int np, int nq, const int32_t *__restrict__ idx0, const int32_t *__restrict__ slot_of,
-                                                              const int32_t *__restrict__ status, int32_t *__restrict__ slot_off) {
+                                                              const int32_t *__restrict__ n_rows, int32_t *__restrict__ status,
+                                                              int32_t *__restrict__ slot_off) {
+    __shared__ int s_q[4][NN];
     const int bi = blockIdx.y;
-    if (status[bi] != 0) return;
+    if (status[bi] != 0) return;                                             // block-uniform enough: a late flag only costs work
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;          // (p, t, m)
-    if (e >= (long long)np * NN) return;
-    const int p = (int)(e >> 6), tm = (int)(e & 63), t = tm >> 5, m = tm & 31;
-    const int q = idx0[((size_t)bi * np + p) * NN + 2 * m + t];
-    const int r = (unsigned)q < (unsigned)nq ? slot_of[(size_t)bi * nq + q] : RCAP;       // out of range: the dump row
+    const bool in = e < (long long)np * NN;
+    const int p = (int)(e >> 6), tm = (int)(e & 63), n = tm;               // tile t = n >> 5, row m = n & 31
+    const int q = in ? idx0[((size_t)bi * np + p) * NN + n] : -1;
+    s_q[threadIdx.x >> 6][n] = q;
+    __syncthreads();
+    if (!in) return;
+    const bool valid = (unsigned)q < (unsigned)nq;
+    bool dup = false;
+    if (valid)
+        for (int j = 0; j < NN; ++j) dup = dup || (j != n && s_q[threadIdx.x >> 6][j] == q);
+    if (dup) atomicOr(status + bi, 1);
+    const int r = valid ? slot_of[(size_t)bi * nq + q] : n_rows[bi];        // out of range: the dump row (the one after the cloud's last)
     slot_off[((size_t)bi * np + p) * NN + tm] = r * ROWB;
 }
 
@@ -82,15 +105,12 @@ __global__ __launch_bounds__(256) void zp_hot_slot_off_kernel(int np, int nq, co
 // 8 * (round * members + member) + x belongs to group 8 * round + x: the 30 workgroups that stream the same points of the
 // same cloud run on ONE XCD (block % 8), so a 128-byte line of grad[c,k,p,:] -- shared by 8 anchor quads -- and the
 // weight rows -- shared by the two channel halves -- reach that XCD's L2 once.
-__global__ __launch_bounds__(TM, 1) void zp_hot_kernel(int nb, int S, int np, int nq, int na, int C, const float *__restrict__ grad,
+__global__ __launch_bounds__(TM, 2) void zp_hot_kernel(int nb, int S, int np, int nq, int na, int C, const float *__restrict__ grad,
                                                        const float *__restrict__ w, const int32_t *__restrict__ slot_off,
                                                        const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows,
                                                        const int32_t *__restrict__ status, float *__restrict__ gfeats,
-                                                       float *__restrict__ partial) {
+                                                       float *__restrict__ partial, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *acc_f = reinterpret_cast<float *>(smem);                                   // [RCAP + 1][AQ][CH]
-    float *stage_g = reinterpret_cast<float *>(smem + (RCAP + 1) * ROWB);              // [AQ][KS][CH]
-    int32_t *stage_s = reinterpret_cast<int32_t *>(smem + (RCAP + 1) * ROWB + STAGE_G);  // [2][32]
 
     const int naq = na >> 2, members = naq * (C / CH);
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, member = j % members, group = (j / members) * 8 + x;
@@ -101,104 +121,141 @@ __global__ __launch_bounds__(TM, 1) void zp_hot_kernel(int nb, int S, int np, in
     const int R = n_rows[bi];
     const int p0 = (int)((long long)np * sp / S), p1 = (int)((long long)np * (sp + 1) / S);
 
+    // LDS: acc[R + 1][AQ][CH] (row R = the dump row of out-of-range indices), then one or -- when the rows leave room,
+    // R <= 270 -- two operand stages: with two, a point's pieces are staged while the previous point's matrix work runs
+    // and the workgroup meets at ONE barrier per point
+    float *acc_f = reinterpret_cast<float *>(smem);
+    const unsigned stage0 = (unsigned)(R + 1) * ROWB;
+    const bool two_stages = stage0 + 2 * (STAGE_G + STAGE_S) <= (unsigned)LDS_BYTES;
+
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                          // = anchor of the quad
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_u & (AQ - 1), wt = wave_u >> 2;                               // anchor of the quad, neighbour half (M tile)
 
     // zero the accumulators (and the dump row)
-    for (int i = tid; i < (RCAP + 1) * ROWB / 16; i += TM) reinterpret_cast<f32x4 *>(acc_f)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < (R + 1) * ROWB / 16; i += TM) reinterpret_cast<f32x4 *>(acc_f)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane byte offsets off wave-uniform bases
-    const unsigned offW = (unsigned)(((KS2 * lh) * NN + 2 * li) * 4);                   // w[p, a, 12 lh + j, 2 li .. 2 li + 1]
+    const unsigned offW = (unsigned)(((KS2 * lh) * NN + 32 * wt + li) * 4);             // w[p, a, 12 lh + j, 32 wt + li]
     const size_t g_k = (size_t)np * na;                                                  // floats between kernel points of grad
-    unsigned offG[3];                                                                    // grad pieces (c = tid & 31, k = (tid >> 5) + 8 u)
-#pragma unroll
-    for (int u = 0; u < 3; ++u) offG[u] = (unsigned)((((size_t)(tid & 31) * KS + (tid >> 5) + 8 * u) * g_k) * 4);
+    // grad pieces of a point: (c = tid & 31, k = tid >> 5) for k < 16, and (c, 16 + (tid >> 5)) from the first half of the threads
+    const unsigned offG0 = (unsigned)((((size_t)(tid & 31) * KS + (tid >> 5)) * g_k) * 4);
+    const unsigned offG1 = (unsigned)((((size_t)(tid & 31) * KS + 16 + ((tid >> 5) & 7)) * g_k) * 4);
+    const bool second = tid < 256;                                                       // wave-uniform
     const float *gbase = grad + ((size_t)bi * C + c0) * KS * g_k + 4 * aq;               // + p * na
     const float *wbase = w + (((size_t)bi * np) * na + 4 * aq + wave) * (size_t)(KS * NN);   // + p * na * KS * NN
     const int32_t *sbase = slot_off + (size_t)bi * np * NN;
-    const unsigned acc_lane = (unsigned)((wave * CH + li) * 4);                          // this lane's word inside a row
-    float *acc_w = acc_f + (acc_lane >> 2);
+    char *acc_w = smem + (wave * CH + li) * 4;                                           // this lane's word inside row 0
 
-    // Operands travel two points ahead in two register sets (X: even steps, Y: odd steps): a set's grad pieces are
-    // re-requested right after they have been written to the stage, its weights right after its matrix instructions --
-    // every request has more than a whole point's matrix work (~1800 cycles) to land, and no register copy forces a
-    // wait before the data is needed.
-    f32x4 GX[3], GY[3];
-    f32x2 AX[KS2], AY[KS2];
-    int sX = 0, sY = 0;
-    auto request_g = [&](f32x4 (&G)[3], int &sreg, int p) {
+    // Operands travel two points ahead in two register sets (X, Y): a set's grad pieces are re-requested right after they
+    // have been written to a stage, its weights right after its matrix instructions -- every request has more than a whole
+    // point's matrix work to land, and no register copy forces a wait before the data is needed.
+    struct GSet { f32x4 g0, g1; int s; };
+    GSet GX{}, GY{};
+    float AX[KS2], AY[KS2];
+    auto request_g = [&](GSet &G, int p) {
         const float *gp = gbase + (size_t)p * na;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) G[u] = ld_off<f32x4>(gp, offG[u]);
-        if (tid < NN) sreg = sbase[(size_t)p * NN + tid];
+        G.g0 = ld_off<f32x4>(gp, offG0);
+        if (second) G.g1 = ld_off<f32x4>(gp, offG1);
+        if (tid < NN) G.s = sbase[(size_t)p * NN + tid];
     };
-    auto request_w = [&](f32x2 (&A)[KS2], int p) {
+    auto request_w = [&](float (&A)[KS2], int p) {
         const float *wp = wbase + (size_t)p * na * (KS * NN);
 #pragma unroll
-        for (int s = 0; s < KS2; ++s) A[s] = ld_off<f32x2>(wp + s * NN, offW);
+        for (int s = 0; s < KS2; ++s) A[s] = ld_off<float>(wp + s * NN, offW);
     };
-    const int plast = p1 - 1;
-    request_g(GX, sX, p0);
-    request_w(AX, p0);
-    request_g(GY, sY, min(p0 + 1, plast));
-    request_w(AY, min(p0 + 1, plast));
-    __syncthreads();
-
-    auto step = [&](f32x4 (&G)[3], f32x2 (&A)[KS2], int &sreg, int p) {
-        // ---- stage the point's grad pieces [anchor][k][c] and slot offsets; re-request the set for point p + 2
-        {
-            const int c = tid & 31;
+    // a point's grad pieces -> stage [anchor][k][c], its slot offsets -> [n]
+    auto put = [&](unsigned stage, const GSet &G) {
+        float *sg = reinterpret_cast<float *>(smem + stage);
+        const int c = tid & 31, k0 = tid >> 5;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int k = (tid >> 5) + 8 * u;
+        for (int a = 0; a < AQ; ++a) sg[(a * KS + k0) * CH + c] = G.g0[a];
+        if (second) {
 #pragma unroll
-                for (int a = 0; a < AQ; ++a) stage_g[(a * KS + k) * CH + c] = G[u][a];
-            }
-            if (tid < NN) stage_s[tid] = sreg;
+            for (int a = 0; a < AQ; ++a) sg[(a * KS + 16 + k0) * CH + c] = G.g1[a];
         }
-        const int pn = min(p + 2, plast);
-        request_g(G, sreg, pn);
-        __syncthreads();
-        // ---- this wave's B operand (grad of its anchor) and the accumulator rows of the 64 neighbours
+        if (tid < NN) reinterpret_cast<int32_t *>(smem + stage + STAGE_G)[tid] = G.s;
+    };
+    // the matrix work of one point from a filled stage: T[n, c] for this wave's 32 neighbours and its accumulation into their
+    // rows.  An accumulator word receives at most ONE contribution per point (a list names a row once: checked on the device)
+    // and the workgroup meets at a barrier between points, so the update is a plain read - add - write and every word sums its
+    // points in order: bit-reproducible, and 30 x faster than ds_add_f32 (measured: an LDS float atomic costs ~800 cycles
+    // per wave-instruction on this part, profiles/r04_zpconv_bwd_hot_ablation.txt).
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto work = [&](unsigned stage, float (&A)[KS2], int pn) {
+        const float *sg = reinterpret_cast<const float *>(smem + stage);
+        const int32_t *ss = reinterpret_cast<const int32_t *>(smem + stage + STAGE_G);
         float Bf[KS2];
 #pragma unroll
-        for (int s = 0; s < KS2; ++s) Bf[s] = stage_g[(wave * KS + KS2 * lh + s) * CH + li];
-        int so[2][16];
+        for (int s = 0; s < KS2; ++s) Bf[s] = sg[(wave * KS + KS2 * lh + s) * CH + li];
+        // D[m][c]: lane column c = li, register i <-> row m = 8 (i >> 2) + 4 lh + (i & 3), neighbour n = 32 wt + m
+        int so[16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int q = 0; q < 4; ++q) {
+            const int4 v = *reinterpret_cast<const int4 *>(ss + 32 * wt + 8 * q + 4 * lh);
+            so[4 * q] = v.x; so[4 * q + 1] = v.y; so[4 * q + 2] = v.z; so[4 * q + 3] = v.w;
+        }
+        // the old values are requested before the matrix instructions and have landed when those finish
+        float old[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int4 v = *reinterpret_cast<const int4 *>(stage_s + t * 32 + 8 * q + 4 * lh);
-                so[t][4 * q] = v.x; so[t][4 * q + 1] = v.y; so[t][4 * q + 2] = v.z; so[t][4 * q + 3] = v.w;
-            }
-        __syncthreads();                               // the stage may be overwritten from here on
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int i = 0; i < 16; ++i) old[i] = ABL(1) && i ? 0.f : *reinterpret_cast<const float *>(acc_w + so[i]);
+        f32x16 acc = zero16;
 #pragma unroll
         for (int s = 0; s < KS2; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][0], Bf[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][1], Bf[s], acc[1], 0, 0, 0);
+            if (ABL(8)) { acc[s] += A[s] * Bf[s]; continue; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], Bf[s], acc, 0, 0, 0);
         }
-        request_w(A, pn);
-        // D[m][c]: lane column c = li, register i <-> row m = 8 (i >> 2) + 4 lh + (i & 3), neighbour n = 2 m + t
+        if (!ABL(4)) request_w(A, pn);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                __hip_atomic_fetch_add(reinterpret_cast<float *>(reinterpret_cast<char *>(acc_w) + so[t][i]), acc[t][i], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int i = 0; i < 16; ++i)
+            if (!ABL(1) || i == 0) *reinterpret_cast<float *>(acc_w + so[i]) = old[i] + acc[i];
     };
-    for (int p = p0; p < p1; p += 2) {
-        step(GX, AX, sX, p);
-        if (p + 1 < p1) step(GY, AY, sY, p + 1);
+
+    const int plast = p1 - 1;
+    request_g(GX, p0);
+    request_w(AX, p0);
+    request_g(GY, min(p0 + 1, plast));
+    request_w(AY, min(p0 + 1, plast));
+    __syncthreads();                                   // the accumulators are zero
+    if (ABL(32)) {
+    } else if (two_stages) {
+        // stage (p - p0) & 1 holds point p.  Step p: matrix work from its stage, then point p + 1 (waiting in the OTHER
+        // register set) goes into the other stage -- last read during step p - 1, which every wave left through that
+        // step's barrier -- and the set is re-requested for p + 3.
+        const unsigned st[2] = {stage0, stage0 + STAGE_G + STAGE_S};
+        put(st[0], GX);
+        if (!ABL(2)) request_g(GX, min(p0 + 2, plast));
+        __syncthreads();
+        auto step = [&](int cur, float (&A)[KS2], GSet &Gn, int p) {
+            work(st[cur], A, min(p + 2, plast));
+            if (!ABL(128)) put(st[cur ^ 1], Gn);
+            if (!ABL(2)) request_g(Gn, min(p + 3, plast));
+            if (!ABL(64)) __syncthreads();
+        };
+        for (int p = p0; p < p1; p += 2) {
+            step(0, AX, GY, p);
+            if (p + 1 < p1) step(1, AY, GX, p + 1);
+        }
+    } else {
+        auto step = [&](GSet &G, float (&A)[KS2], int p) {
+            if (!ABL(128)) put(stage0, G);
+            if (!ABL(2)) request_g(G, min(p + 2, plast));
+            if (!ABL(64)) __syncthreads();
+            // (the stage is read into registers at the top of work(); the second barrier lets the next put() overwrite it, and
+            // keeps the accumulation steps of consecutive points apart)
+            work(stage0, A, min(p + 2, plast));
+            if (!ABL(64)) __syncthreads();
+        };
+        for (int p = p0; p < p1; p += 2) {
+            step(GX, AX, p);
+            if (p + 1 < p1) step(GY, AY, p + 1);
+        }
     }
     __syncthreads();
 
     // ---- flush: thread <-> (row, channel): the row's four anchors as one 16-byte word
-    if (S == 1) {
+    if (ABL(16)) {
+    } else if (S == 1) {
         for (int e = tid; e < R * CH; e += TM) {
             const int r = e / CH, c = e - r * CH;
             const int q = rows[(size_t)bi * nq + r];
@@ -296,7 +353,7 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     e = eap_inv_lists_rows(b, np, nq, ann, idx0, counts, rows, off, cnt, n_rows, stream);
     if (e) return e;
     hipLaunchKernelGGL(zp_hot_slot_of_kernel, dim3(b), dim3(1024), 0, s, nq, rows, n_rows, flag, slot_of, status);
-    hipLaunchKernelGGL(zp_hot_slot_off_kernel, dim3(eap::cdiv((long long)np * NN, 256), b), dim3(256), 0, s, np, nq, idx0, slot_of, status,
+    hipLaunchKernelGGL(zp_hot_slot_off_kernel, dim3(eap::cdiv((long long)np * NN, 256), b), dim3(256), 0, s, np, nq, idx0, slot_of, n_rows, status,
                        slot_off);
     e = eap::check_launch("inter_zpconv_backward (on-chip rows) slots");
     if (e) return e;
@@ -309,8 +366,13 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     const int members = (na / 4) * (c / CH), groups = b * L.S;
     const long long blocks = 8ll * members * ((groups + 7) / 8);
     if (blocks >= (1ll << 31)) return eap::bad_arg("inter_zpconv_backward (on-chip rows): too many workgroups");
+#ifdef EAP_ABLATION
+    const int dbg = getenv("EAP_ZPHOT_DEBUG") ? atoi(getenv("EAP_ZPHOT_DEBUG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     hipLaunchKernelGGL(zp_hot_kernel, dim3((unsigned)blocks), dim3(TM), LDS_BYTES, s, b, L.S, np, nq, na, c, grad, w, slot_off, rows, n_rows,
-                       status, gfeats, partial);
+                       status, gfeats, partial, dbg);
     e = eap::check_launch("inter_zpconv_backward (on-chip rows)");
     if (e) return e;
     eap::set_kernel("zp_hot_kernel");

@@ -292,7 +292,7 @@ class _Contract(torch.autograd.Function):
         o = W.shape[0]
         y = torch.empty(b, o, pa, dtype=torch.float32, device=x.device)
         if epilogue is not None:
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and torch.is_grad_enabled():
                 raise RuntimeError('a folded epilogue is an inference-time fusion: call under torch.no_grad()')
             res = None if epilogue.residual is None else epilogue.residual.contiguous().view(b, o, pa)
             epilogue.applied = _hip.gemm_epilogue(0, o, pa, ck, W, ck, x, pa, ck * pa, y, pa, o * pa, b, epilogue.scale, epilogue.shift,
@@ -454,7 +454,8 @@ class _InterConv(torch.autograd.Function):
         layout = 0 if not can else (2 if X_LAYOUT == 'transposed' else 1)
         b, c, n, na = feats.shape
         p, ks, o = idx.shape[1], rk.shape[1], W.shape[0]
-        needs_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        # (under torch.no_grad() needs_input_grad still reports the parameters: nothing will be differentiated then)
+        needs_grad = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and torch.is_grad_enabled()
         if epilogue is not None and needs_grad:
             raise RuntimeError('a folded epilogue is an inference-time fusion: call under torch.no_grad()')
         lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)

@@ -567,7 +567,9 @@ def test_pose_head_over_subsets_equals_the_per_cloud_loop(dev, pooling, A=60):
             if pre_bn_bias:        # a bias in front of a training-mode BatchNorm is absorbed by the batch mean: rounding noise in
                                    # autograd's sum, exactly zero in the fused backward
                 top = max(float(p_.grad.abs().max()) for p_ in ref_head.parameters() if p_.grad is not None)
-                assert np.abs(ref_g).max() < 1e-4 * top and (w.grad is None or np.abs(w.grad.cpu().numpy()).max() == 0.0), k
+                # (the single-anchor case runs the same expressions as device torch ops: rounding noise there too)
+                noise = 0.0 if A % 4 == 0 else 1e-6 * top
+                assert np.abs(ref_g).max() < 1e-4 * top and (w.grad is None or np.abs(w.grad.cpu().numpy()).max() <= noise), k
             else:
                 assert rel_err(w.grad.cpu().numpy(), ref_g) < 1e-4, (training, k)
 

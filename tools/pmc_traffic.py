@@ -7,7 +7,7 @@ Written to out_dir/<tag>_pmc_traffic.json (copy into profiles/ to have bench.py 
 import collections, csv, glob, json, os, re, sys
 
 out_dir, run, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-WANT = ('so3_group_lists', 'gemm_bf16x3_kernel', 'gemm_dma_f32_kernel', 'gemm_f32_kernel', 'zpconv_', 'bn_act_', 'so3_inter_group', 'chamfer', 'anchor_attn')
+WANT = ('so3_group_lists', 'gemm_bf16x3_kernel', 'gemm_dma_f32_kernel', 'gemm_f32_kernel', 'zpconv_', 'zp_hot', 'bn_act_', 'so3_inter_group', 'chamfer', 'anchor_attn')
 
 
 def key_of(name):
