@@ -100,7 +100,14 @@ int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, 
                           const float *feats, const int32_t *skip, float *out, hipStream_t s);
 // index pattern check shared by the zpconv forward and backward (csrc/zpconv_mfma.hip), the flag-gated scatter backward
 // (csrc/zpconv.hip)
+// (idx0 == nullptr: only the comparison)
 int zpconv_index_check(int b, int np, int per_point, int nn, const int32_t *idx, int32_t *idx0, float *eid, int32_t *flag, hipStream_t s);
+// idx0[b,p,:] = the first (a,k) row of every point's 5-D index (1 MB per cloud): what the matrix kernels walk while the full
+// comparison above still streams on the side stream
+int zpconv_first_rows(int b, int np, int per_point, int nn, const int32_t *idx, int32_t *idx0, hipStream_t s);
+// csrc/abi.hip: a side stream per device (fork: it waits for `s` so far; join: `s` waits for it)
+int side_fork(hipStream_t s, hipStream_t *side);
+int side_join(hipStream_t s);
 int inter_zpconv_bwd_flagged(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx, const float *w,
                              const float *grad, float *gfeats, const int32_t *only_flagged, hipStream_t s);
 // csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped

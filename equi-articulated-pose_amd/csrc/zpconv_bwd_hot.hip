@@ -63,17 +63,23 @@ __device__ __forceinline__ V ld_off(const float *ubase, unsigned voff) {
 // slot_of[b, q] = position of support row q among the cloud's referenced rows (rows[b, r] = q), status[b] = 1 when the
 // cloud cannot take this path
 __global__ __launch_bounds__(1024) void zp_hot_slot_of_kernel(int nq, const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows,
-                                                              const int32_t *__restrict__ flag, int32_t *__restrict__ slot_of,
-                                                              int32_t *__restrict__ status) {
+                                                              int32_t *__restrict__ slot_of, int32_t *__restrict__ status) {
     const int bi = blockIdx.x, t = threadIdx.x;
     const int R = n_rows[bi];
-    const bool ok = flag[bi] == 0 && R <= RCAP;
+    const bool ok = R <= RCAP;
     if (t == 0) status[bi] = ok ? 0 : 1;
     if (!ok) return;
     for (int r = t; r < R; r += 1024) {
         const int q = rows[(size_t)bi * nq + r];
         if (q >= 0) slot_of[(size_t)bi * nq + q] = r;
     }
+}
+
+// the verdict of the index check (side stream) joins the status: a cloud whose index is not one list per point was computed
+// from its first rows only -- reported, and recomputed by the caller's other path
+__global__ void zp_hot_status_kernel(int b, const int32_t *__restrict__ flag, int32_t *__restrict__ status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b && flag[i] != 0) status[i] = 1;
 }
 
 // slot_off[b, p, n] = byte offset of the accumulator row of neighbour n of point p (tile t = n >> 5, row m = n & 31)
@@ -195,16 +201,19 @@ __global__ __launch_bounds__(TM, 2) void zp_hot_kernel(int nb, int S, int np, in
             const int4 v = *reinterpret_cast<const int4 *>(ss + 32 * wt + 8 * q + 4 * lh);
             so[4 * q] = v.x; so[4 * q + 1] = v.y; so[4 * q + 2] = v.z; so[4 * q + 3] = v.w;
         }
-        // the old values are requested before the matrix instructions and have landed when those finish
+        // the old values are requested BEFORE the matrix instructions and have landed when those finish (left to itself the
+        // compiler sinks these reads below the MFMAs: two LDS round trips on the critical path of every point)
         float old[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) old[i] = ABL(1) && i ? 0.f : *reinterpret_cast<const float *>(acc_w + so[i]);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc = zero16;
 #pragma unroll
         for (int s = 0; s < KS2; ++s) {
             if (ABL(8)) { acc[s] += A[s] * Bf[s]; continue; }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], Bf[s], acc, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (!ABL(4)) request_w(A, pn);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -348,11 +357,18 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
 
     int e = eap::hip_fail(hipMemsetAsync(flag, 0, sizeof(int32_t) * b, s), "inter_zpconv_backward (on-chip rows) flags");
     if (e) return e;
-    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, idx0, nullptr, flag, s);
+    // idx0 = every point's first (a,k) row; the comparison of all the other rows with it streams the 5-D index once on the
+    // side stream, beside the kernels below (they are bound by their barriers, not by bandwidth)
+    e = eap::zpconv_first_rows(b, np, na * ks * ann, ann, idx, idx0, s);
+    if (e) return e;
+    hipStream_t side;
+    e = eap::side_fork(s, &side);
+    if (e) return e;
+    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, nullptr, nullptr, flag, side);
     if (e) return e;
     e = eap_inv_lists_rows(b, np, nq, ann, idx0, counts, rows, off, cnt, n_rows, stream);
     if (e) return e;
-    hipLaunchKernelGGL(zp_hot_slot_of_kernel, dim3(b), dim3(1024), 0, s, nq, rows, n_rows, flag, slot_of, status);
+    hipLaunchKernelGGL(zp_hot_slot_of_kernel, dim3(b), dim3(1024), 0, s, nq, rows, n_rows, slot_of, status);
     hipLaunchKernelGGL(zp_hot_slot_off_kernel, dim3(eap::cdiv((long long)np * NN, 256), b), dim3(256), 0, s, np, nq, idx0, slot_of, n_rows, status,
                        slot_off);
     e = eap::check_launch("inter_zpconv_backward (on-chip rows) slots");
@@ -379,6 +395,10 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     if (L.S > 1) {
         hipLaunchKernelGGL(zp_hot_reduce_kernel, dim3(members, b), dim3(256), 0, s, L.S, nq, na, c, partial, rows, n_rows, status, gfeats);
         e = eap::check_launch("inter_zpconv_backward (on-chip rows) reduce");
+        if (e) return e;
     }
-    return e;
+    e = eap::side_join(s);
+    if (e) return e;
+    hipLaunchKernelGGL(zp_hot_status_kernel, dim3(eap::cdiv(b, 256)), dim3(256), 0, s, b, flag, status);
+    return eap::check_launch("inter_zpconv_backward (on-chip rows) status");
 }

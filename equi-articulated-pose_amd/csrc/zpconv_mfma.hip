@@ -45,7 +45,7 @@ __global__ __launch_bounds__(CT) void zpconv_index_check_kernel(int np, int per_
     for (int q = t; q < qpr; q += CT) {
         const int4 v = src[q];
         s_ref[q] = v;
-        reinterpret_cast<int4 *>(idx0 + pb * nn)[q] = v;
+        if (idx0 != nullptr) reinterpret_cast<int4 *>(idx0 + pb * nn)[q] = v;
     }
     if (eid != nullptr)
         for (int n = t; n < nn; n += CT) eid[pb * nn + n] = make_float4(__uint_as_float((unsigned)(p * nn + n)), 0.f, 0.f, 0.f);
@@ -63,6 +63,14 @@ __global__ __launch_bounds__(CT) void zpconv_index_check_kernel(int np, int per_
         }
     }
     if (__syncthreads_or(mismatch != 0) && t == 0) atomicOr(flag + bi, 1);
+}
+
+__global__ __launch_bounds__(256) void zpconv_first_rows_kernel(long long rows4, int qpr, long long per_point4, const int4 *__restrict__ idx,
+                                                                int4 *__restrict__ idx0) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // (point, 16-byte piece of its first row)
+    if (i >= rows4) return;
+    const long long pt = i / qpr;
+    idx0[i] = idx[pt * per_point4 + (i - pt * qpr)];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,6 +379,13 @@ int zpconv_index_check(int b, int np, int per_point, int nn, const int32_t *idx,
     return eap::check_launch("inter_zpconv (index check)");
 }
 
+int zpconv_first_rows(int b, int np, int per_point, int nn, const int32_t *idx, int32_t *idx0, hipStream_t s) {
+    const long long rows4 = (long long)b * np * (nn >> 2);
+    hipLaunchKernelGGL(zpconv_first_rows_kernel, dim3(eap::cdiv(rows4, 256)), dim3(256), 0, s, rows4, nn >> 2, (long long)(per_point >> 2),
+                       reinterpret_cast<const int4 *>(idx), reinterpret_cast<int4 *>(idx0));
+    return eap::check_launch("inter_zpconv (first rows)");
+}
+
 bool inter_zpconv_mfma_supported(int np, int nq, int na, int ks, int nn, int c) {
     if (na <= 0 || na > 64 || (na & 3) != 0 || ks <= 0 || ks > 32 || nn <= 0 || (nn % SBK) != 0 || c < 16) return false;
     if ((long long)CB * nq * na * 4 >= (1ll << 32) || (long long)ks * nn * 4 >= (1ll << 24)) return false;
@@ -403,7 +418,7 @@ int inter_zpconv_mfma_fwd(int b, int np, int nq, int na, int ks, int nn, int c, 
 }  // namespace eap
 
 extern "C" int64_t eap_inter_zpconv_fwd_workspace(int b, int np, int ann) {
-    return 256 + 4ll * ((int64_t)b * np * ann) + 4ll * 64 * ((b + 63) / 64);
+    return 256 + 4ll * ((int64_t)b * np * ann) + 2 * 4ll * 64 * ((b + 63) / 64);        // flags | zeros | idx0
 }
 
 extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx,
@@ -415,18 +430,31 @@ extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks
                         eap::inter_zpconv_rows_supported(np, nq, na, ks, ann, c) && (long long)na * ks * ann < (1ll << 31) &&
                         ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
     if (!matrix) return eap_inter_zpconv_fwd_f32(b, np, nq, na, ks, ann, c, idx, w, src, dst, stream);
+    // The matrix kernel walks one neighbour list per point: idx0 = the first (a,k) row of every point (a 1 MB gather).  Whether
+    // every other row equals it is checked by streaming the whole index once -- on the side stream, BESIDE the matrix kernel
+    // (an HBM stream next to a kernel bound by its barriers); a cloud that fails the check is recomputed afterwards by the
+    // arbitrary-index kernel, which overwrites its output.
+    const int fl = 64 * ((b + 63) / 64);
     int32_t *flag = reinterpret_cast<int32_t *>(workspace);
-    int32_t *idx0 = flag + 64 * ((b + 63) / 64);
-    int e = eap::hip_fail(hipMemsetAsync(flag, 0, sizeof(int32_t) * b, s), "inter_zpconv_forward flags");
+    int32_t *nobody = flag + fl;                                         // all zero: the matrix kernel skips no cloud
+    int32_t *idx0 = flag + 2 * fl;
+    int e = eap::hip_fail(hipMemsetAsync(flag, 0, sizeof(int32_t) * 2 * fl, s), "inter_zpconv_forward flags");
     if (e) return e;
-    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, idx0, nullptr, flag, s);
+    e = eap::zpconv_first_rows(b, np, na * ks * ann, ann, idx, idx0, s);
+    if (e) return e;
+    hipStream_t side;
+    e = eap::side_fork(s, &side);
+    if (e) return e;
+    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, nullptr, nullptr, flag, side);
     if (e) return e;
 #ifdef EAP_EXPERIMENTS   // `make EXPERIMENTS=1`: the 32-neighbour re-cut of tools/experiments/kernels/zpconv_mfma2.hip behind eap_inter_zpconv_fwd_kernel(2)
     if (eap::zp_fwd_kernel() == 2 && eap::inter_zpconv_mfma2_supported(np, nq, na, ks, ann, c))
-        e = eap::inter_zpconv_mfma2_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
+        e = eap::inter_zpconv_mfma2_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, nobody, dst, s);
     else
 #endif
-    e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, flag, dst, s);
+    e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, nobody, dst, s);
+    if (e) return e;
+    e = eap::side_join(s);
     if (e) return e;
     return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, flag, s);
 }
