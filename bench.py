@@ -582,6 +582,7 @@ def main(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plan-points', type=int, default=None, help='radii / sigmas of the backbone built for this input size (default: --points)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configurations (config 3 composite included)')
+    ap.add_argument('--plain', action='store_true', help='warm-up + timed steps only (no attribution loop, no A/B leg, no extras): what the counter passes of tools/gpu/profile_round.sh run')
     ap.add_argument('--check-launch', action='store_true', help='start the ranks, run the two exchanges on small tensors, print what was started (no GPU needed)')
     args = ap.parse_args(argv)
 
@@ -660,6 +661,15 @@ def main(argv=None):
     # the headline loop: EXACTLY --steps steps, no per-launch events
     dt = timed(args.steps)
     # kernel attribution in a second, short loop: every C-ABI launch bracketed by two HIP events on the launch stream
+    if args.plain:
+        if rank == 0:
+            print(json.dumps({'metric': 'point-clouds/sec (4096 pts, 60 anchors) ' + ('fwd' if args.fwd_only else 'fwd+bwd'), 'value': args.batch * world * args.steps / dt,
+                              'unit': 'point-clouds/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+                              'plain': True}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     attr_steps = min(args.steps, 3)
     _hip.KERNEL_TIMES = []
     dt_attr = timed(attr_steps)

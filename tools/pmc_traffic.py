@@ -68,12 +68,24 @@ for e, c in per.items():
     res.setdefault(e, {})['mfma_util'] = sum(mf.values()) / (cyc * 1024) if cyc else None
     res[e]['shader_clock_ghz'] = cyc / max(sum(dur[e].values()), 1)
     res[e]['avg_launch_ms_under_pmc'] = sum(dur[e].values()) / len(dur[e]) / 1e6
+# wave-cycle breakdown (optional passes pmc_breakdown_*): per kernel, counter sums per launch and, where SQ_WAVE_CYCLES is in the
+# same pass, as fractions of it (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, MI355X_MICROARCH.md)
+breakdown = {}
+for d in sorted(glob.glob(os.path.join(run, 'pmc_breakdown_*'))):
+    per, _ = collect(os.path.basename(d))
+    for e, c in per.items():
+        tot = {name: sum(v for _, v in vals) / max(len(per_dispatch_sum(vals)), 1) for name, vals in c.items()}
+        b = breakdown.setdefault(e, {})
+        b.update({k: v for k, v in tot.items()})
+        if 'SQ_WAVE_CYCLES' in tot and tot['SQ_WAVE_CYCLES'] > 0:
+            b.update({k + '_frac_of_wave_cycles': v / tot['SQ_WAVE_CYCLES'] for k, v in tot.items() if k != 'SQ_WAVE_CYCLES'})
 per_kernel = {}
 for e, r in res.items():
     if 'FETCH_SIZE_KB_per_launch' in r:
         per_kernel[e] = {'fetch': 2.0 * 1024 * r['FETCH_SIZE_KB_per_launch'], 'write': 1024 * r.get('WRITE_SIZE_KB_per_launch', 0.0),
                          'l2_hit': r.get('l2_hit'), 'mfma_util': r.get('mfma_util'), 'shader_clock_ghz': r.get('shader_clock_ghz'),
                          'launches_per_step': r.get('launches_per_step')}
-doc = {'how': __doc__.strip(), 'per_kernel': per_kernel, 'counters': res}
+import datetime
+doc = {'how': __doc__.strip(), 'collected': datetime.date.today().isoformat(), 'per_kernel': per_kernel, 'counters': res, 'wave_cycle_breakdown': breakdown}
 json.dump(doc, open(os.path.join(out_dir, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(per_kernel, indent=1))
