@@ -661,7 +661,7 @@ def test_orbit_selection_matches_reference_statements(dev, golden, tag, cd, sing
     np.testing.assert_allclose(dist.cpu().numpy(), g[f'{tag}_slot_dist'], rtol=2e-5)
 
 
-@pytest.mark.parametrize('M,N,K,batch', [(512, 2048, 3072, 2), (128, 1920, 1536, 2), (384, 768, 48, 3), (256, 256, 16, 1), (512, 384, 32, 2)])
+@pytest.mark.parametrize('M,N,K,batch', [(512, 2048, 3072, 2), (512, 1024, 6144, 1), (128, 1920, 1536, 2), (384, 768, 48, 3), (256, 256, 16, 1), (512, 384, 32, 2)])
 def test_split_bf16_contraction_is_fp32_accurate(dev, M, N, K, batch):
     """csrc/gemm_bf16x3.hip: C = A B^T with fp32 operands on the bf16 matrix cores (3 x bf16 split, six partial products,
     fp32 accumulation) against fp64 -- its error must be of the size of the fp32-MFMA kernel's own (an fmaf chain), on
@@ -687,8 +687,11 @@ def test_split_bf16_contraction_is_fp32_accurate(dev, M, N, K, batch):
     bound = torch.matmul(A.abs().double().cpu(), B.abs().double().cpu().transpose(1, 2))
     rel_el = ((out[True] - ref).abs() / bound.clamp_min(1e-300)).max().item()
     print(f'\nGEMM {M}x{N}x{K}: split {err_split:.2e}, fp32 MFMA {err_fp32:.2e} (max error / max |C|); split per-element {rel_el:.2e} of sum |a||b|')
-    # both kernels accumulate K products in fp32: their errors are of the same size (the split adds ~2^-23 per product)
-    assert err_split < 3 * err_fp32 + 2e-7, (err_split, err_fp32)
+    # both kernels accumulate K products in fp32: their errors are of the same size (the split adds ~2^-23 per product).
+    # K = 6144 is the intra conv's C * 12 at C = 512.
+    rms = lambda x: float((x - ref).pow(2).mean().sqrt()) / scale
+    assert err_split < 2 * err_fp32 + 1e-7, (err_split, err_fp32)
+    assert rms(out[True]) < 2 * rms(out[False]) + 1e-8, (rms(out[True]), rms(out[False]))
     assert rel_el < 1e-6, rel_el
 
 
