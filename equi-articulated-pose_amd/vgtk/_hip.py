@@ -149,6 +149,12 @@ def gemm_epilogue(transB, M, N, K, A, lda, B, ldb, strideB, C, ldc, strideC, bat
     return True
 
 
+def gemm_reduce_takes_split(M, N, K, A, lda, strideA, B, ldb, strideB, ldc):
+    """Would gemm_reduce(0, 1, ...) with these operands run on the split-bf16 kernel?"""
+    return bool(SPLIT_BF16_CONTRACTION and lib.eap_gemm_bf16x3_reduce_f32_supported(M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb),
+                                                                                  _I64(strideB), _I64(ldc)))
+
+
 def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, batch, b_blocked=False):
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_reduce', int(transA), int(transB), M, N, K, batch)}
     if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and \

@@ -537,9 +537,16 @@ class _InterConv(torch.autograd.Function):
                 gF = _hip.rows_scatter(gFc.view(b, c, rcap, na), rows, n)           # unreferenced rows: zero gradient
             if ctx.needs_input_grad[1]:
                 fc = _hip.rows_gather(feats, rows, rcap).view(b, c, ra)              # [b,c,rcap*na]; unused slots: zeros
-                d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
-                _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
-                gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
+                if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, o * ks):
+                    # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
+                    # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe
+                    dt = torch.empty(c, o * ks, dtype=torch.float32, device=gy.device)
+                    _hip.gemm_reduce(0, 1, c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, dt, o * ks, b)
+                    gW = dt.view(c, o, ks).permute(1, 0, 2).reshape(o, c * ks).contiguous()
+                else:
+                    d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
+                    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
+                    gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
         else:
             if ctx.needs_input_grad[1]:
                 gW = torch.empty_like(W)          # sum_b gy_b x_b^T
@@ -727,6 +734,46 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
                          anchors if mult is not None else None, epilogue)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
+
+
+def inter_so3conv_fused_art_mode(xyz, pose, feats, W, seg_labels, n_neighbor, anchors, kernels, radius, sigma, permute):
+    """The stride-1 branch of inter_so3poseconv_grouping_strided_arti_mode (functional.py:L1420-1520) + the contraction:
+    xyz [b, ns, 3, p] holds the cloud in ns articulation states; every state gets its own ball query, and point p takes the
+    neighbour list and the (UNROTATED) offset vectors of state seg_labels[b, p]; the relative rotations of the poses only
+    select the anchor permutation.  -> (InterWeights, y [b,o,p,a]).  Runs on the fused kernels: per-state ball query +
+    offsets (eap_so3_prep_f32 without poses), the selection by label, the relative-rotation anchors from a second prep call
+    on the selected lists, then the same autograd node as the regular conv."""
+    if xyz.dim() != 4 or xyz.shape[2] != 3:
+        raise RuntimeError('use_art_mode: xyz must be [b, n_states, 3, p]')
+    if seg_labels is None:
+        raise RuntimeError('use_art_mode: the per-point state labels `seg` are required')
+    if feats.dtype != torch.float32 or xyz.dtype != torch.float32 or W.dtype != torch.float32:
+        raise RuntimeError('so3conv: float32 only')
+    _hip.check_input(xyz)
+    b, ns, _, p = xyz.shape
+    flat = xyz.reshape(b * ns, 3, p).contiguous()
+    idx_all = cuda_nn.ball_query(flat, flat, radius, n_neighbor)                                     # [b*ns, p, nn]
+    gx_all, _ = _hip.so3_prep(flat, flat, idx_all, None, None, anchors.contiguous(), 0)              # offsets x_n - x_p per state
+    nn = idx_all.shape[2]
+    pick = seg_labels.long().view(b, 1, p, 1)
+    ball_idx = idx_all.view(b, ns, p, nn).gather(1, pick.expand(b, 1, p, nn)).squeeze(1).contiguous()
+    gx = gx_all.view(b, ns, p, nn, 4).gather(1, pick.unsqueeze(-1).expand(b, 1, p, nn, 4)).squeeze(1).contiguous()
+    rk = rotated_kernels(anchors, kernels)
+    mult = nonident = None
+    ident = 0
+    if pose is not None and permute:
+        rot = pose.contiguous()
+        mult, ident = _group_tables(anchors)
+        if mult is None:
+            raise NotImplementedError('anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
+        # the nearest anchor of every pair's relative rotation (4th word of gx) and the per-cloud "not all identity" flag; the
+        # rotated offsets this call also produces are not used in this mode
+        first = xyz[:, 0].contiguous()
+        g_rot, nonident = _hip.so3_prep(first, first, ball_idx, rot, rot, anchors.contiguous(), ident)
+        gx = torch.cat([gx[..., :3], g_rot[..., 3:]], dim=-1).contiguous()
+    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), ident, nonident, anchors if mult is not None else None, None)
+    inter_w = InterWeights(gx, rk, sigma)
+    return (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 
 
 def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, radius, sigma,

@@ -1089,3 +1089,28 @@ def test_inference_mode_batchnorm_folds_into_the_contraction(dev):
         a = sptk.conv_norm_act(conv0, norm0, x0)[3].feats
         bsep = norm0(conv0(x0)[3].feats)
     assert torch.equal(a, bsep)
+
+
+@pytest.mark.parametrize('tag,pm', [('parts_pm1', 1), ('random_pm0', 0)])
+def test_art_mode_conv_matches_the_reference(dev, golden, tag, pm):
+    """InterSO3PoseConv(use_art_mode=True) (so3conv/modules.py:L256-262, functional.py:L1420-1520): the cloud in n_states
+    articulation states, a per-point label picking the state whose ball query and (unrotated) offsets the point uses, poses
+    selecting the anchor permutation only -- output, feature and weight gradients against the reference's own layer run on CPU
+    (tests/golden/make_golden_artmode.py)."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    g = golden('inter_pose_artmode.npz')
+    xyz, seg = T(g['xyz']).to(dev), T(g['seg']).to(dev)
+    conv = sptk.InterSO3PoseConv(6, 8, 1, 1, 0.2, 0.02, 16, kanchor=60, permute_modes=pm, use_art_mode=True)
+    conv.basic_conv.W.data.copy_(T(g[f'{tag}_W']))
+    conv = conv.to(dev)
+    feats = T(g[f'{tag}_feats']).to(dev).requires_grad_(True)
+    pose = T(g[f'{tag}_pose']).to(dev)
+    inter_idx, inter_w, sample_idx, y = conv(zptk.SphericalPointCloudPose(xyz, feats, None, pose), seg=seg)
+    assert inter_idx is None and sample_idx is None and tuple(y.xyz.shape) == tuple(xyz.shape)
+    w = inter_w.materialize() if hasattr(inter_w, 'materialize') else inter_w
+    assert np.abs(w[:, ::8, ::7, ::5].cpu().numpy() - g[f'{tag}_inter_w_sample']).max() < 2e-6
+    gf, gW = torch.autograd.grad(y.feats, [feats, conv.basic_conv.W], T(g[f'{tag}_gy']).to(dev))
+    assert rel_err(y.feats.detach().cpu().numpy(), g[f'{tag}_out']) < 1e-5
+    assert rel_err(gf.cpu().numpy(), g[f'{tag}_gfeats']) < 1e-5
+    assert rel_err(gW.cpu().numpy(), g[f'{tag}_gW']) < 2e-5
