@@ -66,14 +66,21 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // neighbours (ent_p = idx, shadow indices >= p carry weight 0), the table is `mult`, the offset vectors are NOT rotated
 // (the weight of output anchor a uses a itself), clouds whose flag says "all identity" are left to the entry-list kernel,
 // and the output is X in the reference layout (blocked = 0) or transposed [row*na + a][c*ks + k] (blocked = 2).
-template <bool HAS_MULT, bool DMA, bool FWD = false>
+// COSET = true (HAS_MULT, backward): the anchor axis of the operand is in COSET-MAJOR order -- in LDS and, with DMA, already in
+// global memory (the caller re-orders gy once, eap_anchor_reorder_f32: a 1.6 ms pass for a 4 GB gradient) --
+// (`order`: blocks of 4 = left cosets a.H of a Klein four-group H of the anchor group, vgtk/so3conv/functional.py
+// _coset_tables).  The permutation of an entry is a left multiplication: it moves whole blocks and XORs the position inside,
+// `code[r][block] = sigma | x << 4`.  A wave owns two blocks; the four permuted anchors of a block are ONE aligned 16-byte LDS
+// read of block sigma + 8 selects, instead of 4 byte-table lookups + 4 dword reads at conflicting banks.
+template <bool HAS_MULT, bool DMA, bool FWD = false, bool COSET = false>
 __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     int o, int p, int nn, int na, int ks, int rcap, float inv_sigma, int identity_anchor,
     const float *__restrict__ gy,
     const int32_t *__restrict__ rows, const int32_t *__restrict__ off, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx, const float *__restrict__ rk,
     const uint8_t *__restrict__ multinv, const float *__restrict__ anchors, float *__restrict__ out,
-    int blocked, const int32_t *__restrict__ nonident) {
+    int blocked, const int32_t *__restrict__ nonident, const uint8_t *__restrict__ order = nullptr) {
+    static_assert(!COSET || (HAS_MULT && !FWD), "coset-major operand: permuted backward");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int FP = DMA ? na : (na <= 60 ? 60 : FPMAX), FP_ = FP;
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][FP]
@@ -105,10 +112,14 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     const int n_ent = FWD ? nn : (q >= 0 ? cnt[(size_t)bi * rcap + ri] : 0);
     const size_t e0 = FWD ? ((size_t)bi * rcap + ri) * nn : (size_t)bi * p * nn + (q >= 0 ? off[(size_t)bi * rcap + ri] : 0);
 
+    // COSET: s_mult holds code [na][16] (the caller passes that table as `multinv`), then pos [64] = position of every anchor in
+    // the coset-major order
+    uint8_t *s_pos = s_mult + na * 16;
     if (HAS_MULT) {
-        const int words = (na * na) >> 2;
+        const int words = COSET ? (na * 16) >> 2 : (na * na) >> 2;
         for (int i = t; i < words; i += TM)
             reinterpret_cast<uint32_t *>(s_mult)[i] = reinterpret_cast<const uint32_t *>(multinv)[i];
+        if (COSET && t < na) s_pos[order[t]] = (uint8_t)t;
         if (!FWD) for (int i = t; i < 3 * na; i += TM) s_A[i] = make_float4(anchors[3 * i], anchors[3 * i + 1], anchors[3 * i + 2], 0.f);
         __syncthreads();
     }
@@ -133,9 +144,14 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // 8 waves, contiguous anchor ranges that all start at an EVEN anchor (8,8,8,8,8,8,6,6 at na = 60)
     // so that a pair of anchors is one aligned 8-byte LDS read; waves w and w+4 share a SIMD
-    const int per = min(APW, (((na + NWV - 1) / NWV) + 1) & ~1);
-    const int a_beg = min(wave_u * per, na);
+    const int per = COSET ? 8 : min(APW, (((na + NWV - 1) / NWV) + 1) & ~1);
+    const int a_beg = min(wave_u * per, na);                          // COSET: first POSITION in the coset-major order
     const int a_cnt = max(0, min(per, na - a_beg));
+    // memory index of the wave's ai-th anchor (COSET: two blocks of the order; otherwise a contiguous range)
+    int am[APW];
+#pragma unroll
+    for (int ai = 0; ai < APW; ++ai)
+        am[ai] = COSET ? __builtin_amdgcn_readfirstlane((int)order[min(a_beg + ai, na - 1)]) : min(a_beg + ai, na - 1);
     const int lk = lane & 31, lh = lane >> 5;
     const int lkc = min(lk, ks - 1);
     // kernel weight  w = relu(1 - |g - k|^2 / sigma) = relu(base_e + kc + g . k'),
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
     f32x2 kxp[APW / 2], kyp[APW / 2], kzp[APW / 2], kcp[APW / 2];
 #pragma unroll
     for (int ai = 0; ai < APW; ++ai) {
-        const float *r3 = rk + ((size_t)min(a_beg + ai, na - 1) * ks + lkc) * 3;
+        const float *r3 = rk + ((size_t)am[ai] * ks + lkc) * 3;
         const float x = r3[0], y = r3[1], z = r3[2];
         kxp[ai >> 1][ai & 1] = 2.f * inv_sigma * x; kyp[ai >> 1][ai & 1] = 2.f * inv_sigma * y; kzp[ai >> 1][ai & 1] = 2.f * inv_sigma * z;
         kcp[ai >> 1][ai & 1] = lk < ks ? -inv_sigma * (x * x + y * y + z * z) : -1e30f;
@@ -184,6 +200,11 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
         const int cl = (u * (TM / 16) + rgrp) % CB;
         row_off[u] = (unsigned)min(c0 + cl, o - 1) * (unsigned)p * (unsigned)na + 4u * (unsigned)pc;
     }
+    int cpos[4] = {0, 0, 0, 0};                        // COSET: where this thread's piece (anchors 4 pc .. 4 pc + 3) lands in a row
+    if (COSET) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) cpos[jj] = s_pos[4 * pc + jj];
+    }
     auto fetch = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
@@ -200,7 +221,13 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             const int row = u * (TM / 16) + rgrp;
             const int cl = row % CB;
             const bool live = stage_p[u] >= 0 && c0 + cl < o && piece < npiece;
-            if (piece < npiece)   // the row pitch has no slack for the idle 16th lane
+            if (COSET) {          // the piece's four anchors go to their positions in the coset-major order (fixed per thread)
+                if (piece < npiece) {
+                    float *dst = s_f + ((size_t)buf * NBK * CB + row) * FP;
+                    const float4 v = live ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    dst[cpos[0]] = v.x; dst[cpos[1]] = v.y; dst[cpos[2]] = v.z; dst[cpos[3]] = v.w;
+                }
+            } else if (piece < npiece)   // the row pitch has no slack for the idle 16th lane
                 *reinterpret_cast<float4 *>(s_f + ((size_t)buf * NBK * CB + row) * FP + 4 * piece) =
                     live ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -293,6 +320,18 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
             for (int ai = 0; ai < APW; ai += 2) {
                 const float2 v = *reinterpret_cast<const float2 *>(frow + min(a_beg + ai, na - 2));
                 fa[ai] = v.x; fa[ai + 1] = v.y;
+            }
+        } else if (COSET) {
+            // the wave's two blocks: source block sigma, inner XOR x -- out[j] = in[j ^ x]
+            const int r = __float_as_int(s_g[gb * NBK + nl].w);
+            const unsigned codes = *reinterpret_cast<const unsigned short *>(s_mult + r * 16 + 2 * wave_u);
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl) {
+                const unsigned code = (codes >> (8 * bl)) & 0xffu;
+                const float4 v = *reinterpret_cast<const float4 *>(frow + 4 * (code & 15u));
+                const bool x0 = (code & 16u) != 0, x1 = (code & 32u) != 0;
+                const float a0 = x0 ? v.y : v.x, a1 = x0 ? v.x : v.y, a2 = x0 ? v.w : v.z, a3 = x0 ? v.z : v.w;
+                fa[4 * bl] = x1 ? a2 : a0; fa[4 * bl + 1] = x1 ? a3 : a1; fa[4 * bl + 2] = x1 ? a0 : a2; fa[4 * bl + 3] = x1 ? a1 : a3;
             }
         } else {
             const int r = __float_as_int(s_g[gb * NBK + nl].w);
@@ -496,7 +535,7 @@ __global__ __launch_bounds__(TM, 2) void so3_inter_group_inv_kernel(
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int cl8 = rr + 4 * lh;
-                        s_o[((size_t)cl8 * ks + lk) * na + a_beg + ai] = acc[ai][ps * 4 + rr];
+                        s_o[((size_t)cl8 * ks + lk) * na + am[ai]] = acc[ai][ps * 4 + rr];
                     }
                 }
             }
@@ -546,7 +585,7 @@ int eap::group_fwd_perm_lists(int b, int c, int p, int n, int nn, int na, int ks
     if (int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_fwd (permuted) shared memory")) return e;
     hipLaunchKernelGGL(kern, dim3(p, (c + CB - 1) / CB, b), dim3(TM), shmem, s, c, n, nn, na, ks, p, 1.0f / sigma, -1, feats,
                        (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, idx, reinterpret_cast<const float4 *>(gx), rk,
-                       mult, (const float *)nullptr, out, blocked, nonident);
+                       mult, (const float *)nullptr, out, blocked, nonident, (const uint8_t *)nullptr);
     return eap::check_launch("so3_inter_group_fwd (permuted clouds, entry-list kernel)");
 }
 
@@ -568,12 +607,64 @@ extern "C" int eap_so3_inter_group_inv_pitch_f32(int b, int o, int p, int nn, in
     return eap::group_lists_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
 }
 
+static int group_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy, const int32_t *rows,
+                     const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx, const float *rk,
+                     const uint8_t *multinv, const float *anchors, int identity_anchor, const uint8_t *coset_order,
+                     const uint8_t *coset_code, float *z, eap_stream_t stream);
+
+namespace {
+// dst[row, i] = src[row, order[i]]: the anchor axis of a [rows, na] tensor re-ordered (thread = one 16-byte word of dst)
+__global__ __launch_bounds__(256) void anchor_reorder_kernel(long long words, int npiece, int na, const float *__restrict__ src,
+                                                             const uint8_t *__restrict__ order, float4 *__restrict__ dst) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    const long long row = i / npiece;
+    const int pc = (int)(i - row * npiece);
+    const float *r = src + row * na;
+    const uchar4 o4 = *reinterpret_cast<const uchar4 *>(order + 4 * pc);
+    dst[i] = make_float4(r[o4.x], r[o4.y], r[o4.z], r[o4.w]);
+}
+}  // namespace
+
+// dst [rows, na] = src with its anchor axis re-ordered: dst[., i] = src[., order[i]] (order uint8 [>= na], 4-byte aligned; na a
+// multiple of 4).  What eap_so3_inter_group_inv_coset_f32 expects of gy when na = 4 mod 8 (its rows then travel by DMA).
+extern "C" int eap_anchor_reorder_f32(int64_t rows, int na, const float *src, const uint8_t *order, float *dst, eap_stream_t stream) {
+    if (rows <= 0 || na <= 0) return 0;
+    if ((na & 3) != 0 || (reinterpret_cast<uintptr_t>(order) & 3) || (reinterpret_cast<uintptr_t>(dst) & 15))
+        return eap::bad_arg("anchor_reorder: na must be a multiple of 4, order 4-byte and dst 16-byte aligned");
+    const long long words = rows * (na >> 2);
+    hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
+                       reinterpret_cast<float4 *>(dst));
+    return eap::check_launch("anchor_reorder");
+}
+
 extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int rcap,
                                            float sigma, const float *gy, const int32_t *rows,
                                            const int32_t *off, const int32_t *cnt,
                                            const int32_t *ent_p, const float *ent_gx, const float *rk,
                                            const uint8_t *multinv, const float *anchors, int identity_anchor, float *z,
                                            eap_stream_t stream) {
+    return group_inv(b, o, p, nn, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, anchors, identity_anchor, nullptr, nullptr, z, stream);
+}
+
+// the same with the coset tables of `multinv` (vgtk/so3conv/functional.py _coset_tables: order uint8 [64], code uint8 [na,16]):
+// the permuted clouds' operand is coset-major in LDS (kernel template COSET).  For na = 4 mod 8 (the 60 anchors) the rows
+// travel by DMA and `gy` must ALREADY have its anchor axis in that order (eap_anchor_reorder_f32); z comes back in memory order.
+extern "C" int eap_so3_inter_group_inv_coset_f32(int b, int o, int p, int nn, int na, int ks, int rcap,
+                                                 float sigma, const float *gy, const int32_t *rows,
+                                                 const int32_t *off, const int32_t *cnt,
+                                                 const int32_t *ent_p, const float *ent_gx, const float *rk,
+                                                 const uint8_t *multinv, const float *anchors, int identity_anchor,
+                                                 const uint8_t *coset_order, const uint8_t *coset_code, float *z, eap_stream_t stream) {
+    if (!multinv || !coset_order || !coset_code || (na & 3) != 0 || na > 64 || (reinterpret_cast<uintptr_t>(coset_code) & 3))
+        return eap::bad_arg("so3_inter_group_inv_coset: permutation and coset tables are required (4-byte aligned), na a multiple of 4 up to 64");
+    return group_inv(b, o, p, nn, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, anchors, identity_anchor, coset_order, coset_code, z, stream);
+}
+
+static int group_inv(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy, const int32_t *rows,
+                     const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx, const float *rk,
+                     const uint8_t *multinv, const float *anchors, int identity_anchor, const uint8_t *coset_order,
+                     const uint8_t *coset_code, float *z, eap_stream_t stream) {
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (na > 64 || (na & 3) != 0) return eap::bad_arg("so3_inter_group_inv: the anchor count must be a multiple of 4, at most 64");
     if (ks > 32) return eap::bad_arg("so3_inter_group_inv: at most 32 kernel points");
@@ -605,11 +696,21 @@ extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, 
         int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
         if (e) return e;
         hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, multinv, anchors, z,
-                           0, (const int32_t *)nullptr);
+                           0, (const int32_t *)nullptr, (const uint8_t *)nullptr);
         return 0;
     };
     int e;
-    if (multinv) e = dma ? launch(so3_inter_group_inv_kernel<true, true>) : launch(so3_inter_group_inv_kernel<true, false>);
+    if (multinv && coset_order) {
+        // (the code table travels in the `multinv` argument slot; with the DMA loader gy's anchor axis is ALREADY coset-major)
+        auto go = [&](auto kern) {
+            int e2 = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "so3_inter_group_inv shared memory");
+            if (e2) return e2;
+            hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, o, p, nn, na, ks, rcap, 1.0f / sigma, identity_anchor, gy, rows, off, cnt, ent_p, g4, rk, coset_code,
+                               anchors, z, 0, (const int32_t *)nullptr, coset_order);
+            return 0;
+        };
+        e = dma ? go(so3_inter_group_inv_kernel<true, true, false, true>) : go(so3_inter_group_inv_kernel<true, false, false, true>);
+    } else if (multinv) e = dma ? launch(so3_inter_group_inv_kernel<true, true>) : launch(so3_inter_group_inv_kernel<true, false>);
     else e = dma ? launch(so3_inter_group_inv_kernel<false, true>) : launch(so3_inter_group_inv_kernel<false, false>);
     if (e) return e;
 #ifdef EAP_INV_TRACE

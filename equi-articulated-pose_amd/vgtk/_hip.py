@@ -251,12 +251,22 @@ def so3_intra_group_bwd(gout, intra_idx):
     return gfeats
 
 
-def so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, sigma, nn, identity_anchor=0, anchors=None):
-    """gy [b,o,p,na] + inverse neighbour lists -> z [b,o,ks,rcap,na] (see include/eap_hip.h)."""
+def so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, sigma, nn, identity_anchor=0, anchors=None, coset=None):
+    """gy [b,o,p,na] + inverse neighbour lists -> z [b,o,ks,rcap,na] (see include/eap_hip.h).  coset = (order, code) of
+    `multinv` (vgtk.so3conv.functional._coset_tables): the permuted clouds' operand is kept coset-major in LDS."""
     b, o, p, na = gy.shape
     rcap = rows.shape[1]
     ks = rk.shape[1]
     z = torch.empty(b, o, ks, rcap, na, dtype=torch.float32, device=gy.device)
+    if multinv is not None and coset is not None:
+        if na % 8 == 4:          # the kernel's DMA loader copies rows as they are: re-order the anchor axis once (csrc/so3_inter_inv.hip)
+            gyc = torch.empty_like(gy)
+            call('eap_anchor_reorder_f32', gy, _I64(b * o * p), na, _ptr(gy), _ptr(coset[0]), _ptr(gyc))
+            gy = gyc
+        call('eap_so3_inter_group_inv_coset_f32', z, b, o, p, nn, na, ks, rcap, _F32(sigma), _ptr(gy), _ptr(rows), _ptr(off),
+             _ptr(cnt), _ptr(ent_p), _ptr(ent_gx), _ptr(rk), _ptr(multinv), _ptr(anchors), int(identity_anchor), _ptr(coset[0]), _ptr(coset[1]),
+             _ptr(z), tag={'flops': 2.0 * b * o * ks * p * nn * na, 'shape': ('group_inv_coset', b, o, p, nn, na, ks, rcap)})
+        return z
     call('eap_so3_inter_group_inv_f32', z, b, o, p, nn, na, ks, rcap, _F32(sigma), _ptr(gy), _ptr(rows), _ptr(off),
          _ptr(cnt), _ptr(ent_p), _ptr(ent_gx), _ptr(rk), _ptr(multinv), _ptr(anchors if multinv is not None else None), int(identity_anchor), _ptr(z),
          tag={'flops': 2.0 * b * o * ks * p * nn * na, 'shape': ('group_inv', b, o, p, nn, na, ks, rcap)})

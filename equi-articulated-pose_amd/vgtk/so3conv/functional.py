@@ -203,6 +203,69 @@ def _group_tables_inverse(mult):
     return multinv
 
 
+_COSETS = {}
+COSET_OPERAND = True      # permuted-pose backward: coset-major LDS operand (False: per-anchor byte-table lookups, for A/B runs)
+
+
+def _coset_tables(table, ident):
+    """For a byte table of LEFT multiplications of an anchor group (table[r][a] = index of g_r . a for some bijection
+    r -> g_r: `mult` or its row-wise inverse), a re-ordering of the anchors that turns every row into block moves:
+
+        order [4*nb]   anchor index at coset-major position i: blocks of 4 = left cosets a.H of a Klein four-group
+                       H = {e, h1, h2, h3} (h_i h_j = h_{i ^ j}), position j of a block = a.h_j;
+        code [na, 16]  for row r and block b: sigma | x << 4 with table[r][order[4 b + j]] == order[4 sigma + (j ^ x)]
+
+    (left multiplication maps left cosets onto left cosets; inside a block it multiplies the H-part: an index XOR).  A
+    kernel that keeps the anchor axis of its LDS operand in `order` reads the four permuted anchors of a block as ONE
+    16-byte word + a shuffle (csrc/so3_inter_inv.hip, COSET).  -> (order uint8 [64] padded with the last anchor, code uint8
+    [na,16]) on the table's device, or None when the group has no such subgroup / the structure check fails."""
+    key = (id(table), table._version, int(ident))
+    hit = _COSETS.get(key)
+    if hit is not None and hit[0]() is table:
+        return hit[1]
+    T = table.detach().cpu().numpy().astype(np.int64)
+    na = T.shape[0]
+    out = None
+    if na % 4 == 0 and na // 4 <= 16:
+        elem = T[:, ident]                                   # row r multiplies by the element with this anchor index
+        row_of = np.empty(na, np.int64)
+        row_of[elem] = np.arange(na)
+        times = lambda a, b: int(T[row_of[a], b])            # a . b as anchor indices
+        invol = [a for a in range(na) if a != ident and times(a, a) == ident]
+        H = None
+        for i, h1 in enumerate(invol):
+            for h2 in invol[i + 1:]:
+                if times(h1, h2) == times(h2, h1) and times(h1, h2) not in (ident, h1, h2):
+                    H = [ident, h1, h2, times(h1, h2)]
+                    break
+            if H:
+                break
+        if H:
+            order, seen = [], set()
+            for a in range(na):
+                if a not in seen:
+                    blk = [times(a, h) for h in H]
+                    order += blk
+                    seen.update(blk)
+            pos = np.empty(na, np.int64)
+            pos[order] = np.arange(na)
+            code = np.zeros((na, 16), np.uint8)
+            ok = len(order) == na
+            for r in range(na):
+                for b in range(na // 4):
+                    src = pos[T[r, order[4 * b]]]
+                    sigma, x = src >> 2, src & 3
+                    code[r, b] = sigma | (x << 4)
+                    ok = ok and all(T[r, order[4 * b + j]] == order[4 * sigma + (j ^ x)] for j in range(4))
+            if ok:
+                padded = np.asarray(order + [order[-1]] * (64 - na), np.uint8)
+                out = (torch.from_numpy(padded).to(table.device), torch.from_numpy(code).to(table.device).contiguous())
+    if len(_COSETS) > 256:
+        _COSETS.clear()
+    _COSETS[key] = (weakref.ref(table), out)
+    return out
+
+
 def rotated_kernels(anchors, kernels):
     """rk [na,ks,3] = A_a kappa_k  (functional.py:L2519)."""
     return torch.matmul(anchors, kernels.transpose(0, 1)).permute(0, 2, 1).contiguous()
@@ -292,8 +355,8 @@ class _Contract(torch.autograd.Function):
         o = W.shape[0]
         y = torch.empty(b, o, pa, dtype=torch.float32, device=x.device)
         if epilogue is not None:
-            if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and torch.is_grad_enabled():
-                raise RuntimeError('a folded epilogue is an inference-time fusion: call under torch.no_grad()')
+            if not epilogue.inference:
+                raise RuntimeError('a folded epilogue is an inference-time fusion: build and use it under torch.no_grad()')
             res = None if epilogue.residual is None else epilogue.residual.contiguous().view(b, o, pa)
             epilogue.applied = _hip.gemm_epilogue(0, o, pa, ck, W, ck, x, pa, ck * pa, y, pa, o * pa, b, epilogue.scale, epilogue.shift,
                                                   epilogue.slope, res)
@@ -413,6 +476,7 @@ class FoldedEpilogue:
     def __init__(self, scale, shift, slope, residual=None):
         self.scale, self.shift, self.slope, self.residual = scale.contiguous(), shift.contiguous(), float(slope), residual
         self.applied = False
+        self.inference = not torch.is_grad_enabled()      # made under torch.no_grad(): the only place it may be applied
 
 
 def _contract_into(W, x, y, layout, epilogue=None, b0=0):
@@ -442,7 +506,7 @@ class _InterConv(torch.autograd.Function):
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None):
+    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None, grad_mode=True):
         feats = feats.contiguous()
         W = W_param.contiguous()
         ctx.anchors = anchors.detach().contiguous() if anchors is not None else None   # the rotations `mult` was built from
@@ -454,10 +518,11 @@ class _InterConv(torch.autograd.Function):
         layout = 0 if not can else (2 if X_LAYOUT == 'transposed' else 1)
         b, c, n, na = feats.shape
         p, ks, o = idx.shape[1], rk.shape[1], W.shape[0]
-        # (under torch.no_grad() needs_input_grad still reports the parameters: nothing will be differentiated then)
-        needs_grad = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and torch.is_grad_enabled()
-        if epilogue is not None and needs_grad:
-            raise RuntimeError('a folded epilogue is an inference-time fusion: call under torch.no_grad()')
+        # grad_mode = torch.is_grad_enabled() AT THE CALL (inside forward() autograd always has it off; and under torch.no_grad()
+        # needs_input_grad still reports the parameters although nothing will be differentiated)
+        needs_grad = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and grad_mode
+        if epilogue is not None and (needs_grad or not epilogue.inference):
+            raise RuntimeError('a folded epilogue is an inference-time fusion: build and use it under torch.no_grad()')
         lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)
         keep = needs_grad and (not lists_ok or _keep_x_hint(W_param))
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
@@ -527,8 +592,9 @@ class _InterConv(torch.autograd.Function):
             off, cnt = head.off[:, :rcap].contiguous(), head.cnt[:, :rcap].contiguous()
             ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
             multinv = _group_tables_inverse(mult) if (mult is not None and any_nonident) else None
+            coset = _coset_tables(multinv, ctx.ident) if (multinv is not None and COSET_OPERAND) else None
             z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
-                                         ctx.ident, ctx.anchors)                     # [b,o,ks,rcap,na]
+                                         ctx.ident, ctx.anchors, coset)              # [b,o,ks,rcap,na]
             ra = rcap * na
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
@@ -558,7 +624,7 @@ class _InterConv(torch.autograd.Function):
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
-        return gF, gW, None, None, None, None, None, None, None, None, None
+        return gF, gW, None, None, None, None, None, None, None, None, None, None
 
 
 INTRA_DW_SLICE = 64      # channels whose 12-tap gather is materialised at a time for the intra weight gradient
@@ -731,7 +797,7 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
     gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
     y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident,
-                         anchors if mult is not None else None, epilogue)
+                         anchors if mult is not None else None, epilogue, torch.is_grad_enabled())
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 
@@ -771,7 +837,7 @@ def inter_so3conv_fused_art_mode(xyz, pose, feats, W, seg_labels, n_neighbor, an
         first = xyz[:, 0].contiguous()
         g_rot, nonident = _hip.so3_prep(first, first, ball_idx, rot, rot, anchors.contiguous(), ident)
         gx = torch.cat([gx[..., :3], g_rot[..., 3:]], dim=-1).contiguous()
-    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), ident, nonident, anchors if mult is not None else None, None)
+    y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), ident, nonident, anchors if mult is not None else None, None, torch.is_grad_enabled())
     inter_w = InterWeights(gx, rk, sigma)
     return (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 

@@ -237,6 +237,19 @@ int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int
                                 const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
                                 const float *rk, const uint8_t *multinv, const float *anchors,
                                 int identity_anchor, float *z, eap_stream_t stream);
+/* The same for clouds with anchor permutations, given the coset tables of `multinv` (order uint8 [64]: anchor at every position of
+ * a coset-major ordering, blocks of 4 = left cosets of a Klein four-group of the anchor group; code uint8 [na,16], 4-byte
+ * aligned: per permutation row and block `sigma | x << 4`): the LDS operand is kept in that order, so the four permuted anchors
+ * of a block are one 16-byte read of block sigma + an index-XOR shuffle.  Same results to the last bit of the products summed
+ * (the anchors are visited in another order only across waves). */
+/* dst [rows, na] = src with its anchor axis re-ordered, dst[., i] = src[., order[i]]: for na = 4 mod 8 the entry below takes gy's
+ * rows by DMA and expects them in coset-major order already. */
+int eap_anchor_reorder_f32(int64_t rows, int na, const float *src, const uint8_t *order, float *dst, eap_stream_t stream);
+int eap_so3_inter_group_inv_coset_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma,
+                                      const float *gy, const int32_t *rows, const int32_t *off, const int32_t *cnt,
+                                      const int32_t *ent_p, const float *ent_gx, const float *rk, const uint8_t *multinv,
+                                      const float *anchors, int identity_anchor, const uint8_t *coset_order,
+                                      const uint8_t *coset_code, float *z, eap_stream_t stream);
 
 /* so3_inter_group_inv without anchor permutation, gy stored with a row pitch: gy [b,o,p,gy_pitch], gy_pitch a
  * multiple of 4 and >= na (64 makes every 60-anchor row start on a 256-byte boundary). */

@@ -18,13 +18,25 @@ w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
 R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
               2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(B, P, 3, 3)
 rand_pose = np.tile(np.eye(4, dtype=np.float32), (B, P, 1, 1)); rand_pose[..., :3, :3] = R
-for name, ps in (('identity poses', torch.from_numpy(pose).to(dev)), ('random per-point poses', torch.from_numpy(rand_pose).to(dev))):
-    f = torch.randn(B, c, P, 60, device=dev, requires_grad=True)
-    for it in range(2):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
-        yv = conv(zptk.SphericalPointCloudPose(xyz, f, None, ps))[3].feats
-        e1.record()
-        torch.autograd.grad(yv, [f, conv.basic_conv.W], gy)
-        e2.record(); torch.cuda.synchronize()
-    print(f'{name}: forward {e0.elapsed_time(e1):.1f} ms, backward {e1.elapsed_time(e2):.1f} ms', flush=True)
+_, lab, _ = synth_clouds.laptop_batch(0, B, P)
+part_pose = np.tile(np.eye(4, dtype=np.float32), (B, P, 1, 1))
+for bi in range(B):                                   # one rotation per rigid part (the articulated-object case)
+    part_pose[bi, :, :3, :3] = R[bi, :2][lab[bi]]
+import vgtk.so3conv.functional as L
+for name, ps in (('identity poses', torch.from_numpy(pose).to(dev)), ('one rotation per rigid part', torch.from_numpy(part_pose).to(dev)),
+                 ('random per-point poses', torch.from_numpy(rand_pose).to(dev))):
+    for coset in ((True, False) if name != 'identity poses' else (True,)):
+        L.COSET_OPERAND = coset
+        f = torch.randn(B, c, P, 60, device=dev, requires_grad=True)
+        ts = []
+        for it in range(4):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            yv = conv(zptk.SphericalPointCloudPose(xyz, f, None, ps))[3].feats
+            e1.record()
+            torch.autograd.grad(yv, [f, conv.basic_conv.W], gy)
+            e2.record(); torch.cuda.synchronize()
+            ts.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        fw, bw = sorted(t[0] for t in ts[1:])[1], sorted(t[1] for t in ts[1:])[1]
+        print(f'{name}{"" if name == "identity poses" else (", coset-major operand" if coset else ", byte-table lookups")}: forward {fw:.1f} ms, backward {bw:.1f} ms', flush=True)
+L.COSET_OPERAND = True
