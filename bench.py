@@ -154,11 +154,9 @@ class StandInLoss(torch.autograd.Function):
 CPU_BASELINE_THREADS = 16   # torch CPU ops of this path slow down beyond ~8-16 threads (measured on the 256-core GPU host)
 
 
-def cpu_baseline(points, slab=32):
-    """Oracle (oracle/so3_ref.py) fwd+bwd of the 3 layers on a slab of `slab` query points of one `points`-point cloud,
-    scaled to the whole cloud, by BASELINE.md section 2's protocol: 1 warm-up + 3 timed runs (median), at 16 threads AND at
-    os.cpu_count() threads (both stated; `value` / `cores` = the faster of the two).  Faithful = with the reference's 60x60
-    anchor-permutation search; `short_circuit` = search skipped (identity poses), at the faster thread count."""
+def cpu_probe(points, threads, skip, slab=32, runs=3):
+    """One thread count of the CPU baseline, in THIS process: 1 warm-up + `runs` timed runs of the oracle (oracle/so3_ref.py)
+    fwd+bwd of the 3 layers on a slab of `slab` query points of one `points`-point cloud -> dict."""
     import synth_clouds
     from oracle import so3_ref
     consts = np.load(os.path.join(PKG, 'vgtk', 'data', 'anchors', 'constants.npz'))
@@ -166,8 +164,9 @@ def cpu_baseline(points, slab=32):
     anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors()))
     xyz, _, pose = synth_clouds.laptop_batch(0, 1, points)
     xyz, pose = torch.from_numpy(xyz), torch.from_numpy(pose)
+    torch.set_num_threads(threads)
 
-    def one_run(skip):
+    def one_run():
         total = 0.0
         gen = torch.Generator().manual_seed(2913)
         for (c, o, r, s) in synth_clouds.backbone_layers(points):
@@ -183,23 +182,38 @@ def cpu_baseline(points, slab=32):
             total += time.perf_counter() - t0
         return total
 
-    def protocol(threads, skip, give_up_after=None):
-        torch.set_num_threads(threads)
-        warm = one_run(skip)                            # warm-up
-        if give_up_after is not None and warm > give_up_after:
-            # (torch's CPU ops of this path get slower, not faster, with hundreds of threads: one run instead of four keeps the
-            # default bench within its minutes)
-            return {'threads': threads, 'clouds_per_sec': 1.0 / (warm * points / slab), 'runs_s': [round(warm, 3)],
-                    'note': f'warm-up run only: slower than {give_up_after:.1f} s (3 x the {CPU_BASELINE_THREADS}-thread median)'}
-        runs = sorted(one_run(skip) for _ in range(3))
-        return {'threads': threads, 'clouds_per_sec': 1.0 / (runs[1] * points / slab), 'runs_s': [round(r, 3) for r in runs]}
+    one_run()                                           # warm-up
+    times = sorted(one_run() for _ in range(runs))
+    return {'threads': threads, 'clouds_per_sec': 1.0 / (times[len(times) // 2] * points / slab), 'runs_s': [round(t, 3) for t in times]}
+
+
+def cpu_baseline(points, slab=32):
+    """The CPU oracle beside the GPU number, by BASELINE.md section 2's protocol (1 warm-up + 3 timed runs, median) at 16
+    threads AND at os.cpu_count() threads (both stated; `value` / `cores` = the faster).  Faithful = with the reference's 60x60
+    anchor-permutation search; `short_circuit` = search skipped (identity poses), at the faster thread count.  Every thread
+    count runs in a CHILD process under a hard time limit: torch's CPU ops of this path can take minutes per run with
+    hundreds of threads (256 threads: 54 s for what 16 threads do in 2 s), and the default bench must end within minutes."""
+    import subprocess
+
+    def probe(threads, skip, limit):
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-probe', str(threads), '--points', str(points)] + (['--probe-skip-search'] if skip else [])
+        env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, env=env)
+            lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+            if out.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            return {'threads': threads, 'clouds_per_sec': None, 'note': 'probe failed: ' + out.stderr[-200:]}
+        except subprocess.TimeoutExpired:
+            return {'threads': threads, 'clouds_per_sec': None, 'note': f'1 warm-up + 3 runs did not finish within {limit} s'}
 
     ncpu = os.cpu_count() or 1
-    faithful = [protocol(min(ncpu, CPU_BASELINE_THREADS), False)]
+    faithful = [probe(min(ncpu, CPU_BASELINE_THREADS), False, 150)]
     if ncpu > CPU_BASELINE_THREADS:
-        faithful.append(protocol(ncpu, False, give_up_after=3.0 * faithful[0]['runs_s'][len(faithful[0]['runs_s']) // 2]))
-    best = max(faithful, key=lambda d: d['clouds_per_sec'])
-    short = protocol(best['threads'], True)
+        faithful.append(probe(ncpu, False, 45))
+    done = [f for f in faithful if f.get('clouds_per_sec')]
+    best = max(done, key=lambda d: d['clouds_per_sec']) if done else {'threads': min(ncpu, CPU_BASELINE_THREADS), 'clouds_per_sec': None}
+    short = probe(best['threads'], True, 120)
     model = 'unknown'
     try:
         for ln in open('/proc/cpuinfo'):
@@ -210,11 +224,11 @@ def cpu_baseline(points, slab=32):
         pass
     return {'value': best['clouds_per_sec'], 'unit': 'point-clouds/sec', 'cores': best['threads'], 'kind': 'port',
             'host_logical_cpus': ncpu, 'host_cpu_model': model,
-            'protocol': 'BASELINE.md section 2: 1 warm-up + 3 timed runs, median; torch.set_num_threads at each listed count',
+            'protocol': 'BASELINE.md section 2: 1 warm-up + 3 timed runs, median; torch.set_num_threads at each listed count; each count in a child process with a time limit',
             'by_threads': faithful,
             'sample': f'oracle fwd+bwd of the 3 backbone layers on {slab} of {points} query points of 1 cloud, '
                       f'scaled x{points // slab}; includes the reference\'s 60x60 anchor-permutation search',
-            'value_perm_search_short_circuited': short['clouds_per_sec'], 'short_circuit_runs_s': short['runs_s']}
+            'value_perm_search_short_circuited': short.get('clouds_per_sec'), 'short_circuit_runs_s': short.get('runs_s')}
 
 
 def zpconv_roofline(dev, points, clouds=8, channels=64):
@@ -583,9 +597,14 @@ def main(argv=None):
     ap.add_argument('--plan-points', type=int, default=None, help='radii / sigmas of the backbone built for this input size (default: --points)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short runs of the other BASELINE configurations (config 3 composite included)')
     ap.add_argument('--plain', action='store_true', help='warm-up + timed steps only (no attribution loop, no A/B leg, no extras): what the counter passes of tools/gpu/profile_round.sh run')
+    ap.add_argument('--cpu-baseline-probe', type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline(): one thread count, no GPU
+    ap.add_argument('--probe-skip-search', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--check-launch', action='store_true', help='start the ranks, run the two exchanges on small tensors, print what was started (no GPU needed)')
     args = ap.parse_args(argv)
 
+    if args.cpu_baseline_probe > 0:
+        print(json.dumps(cpu_probe(args.points, args.cpu_baseline_probe, args.probe_skip_search)))
+        return
     if args.gpus > 1 and 'RANK' not in os.environ:
         # no launcher around us: start the N ranks ourselves (the driver's N = 1 command form with --gpus N)
         sys.exit(launch_ranks(args.gpus, argv))
@@ -752,7 +771,7 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.points)
             progress('cpu baseline done')
-            line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
+            line['speedup_vs_cpu_baseline'] = (line['value'] / line['cpu_baseline']['value']) if line['cpu_baseline']['value'] else None
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
