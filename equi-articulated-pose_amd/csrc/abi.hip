@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <string.h>
+#include <mutex>
 
 namespace eap {
 static thread_local char g_err[256] = "";
@@ -21,6 +22,7 @@ void set_kernel(const char *name) {
 namespace {
 struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 Side g_side[64];
+std::mutex g_side_mutex;       // creation only: the events are recorded / waited on by the calling thread's own launches
 }  // namespace
 static int side_of(Side **out) {
     int dev = 0;
@@ -28,6 +30,7 @@ static int side_of(Side **out) {
     if (e) return e;
     if (dev < 0 || dev >= 64) return bad_arg("side stream: device index out of range");
     Side &sd = g_side[dev];
+    std::lock_guard<std::mutex> lock(g_side_mutex);
     if (!sd.stream) {
         if ((e = hip_fail(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "side stream (create)"))) return e;
         if ((e = hip_fail(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "side stream (event)"))) return e;

@@ -10,22 +10,28 @@
 // layer's radius -- so the scatter target of a cloud, [rows x 60 anchors x C] floats (4.3 MB at 280 rows, C = 64), fits the
 // chip's LDS when it is spread over 30 workgroups:
 //
-//   workgroup = (cloud, point range, anchor QUAD, 32 channels), one per CU, 4 waves = the quad's anchors;
-//   LDS      = acc[row slot][4 anchors][32 channels] (512 B per referenced row; 294 rows + a dump row) + one point's
-//              operand stage (12.25 KB);
-//   per point and wave: T[n, c] = sum_k w[p,a,k,n] grad[c,k,p,a] as 2 x 12 v_mfma_f32_32x32x2_f32 (M = neighbours,
-//              N = channels, K = kernel points: no padding), then 32 ds_add_f32 of the accumulator registers into
-//              acc[slot(idx[p,n])][a][c] -- lanes run along the channels (conflict-free), and an accumulator word is
-//              only ever touched by ONE wave, in program order: the sums are bit-reproducible, no global atomics;
-//   w        is streamed straight into registers (8 bytes per lane: neighbours 2m, 2m+1 = the two M tiles), one point
-//              ahead; grad[c,k,p,4 anchors] arrives as 16-byte pieces (one piece serves the four waves), one point
+//   workgroup = (cloud, point range, anchor QUAD, 32 channels), one per CU (all 160 KB of LDS), 8 waves = (anchor of the
+//              quad, half of the point's 64 neighbours), two per SIMD;
+//   LDS      = acc[row slot][4 anchors][32 channels] (512 B per referenced row, at most 295 rows + a dump row for
+//              out-of-range indices) + one operand stage (12.25 KB), two when the rows leave room (<= 271);
+//   per point and wave: T[32 n, 32 c] = sum_k w[p,a,k,n] grad[c,k,p,a] as 12 v_mfma_f32_32x32x2_f32 (M = neighbours,
+//              N = channels, K = kernel points: no padding), then acc[slot(idx[p,n])][a][c] += T as read - add - write;
+//              lanes run along the channels (conflict-free).  A word receives at most ONE contribution per point -- a list
+//              names a support row once; checked on the device, a cloud whose lists repeat a row (the ball query pads short
+//              lists with their first hit) is reported and left to the other path -- and the workgroup meets at a barrier
+//              between points, so every word sums its points in order: bit-reproducible, no atomics anywhere.  (LDS float
+//              atomics were the first version: ds_add_f32 costs ~800 cycles per wave-instruction on this part, 59 ms
+//              against 9.5; profiles/r04_zpconv_bwd_hot_ablation.txt.)
+//   w        streams straight into registers (4 bytes per lane and kernel point, the wave's 32 neighbours), two points
+//              ahead; grad[c,k,p,4 anchors] arrives as 16-byte pieces (one piece serves the quad's four anchors), two points
 //              ahead in registers, then through the LDS stage [anchor][k][c];
 //   end      the workgroup writes its rows to gfeats (16-byte stores along the anchors), or, when a cloud's points
-//              are split over several workgroups to fill the chip (small batches), to a partial buffer that a second
-//              kernel sums in a fixed order.
-// w is read by the two channel halves of a quad (2 x), everything else once: 6.1 GB per cloud instead of 16.8.
-// A cloud whose referenced rows do not fit (or whose 5-D index is not one list per point) is reported in `status` and
-// left to csrc/zpconv_bwd.hip.
+//              are split over several workgroups to fill the chip (batches below 8 clouds), to a partial buffer that a
+//              second kernel sums in a fixed order.
+// w is read by the two channel halves of a quad (2 x), everything else once: 6.1 GB per cloud instead of 16.8.  The 5-D index
+// check (the op's 12 GB index read) streams on a side stream beside these kernels.
+// A cloud whose referenced rows do not fit, whose lists repeat a row, or whose 5-D index is not one list per point is
+// reported in `status` and left to csrc/zpconv_bwd.hip.
 #include "common.h"
 #include <stdlib.h>
 
@@ -42,9 +48,9 @@ constexpr int NT = 2;                         // neighbour halves = MFMA M tiles
 constexpr int TM = 64 * AQ * NT;              // 8 waves: (anchor, neighbour half), two per SIMD
 constexpr int ROWB = AQ * CH * 4;             // bytes of accumulators per referenced row
 constexpr int STAGE_G = AQ * KS * CH * 4;     // grad stage [anchor][k][c]
-constexpr int STAGE_S = NN * 4;               // slot byte offsets of the point's 64 neighbours, [tile t][row m]: n = 2 m + t
+constexpr int STAGE_S = NN * 4;               // byte offsets of the accumulator rows of the point's 64 neighbours
 constexpr int LDS_BYTES = 160 * 1024;
-constexpr int RCAP = (LDS_BYTES - STAGE_G - STAGE_S) / ROWB - 1;      // 294 rows + one dump row for out-of-range indices
+constexpr int RCAP = (LDS_BYTES - STAGE_G - STAGE_S) / ROWB - 1;      // referenced rows a cloud may have (+ one dump row)
 
 // Timing ablations (WRONG RESULTS), compiled only with `make ABLATION=1` and selected by EAP_ZPHOT_DEBUG (bit mask): 1 no LDS
 // accumulation, 2 no grad requests after the prologue, 4 no weight requests after the prologue, 8 no matrix instructions,
@@ -300,10 +306,10 @@ __global__ __launch_bounds__(256) void zp_hot_reduce_kernel(int S, int nq, int n
 }
 
 // Workspace layout, shared by the size query and the launcher (every chunk on a 256-byte boundary):
-//   flag [b] | status [b] | n_rows [b] | idx0 [b,np,64] | counts, rows, off, cnt, slot_of [b,nq] | slot_off [b,np,64] |
+//   flag [b] | n_rows [b] | idx0 [b,np,64] | counts, rows, off, cnt, slot_of [b,nq] | slot_off [b,np,64] |
 //   partial [b, S, members, RCAP, 4, 32] (S > 1 only)
 struct HotWorkspace {
-    int64_t flag, status, n_rows, idx0, counts, rows, off, cnt, slot_of, slot_off, partial, total;
+    int64_t flag, n_rows, idx0, counts, rows, off, cnt, slot_of, slot_off, partial, total;
     int S;
     HotWorkspace(int b, int np, int nq, int na, int c) {
         S = b >= 8 ? 1 : (8 + b - 1) / b;                       // point ranges per cloud: at least 8 groups of 30 workgroups
@@ -311,7 +317,7 @@ struct HotWorkspace {
         const int64_t fl = 4 * 64 * (((int64_t)b + 63) / 64), ent = 4ll * b * np * NN, rq = 4ll * b * nq;
         int64_t at = 0;
         auto take = [&](int64_t bytes) { const int64_t r = at; at += (bytes + 255) / 256 * 256; return r; };
-        flag = take(fl); status = take(fl); n_rows = take(fl);
+        flag = take(fl); n_rows = take(fl);
         idx0 = take(ent);
         counts = take(rq); rows = take(rq); off = take(rq); cnt = take(rq); slot_of = take(rq);
         slot_off = take(ent);
