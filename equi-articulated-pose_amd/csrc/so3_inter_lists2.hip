@@ -66,7 +66,8 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 
 // Timing ablations (WRONG RESULTS), compiled only with `make ABLATION=1` and selected by EAP_LISTS2_DEBUG (bit mask):
 // 1 no feature DMA after the prologue, 2 constant weights (no weight evaluation), 4 no row-end stores, 8 no chunk barrier
-// (only together with 1), 16 no per-k-step LDS operand reads.  tools/lists2_ablation.py
+// (only together with 1), 16 no per-k-step LDS operand reads; PERM: 32 no block move (DMA pieces from the thread's own
+// block), 64 no in-block XOR (selects).  tools/lists2_ablation.py, tools/lists2_perm_ablation.py
 #ifdef EAP_ABLATION
 #define ABL(bit) ((dbg & (bit)) != 0)
 #else
@@ -81,12 +82,32 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // stores per wave instead of 128 dword stores; both operands of v_mfma_f32_32x32x2_f32 use the same lane mapping, so the
 // k-loop is unchanged).  Needs ks % 4 == 0.
 #define EAP_MM(f, w, c, x, y, z) (LAYOUT == 3 ? __builtin_amdgcn_mfma_f32_32x32x2f32(w, f, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(f, w, c, 0, 0, 0))
-template <bool LISTS, int LAYOUT>
+//
+// PERM = true: clouds WITH per-entry anchor permutations (articulated input: relative rotations between neighbours), round 4.
+// The permutation of an entry is a left multiplication in the anchor group; with the operand's anchor axis in COSET-MAJOR
+// order (blocks of 4 = left cosets of a Klein four-group, vgtk/so3conv/functional.py _coset_tables; the caller re-orders F
+// once, eap_anchor_reorder_f32) it moves whole 16-byte blocks and XORs the position inside: code[r][block] = sigma | x << 4.
+// The BLOCK move costs nothing here: a lane of the global -> LDS DMA names its own source address, so the piece of block
+// beta of entry e is simply fetched from block sigma_r(beta) of the row -- the LDS image of a workgroup holds its own 16
+// anchors only, exactly as without permutation (csrc/so3_inter_inv.hip had to keep whole 60-anchor rows on chip: one
+// workgroup per CU, one channel tile per weight).  The XOR inside the block is 8 selects per 16-byte operand read.
+// Everything that depends on the entry's rotation r alone is prepared per ENTRY by eap_so3_perm_entries_f32 (below), not
+// per (entry, workgroup, chunk) in here -- table lookups inside the chunk loop cost 12.6 of 71 ms when they were
+// (profiles/r04_lists2_perm_ablation.txt):
+//   ent_p  uint32 [entries][4 anchor groups][4 pieces]: byte offset of the piece's source inside a channel row of the cloud
+//                              (point * row bytes + 16 * sigma_r(block)); a group's four words are one 16-byte ring entry
+//   ent_gx [entries][4]:       offset vector, rotated by A_r in the backward (the weights are then those of the wave's OWN
+//                              anchors, see so3_inter_inv.hip), dead (1e18) for shadow neighbours; w = the x bits of all 15
+//                              blocks, 2 per block
+// The backward's output Z keeps the coset-major anchor order (contiguous 16-byte stores; the caller un-permutes the small
+// tensors that follow); the forward's transposed output has one row per anchor and comes back in memory order.
+template <bool LISTS, int LAYOUT, bool PERM = false>
 __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, int AG, int RPB, int ag_major, int dbg, float inv_sigma,
     const float *__restrict__ F, const int32_t *__restrict__ rows, const int32_t *__restrict__ off,
     const int32_t *__restrict__ cnt, const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
-    const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out) {
+    const float *__restrict__ rk, const int32_t *__restrict__ nonident, float *__restrict__ out,
+    const uint8_t *__restrict__ order = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // ---- block -> (row run, anchor group, channel slice, cloud); an XCD gets whole (slice, cloud) pairs when their
@@ -119,7 +140,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     }
     const int r_begin = run * RPB, rows_blk = min(RPB, R - r_begin);
     const int cy = sl % ny, bi = sl / ny, c0 = cy * CB;
-    if (nonident != nullptr && __builtin_amdgcn_readfirstlane(nonident[bi]) != 0) return;   // permuted cloud: not ours
+    if (nonident != nullptr && (__builtin_amdgcn_readfirstlane(nonident[bi]) != 0) != PERM) return;   // permuted clouds: the PERM kernel's, the others: not
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -131,7 +152,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 
     float *s_f = reinterpret_cast<float *>(smem);                           // [2][NBK][CB][PITCH]
     float4 *s_g = reinterpret_cast<float4 *>(s_f + 2 * NBK * CB * PITCH);   // [3][NBK] ring
-    int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] ring
+    int *s_p = reinterpret_cast<int *>(s_g + 3 * NBK);                      // [3][NBK] ring (PERM: [3][NBK][4], byte offsets of the four pieces)
 
     int n_ent, nchunk_row;
     size_t e0;
@@ -147,11 +168,19 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     }
     const int nchunk = LISTS ? nchunk_row : rows_blk * nchunk_row;
 
+    // memory index of the wave's ai-th anchor (PERM: position a0 + al_beg + ai of the coset-major order)
+    int am[APW];
+#pragma unroll
+    for (int ai = 0; ai < APW; ++ai) {
+        const int pos = a0 + min(al_beg + ai, gcount - 1);
+        am[ai] = PERM ? __builtin_amdgcn_readfirstlane((int)order[pos]) : pos;
+    }
+    const int blk_w = (a0 >> 2) + wave_u;                          // PERM: the wave's block of the order
     // ---- per-lane weight constants of this wave's anchors (k = lane & 31): see csrc/so3_inter_lists.hip ----
     f32x2 kxp[APW / 2], kyp[APW / 2], kzp[APW / 2], kcp[APW / 2];
 #pragma unroll
     for (int ai = 0; ai < APW; ++ai) {
-        const int a = a0 + min(al_beg + ai, gcount - 1);
+        const int a = am[ai];
         const float *r3 = rk + ((size_t)a * ks + min(lk, ks - 1)) * 3;
         const float x = r3[0], y = r3[1], z = r3[2];
         kxp[ai >> 1][ai & 1] = 2.f * inv_sigma * x;
@@ -177,12 +206,14 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     const unsigned row_bytes = (unsigned)fpitch * 4u;
     const int d_row = t >> 2, d_piece = ((t & 3) - (d_row >> 2)) & 3;
     const bool d_valid = d_piece < npg;
-    const unsigned dma_off = ((unsigned)(min(c0 + d_row, C - 1) - c0) * (unsigned)PF * (unsigned)fpitch + (unsigned)(a0 + 4 * min(d_piece, npg - 1))) * 4u;
+    const unsigned dma_off = ((unsigned)(min(c0 + d_row, C - 1) - c0) * (unsigned)PF * (unsigned)fpitch + (PERM ? 0u : (unsigned)(a0 + 4 * min(d_piece, npg - 1)))) * 4u;
+    const int d_pc = min(d_piece, npg - 1), blk_t = (a0 >> 2) + d_pc;   // PERM: the block this thread's DMA piece belongs to
     const unsigned lds_g = lds_addr(s_g), lds_p = lds_addr(s_p);
     auto issue_idx = [&](int j0, int slot) {
         if (wave_u == 0 && lane < NBK) {
             const size_t e = e0 + min(j0 + lane, max(n_ent - 1, 0));
-            glds4(ent_p + e, __builtin_amdgcn_readfirstlane(lds_p + (unsigned)slot * NBK * 4u));
+            if (PERM) glds16(ent_p + 4 * (4 * e + ag), __builtin_amdgcn_readfirstlane(lds_p + (unsigned)slot * NBK * 16u));
+            else glds4(ent_p + e, __builtin_amdgcn_readfirstlane(lds_p + (unsigned)slot * NBK * 4u));
             glds16(ent_gx + e, __builtin_amdgcn_readfirstlane(lds_g + (unsigned)slot * NBK * 16u));
         }
     };
@@ -190,6 +221,10 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     auto prep_rows = [&](int slot) {
 #pragma unroll
         for (int u = 0; u < NSTD; ++u) {
+            if (PERM) {                // byte offset of the piece inside the cloud's channel row: point row + its SOURCE block
+                src_off[u] = dma_off + (ABL(32) ? (unsigned)s_p[(slot * NBK + u) * 4] + 16u * (unsigned)blk_t : (unsigned)s_p[(slot * NBK + u) * 4 + d_pc]);
+                continue;
+            }
             int pe = s_p[slot * NBK + u];
             if (!LISTS) pe = (unsigned)pe < (unsigned)PF ? pe : 0;     // shadow row: any valid row, weight 0
             src_off[u] = dma_off + __umul24((unsigned)pe, row_bytes);
@@ -217,8 +252,14 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
         const float4 g = s_g[gslot * NBK + e];
         float b = 1.0f - inv_sigma * (g.x * g.x + g.y * g.y + g.z * g.z);
         bool dead = ch * NBK + e >= n_ent;
-        if (!LISTS) dead = dead || (unsigned)s_p[gslot * NBK + e] >= (unsigned)PF;
+        if (!LISTS && !PERM) dead = dead || (unsigned)s_p[gslot * NBK + e] >= (unsigned)PF;     // (PERM: shadow entries carry a dead offset vector)
         return __float_as_int(dead ? -1e30f : b);
+    };
+    // PERM: position j of the wave's block takes the value at position j ^ x of the source block
+    auto unxor = [&](float4 &v, int x) {
+        const bool x0 = (x & 1) != 0, x1 = (x & 2) != 0;
+        const float a0_ = x0 ? v.y : v.x, a1_ = x0 ? v.x : v.y, a2_ = x0 ? v.w : v.z, a3_ = x0 ? v.z : v.w;
+        v = make_float4(x1 ? a2_ : a0_, x1 ? a3_ : a1_, x1 ? a0_ : a2_, x1 ? a1_ : a3_);
     };
     auto gather = [&](const float4 *fab, int gslot, int bases, int s, float4 &fa, float4 &fb1, float4 &g, float &bk) {
         if (ABL(16)) {
@@ -229,6 +270,11 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
         fb1 = fab[s * STEP_F4 + TILE_F4];
         g = s_g[gslot * NBK + 2 * s + lh];
         bk = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (2 * s + lh), bases));
+        if (PERM && !ABL(64)) {
+            const int x = __float_as_int(g.w) >> (2 * blk_w);        // the entry's x bits, 2 per block
+            unxor(fa, x);
+            unxor(fb1, x);
+        }
     };
     auto nothing = [] {};
     // one MFMA k-step (2 entries): 4 weights per lane, 8 matrix instructions; q0..q3 run after MFMA pairs 1..4
@@ -292,7 +338,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
             // 8 q + 4 lh .. + 3 -- 16 contiguous bytes of out[b][row*na + a][c*ks + k]
             if (active && !ABL(4)) {
                 const size_t CK = (size_t)C * ks;
-                float *rb = obb + ((size_t)row * na + a0 + al_beg) * CK + (size_t)c0 * ks;      // uniform
+                float *rb = obb + ((size_t)row * na + (PERM ? 0 : a0 + al_beg)) * CK + (size_t)c0 * ks;      // uniform
                 const unsigned lo_b = (unsigned)(lk * ks + 4 * lh) * 4u;
                 asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // the accumulators were last written by MFMAs the asm cannot see
 #pragma unroll
@@ -306,7 +352,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
                             for (int ai = 0; ai < APW; ++ai) {
                                 const f32x4 v = {acc[ct][ai][4 * q], acc[ct][ai][4 * q + 1], acc[ct][ai][4 * q + 2], acc[ct][ai][4 * q + 3]};
                                 asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lo_b), "v"(v),
-                                             "s"(rb + (size_t)ai * CK + (size_t)(32 * ct) * ks + 8 * q) : "memory");
+                                             "s"(rb + (size_t)(PERM ? am[ai] : ai) * CK + (size_t)(32 * ct) * ks + 8 * q) : "memory");
                             }
                         }
                     }
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
             if (LAYOUT == 2) {
                 // transposed output out[b][row*na + a][c*ks + k] (the plain [P*A, C*K] matrix the contraction GEMM reads)
                 const size_t CK = (size_t)C * ks;
-                float *rb = obb + ((size_t)row * na + a0 + al_beg) * CK + (size_t)c0 * ks;      // uniform
+                float *rb = obb + ((size_t)row * na + (PERM ? 0 : a0 + al_beg)) * CK + (size_t)c0 * ks;      // uniform
                 const unsigned lo_b = (unsigned)((4 * lh) * ks + lk) * 4u;
                 asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // the accumulators were last written by MFMAs the asm cannot see
 #pragma unroll
@@ -329,14 +375,14 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 #pragma unroll
                             for (int ai = 0; ai < APW; ++ai)
                                 asm volatile("global_store_dword %0, %1, %2" : : "v"(lo_b), "v"(acc[ct][ai][r]),
-                                             "s"(rb + (size_t)ai * CK + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * ks) : "memory");
+                                             "s"(rb + (size_t)(PERM ? am[ai] : ai) * CK + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * ks) : "memory");
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if (c0 + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh < C) {
 #pragma unroll
                                 for (int ai = 0; ai < APW; ++ai)
-                                    *reinterpret_cast<float *>(reinterpret_cast<char *>(rb + (size_t)ai * CK + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * ks) + lo_b) = acc[ct][ai][r];
+                                    *reinterpret_cast<float *>(reinterpret_cast<char *>(rb + (size_t)(PERM ? am[ai] : ai) * CK + (size_t)(32 * ct + (r & 3) + 8 * (r >> 2)) * ks) + lo_b) = acc[ct][ai][r];
                             }
                     }
                 }
@@ -419,22 +465,29 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 }
 
 constexpr size_t SHMEM = 2 * BUF_BYTES + 16 * 3 * NBK + 16 * NBK;
+constexpr size_t SHMEM_PERM = 2 * BUF_BYTES + 16 * 3 * NBK + 16 * 3 * NBK;
 
 int g_xcd_map_fwd = 1, g_xcd_map_inv = 1;       // eap_so3_group_lists_xcd_map
 int g_store16 = 1;                              // eap_so3_group_lists_store16
 
+int g_perm_lists2 = 1;                          // eap_so3_group_perm_lists2
+
 template <bool LISTS>
 int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R, int nn, int ent_stride, float sigma, const float *F,
             const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p, const float *ent_gx,
-            const float *rk, const int32_t *nonident, float *out, hipStream_t s, const char *what) {
+            const float *rk, const int32_t *nonident, float *out, hipStream_t s, const char *what, const uint8_t *order = nullptr) {
     if (fpitch < na || (fpitch & 3) != 0) return eap::bad_arg("so3_group_lists2: the feature row pitch must be a multiple of 4, at least the anchor count");
     if ((long long)CB * PF * fpitch * 4 >= (1ll << 32) || PF >= (1 << 24) || fpitch * 4 >= (1 << 24))
         return eap::bad_arg("so3_group_lists2: 64 feature rows of a cloud exceed the 32-bit request offsets");
     if (((long long)ks * R * na * 4 + 64ll * R * na + 64) * 4 >= (1ll << 31) || (long long)CB * ks * 4 >= (1ll << 31))
         return eap::bad_arg("so3_group_lists2: output rows too far apart for 32-bit store offsets");
+    const bool perm = order != nullptr;          // ent_p / ent_gx are then the per-entry words of eap_so3_perm_entries_f32
+    if (perm && ((na & 3) != 0 || fpitch != na)) return eap::bad_arg("so3_group_lists2: the permuted variant takes unpadded rows of a multiple of 4 anchors");
     const bool wide = !LISTS && layout == 2 && g_store16 != 0 && (ks & 3) == 0;
-    auto kern = wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>;
-    int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM), what);
+    auto kern = perm ? (wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3, true> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2, true> : so3_group_lists2_kernel<LISTS, 0, true>)
+                     : (wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>);
+    const size_t shmem = perm ? SHMEM_PERM : SHMEM;
+    int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), what);
     if (e) return e;
     const int AG = (na + GSZ - 1) / GSZ;
     const int RPB = LISTS ? 1 : ((nn % NBK) == 0 ? 8 : 1);
@@ -444,9 +497,10 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
 #else
     const int dbg = 0;
 #endif
-    hipLaunchKernelGGL(kern, grid, dim3(TM), SHMEM, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, (LISTS ? g_xcd_map_inv : g_xcd_map_fwd) == 2, dbg, 1.0f / sigma, F,
-                       rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out);
-    eap::set_kernel(LISTS ? "so3_group_lists2_kernel<true, 0>" : wide ? "so3_group_lists2_kernel<false, 3>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>");
+    hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, (LISTS ? g_xcd_map_inv : g_xcd_map_fwd) == 2, dbg, 1.0f / sigma, F,
+                       rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out, order);
+    eap::set_kernel(perm ? (LISTS ? "so3_group_lists2_kernel<true, 0, true>" : wide ? "so3_group_lists2_kernel<false, 3, true>" : layout == 2 ? "so3_group_lists2_kernel<false, 2, true>" : "so3_group_lists2_kernel<false, 0, true>")
+                         : (LISTS ? "so3_group_lists2_kernel<true, 0>" : wide ? "so3_group_lists2_kernel<false, 3>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>"));
     return eap::check_launch(what);
 }
 
@@ -472,6 +526,14 @@ extern "C" int eap_so3_group_lists_tiles(int tiles) {
 extern "C" int eap_so3_group_lists_store16(int on) {
     const int was = g_store16;
     if (on == 0 || on == 1) g_store16 = on;
+    return was;
+}
+
+// Clouds with anchor permutations on the two-tile kernel (PERM; default 1) or on csrc/so3_inter_inv.hip's whole-row kernel (0),
+// for A/B runs.  Returns the previous setting; other values only query.
+extern "C" int eap_so3_group_perm_lists2(int on) {
+    const int was = g_perm_lists2;
+    if (on == 0 || on == 1) g_perm_lists2 = on;
     return was;
 }
 
@@ -514,3 +576,77 @@ int group_lists2_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, 
 }
 
 }  // namespace eap
+
+// ---- clouds with anchor permutations on the two-tile kernel (PERM) ---------------------------------------------------
+namespace {
+// one thread per entry: everything the PERM kernel needs that depends on the entry's rotation r alone (see the kernel's header)
+__global__ __launch_bounds__(256) void perm_entries_kernel(long long total, int na, int PF, int ident, int rotate,
+                                                           const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
+                                                           const uint8_t *__restrict__ code, const float *__restrict__ anchors,
+                                                           uint4 *__restrict__ ent_off, float4 *__restrict__ ent_gx2) {
+    __shared__ uint32_t s_code[64 * 4];
+    __shared__ float s_A[64 * 9];
+    for (int i = threadIdx.x; i < na * 4; i += 256) s_code[i] = reinterpret_cast<const uint32_t *>(code)[i];
+    if (rotate) for (int i = threadIdx.x; i < na * 9; i += 256) s_A[i] = anchors[i];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float4 g = ent_gx[i];
+    const int p = ent_p[i];
+    int r = __float_as_int(g.w);
+    r = (unsigned)r < (unsigned)na ? r : ident;
+    if (rotate && r != ident && g.x < 1e17f) {
+        const float *A = s_A + 9 * r;
+        g = make_float4(A[0] * g.x + A[1] * g.y + A[2] * g.z, A[3] * g.x + A[4] * g.y + A[5] * g.z, A[6] * g.x + A[7] * g.y + A[8] * g.z, 0.f);
+    }
+    const bool shadow = (unsigned)p >= (unsigned)PF;                 // forward: a neighbour slot without a point
+    const unsigned row = shadow ? 0u : (unsigned)p * (unsigned)na * 4u;
+    if (shadow) g = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+    unsigned xb = 0;
+#pragma unroll
+    for (int ag = 0; ag < 4; ++ag) {
+        const uint32_t w = s_code[4 * r + ag];                       // code bytes of blocks 4 ag .. 4 ag + 3: sigma | x << 4
+        ent_off[4 * i + ag] = make_uint4(row + 16u * (w & 15u), row + 16u * ((w >> 8) & 15u), row + 16u * ((w >> 16) & 15u), row + 16u * ((w >> 24) & 15u));
+        xb |= (((w >> 4) & 3u) | ((w >> 12) & 3u) << 2 | ((w >> 20) & 3u) << 4 | ((w >> 28) & 3u) << 6) << (8 * ag);
+    }
+    g.w = __uint_as_float(xb);
+    ent_gx2[i] = g;
+}
+}  // namespace
+
+// 1 if clouds with anchor permutations and this shape go to the two-tile kernel (the caller then prepares the per-entry words
+// and the coset-major operand), 0: csrc/so3_inter_inv.hip's whole-row kernel takes them
+extern "C" int eap_so3_group_perm_lists2_takes(int channels, int na, int ks, int n_support) {
+    return g_perm_lists2 && (na & 3) == 0 && na <= 60 && (long long)n_support * na * 4 < (1ll << 31) && eap::group_lists_supported(na, ks) &&
+           eap::group_lists2_preferred(channels, na, ks, 0);
+}
+
+// per-entry words of the PERM kernel.  ent_p int32 [b*per_cloud] (inverse lists: query point of the entry; forward: idx),
+// ent_gx [b*per_cloud,4] (offset vector, w = bits of the relative-rotation anchor r), code uint8 [na,16] = coset code table
+// of the permutation table in force (row-wise inverse of the multiplication table in the backward), anchors [na,3,3] or NULL:
+// offset vectors rotated by A_r (backward).  -> ent_pc uint32 [b*per_cloud,4,4], ent_gx2 [b*per_cloud,4].
+extern "C" int eap_so3_perm_entries_f32(int b, int per_cloud, int na, int n_support, const int32_t *ent_p, const float *ent_gx,
+                                        const uint8_t *code, const float *anchors, int identity_anchor, int32_t *ent_pc, float *ent_gx2,
+                                        eap_stream_t stream) {
+    if (b <= 0 || per_cloud <= 0) return 0;
+    if ((na & 3) != 0 || na > 60 || (long long)n_support * na * 4 >= (1ll << 31) || (reinterpret_cast<uintptr_t>(code) & 3) != 0)
+        return eap::bad_arg("so3_perm_entries: na a multiple of 4 up to 60, point rows within 2^31 bytes, code table 4-byte aligned");
+    const long long total = (long long)b * per_cloud;
+    hipLaunchKernelGGL(perm_entries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eap::S(stream), total, na, n_support, identity_anchor,
+                       anchors != nullptr, ent_p, reinterpret_cast<const float4 *>(ent_gx), code, anchors, reinterpret_cast<uint4 *>(ent_pc),
+                       reinterpret_cast<float4 *>(ent_gx2));
+    return eap::check_launch("so3_perm_entries");
+}
+
+// Z of the re-associated backward (csrc/so3_inter_inv.hip) for clouds WITH anchor permutations, on the two-tile kernel.
+// gy [b,o,p,na] with its anchor axis COSET-MAJOR (eap_anchor_reorder_f32 with `order`), inverse lists as for
+// eap_so3_inter_group_inv_f32 with ent_pc / ent_gx2 from eap_so3_perm_entries_f32 (code table of the row-wise inverse of the
+// multiplication table, offset vectors rotated); z [b,o,ks,rcap,na] comes back with its anchor axis COSET-MAJOR too.
+extern "C" int eap_so3_inter_group_inv_perm2_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
+                                                 const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_pc,
+                                                 const float *ent_gx2, const float *rk, const uint8_t *order, float *z, eap_stream_t stream) {
+    if (b <= 0 || o <= 0 || rcap <= 0) return 0;
+    if (!order || !eap_so3_group_perm_lists2_takes(o, na, ks, p)) return eap::bad_arg("so3_inter_group_inv_perm2: shape not taken (ask eap_so3_group_perm_lists2_takes)");
+    return launch2<true>(0, b, o, p, na, na, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_pc, ent_gx2, rk, nullptr, z, eap::S(stream),
+                         "so3_inter_group_inv (permuted clouds, two channel tiles)", order);
+}

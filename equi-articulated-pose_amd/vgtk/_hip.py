@@ -273,6 +273,41 @@ def so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, sigma, n
     return z
 
 
+def anchor_reorder(t, order):
+    """t [..., na] -> the same with its last axis re-ordered: out[..., i] = t[..., order[i]] (order uint8 [>= na])."""
+    t = t.contiguous()
+    na = t.shape[-1]
+    out = torch.empty_like(t)
+    call('eap_anchor_reorder_f32', t, _I64(t.numel() // na), na, _ptr(t), _ptr(order), _ptr(out))
+    return out
+
+
+def so3_group_perm_lists2_takes(channels, na, ks, n_support):
+    return bool(lib.eap_so3_group_perm_lists2_takes(int(channels), int(na), int(ks), int(n_support)))
+
+
+def so3_perm_entries(ent_p, ent_gx, code, anchors, identity_anchor, na, n_support):
+    """per-entry words of the permuted two-tile kernel (include/eap_hip.h): -> ent_pc int32 [b,per,4,4], ent_gx2 [b,per,4]."""
+    b, per = ent_p.shape[0], ent_p[0].numel()
+    ent_pc = torch.empty(b, per, 4, 4, dtype=torch.int32, device=ent_p.device)
+    ent_gx2 = torch.empty(b, per, 4, dtype=torch.float32, device=ent_p.device)
+    anchors = anchors.contiguous() if anchors is not None else None
+    call('eap_so3_perm_entries_f32', ent_p, b, per, int(na), int(n_support), _ptr(ent_p), _ptr(ent_gx), _ptr(code),
+         _ptr(anchors), int(identity_anchor), _ptr(ent_pc), _ptr(ent_gx2))
+    return ent_pc, ent_gx2
+
+
+def so3_inter_group_inv_perm2(gy_c, rows, off, cnt, ent_pc, ent_gx2, rk, order, sigma, nn):
+    """gy_c [b,o,p,na] (anchor axis coset-major) -> z [b,o,ks,rcap,na] (coset-major), see include/eap_hip.h."""
+    b, o, p, na = gy_c.shape
+    rcap, ks = rows.shape[1], rk.shape[1]
+    z = torch.empty(b, o, ks, rcap, na, dtype=torch.float32, device=gy_c.device)
+    call('eap_so3_inter_group_inv_perm2_f32', z, b, o, p, nn, na, ks, rcap, _F32(sigma), _ptr(gy_c), _ptr(rows), _ptr(off), _ptr(cnt),
+         _ptr(ent_pc), _ptr(ent_gx2), _ptr(rk), _ptr(order), _ptr(z),
+         tag={'flops': 2.0 * b * o * ks * p * nn * na, 'shape': ('group_inv_perm2', b, o, p, nn, na, ks, rcap)})
+    return z
+
+
 def inv_lists_rows(idx, n):
     """idx int32 [b,p,nn] -> rows, off, cnt [b,n] and n_rows [b] (csrc/inv_lists.hip); no host sync."""
     b, p, nn = idx.shape

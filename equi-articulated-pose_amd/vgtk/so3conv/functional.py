@@ -217,8 +217,9 @@ def _coset_tables(table, ident):
 
     (left multiplication maps left cosets onto left cosets; inside a block it multiplies the H-part: an index XOR).  A
     kernel that keeps the anchor axis of its LDS operand in `order` reads the four permuted anchors of a block as ONE
-    16-byte word + a shuffle (csrc/so3_inter_inv.hip, COSET).  -> (order uint8 [64] padded with the last anchor, code uint8
-    [na,16]) on the table's device, or None when the group has no such subgroup / the structure check fails."""
+    16-byte word + a shuffle (csrc/so3_inter_inv.hip, COSET; csrc/so3_inter_lists2.hip, PERM).  -> (order uint8 [64] padded
+    with the last anchor, code uint8 [na,16], pos uint8 [64] = position of every anchor in `order`) on the table's device, or
+    None when the group has no such subgroup / the structure check fails."""
     key = (id(table), table._version, int(ident))
     hit = _COSETS.get(key)
     if hit is not None and hit[0]() is table:
@@ -259,7 +260,10 @@ def _coset_tables(table, ident):
                     ok = ok and all(T[r, order[4 * b + j]] == order[4 * sigma + (j ^ x)] for j in range(4))
             if ok:
                 padded = np.asarray(order + [order[-1]] * (64 - na), np.uint8)
-                out = (torch.from_numpy(padded).to(table.device), torch.from_numpy(code).to(table.device).contiguous())
+                where = np.zeros(64, np.uint8)
+                where[:na] = pos
+                out = (torch.from_numpy(padded).to(table.device), torch.from_numpy(code).to(table.device).contiguous(),
+                       torch.from_numpy(where).to(table.device))
     if len(_COSETS) > 256:
         _COSETS.clear()
     _COSETS[key] = (weakref.ref(table), out)
@@ -593,16 +597,30 @@ class _InterConv(torch.autograd.Function):
             ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
             multinv = _group_tables_inverse(mult) if (mult is not None and any_nonident) else None
             coset = _coset_tables(multinv, ctx.ident) if (multinv is not None and COSET_OPERAND) else None
-            z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
-                                         ctx.ident, ctx.anchors, coset)              # [b,o,ks,rcap,na]
+            z_order = None
+            if coset is not None and _hip.so3_group_perm_lists2_takes(o, na, ks, p):
+                # permuted clouds on the two-tile kernel (csrc/so3_inter_lists2.hip, PERM): gy and Z with a coset-major anchor
+                # axis, the per-entry words prepared once; the small tensors around the two GEMMs change their anchor order
+                z_order, z_pos = coset[0], coset[2]
+                ent_pc, ent_gx2 = _hip.so3_perm_entries(ent_p, ent_gx, coset[1], ctx.anchors, ctx.ident, na, p)
+                z = _hip.so3_inter_group_inv_perm2(_hip.anchor_reorder(gy, z_order), rows, off, cnt, ent_pc, ent_gx2, rk, z_order,
+                                                   ctx.sigma, idx.shape[2])
+            else:
+                z = _hip.so3_inter_group_inv(gy, rows, off, cnt, ent_p, ent_gx, rk, multinv, ctx.sigma, idx.shape[2],
+                                             ctx.ident, ctx.anchors, coset)              # [b,o,ks,rcap,na]
             ra = rcap * na
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
                 _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
+                if z_order is not None:
+                    gFc = _hip.anchor_reorder(gFc.view(b, c, rcap, na), z_pos)
                 gF = _hip.rows_scatter(gFc.view(b, c, rcap, na), rows, n)           # unreferenced rows: zero gradient
             if ctx.needs_input_grad[1]:
-                fc = _hip.rows_gather(feats, rows, rcap).view(b, c, ra)              # [b,c,rcap*na]; unused slots: zeros
+                fc = _hip.rows_gather(feats, rows, rcap)                             # [b,c,rcap,na]; unused slots: zeros
+                if z_order is not None:
+                    fc = _hip.anchor_reorder(fc, z_order)
+                fc = fc.view(b, c, ra)
                 if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, o * ks):
                     # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
                     # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe

@@ -216,6 +216,27 @@ int eap_so3_group_lists_store16(int on);
  * forward mode (global -> LDS DMA rows), 0 = the register-staged kernel of csrc/so3_inter_mfma.hip (round 1); returns the
  * previous setting, any other argument only queries.  Same results to rounding; for A/B runs and tests. */
 int eap_so3_group_perm_fwd(int on);
+/* Clouds WITH anchor permutations on the two-tile kernel (csrc/so3_inter_lists2.hip, PERM; round 4): the operand's anchor
+ * axis is COSET-MAJOR (eap_anchor_reorder_f32 with the `order` of vgtk.so3conv.functional._coset_tables), the block move of an
+ * entry's permutation rides on the DMA source addresses, the in-block XOR is 8 selects per operand read, and everything that
+ * depends on the entry's rotation alone is prepared once per entry:
+ *   eap_so3_group_perm_lists2(on)      1 (default) / 0: switch for A/B runs and tests; returns the previous setting
+ *   eap_so3_group_perm_lists2_takes    1 if this shape goes there (else the whole-row kernel, eap_so3_inter_group_inv_coset_f32)
+ *   eap_so3_perm_entries_f32           ent_p int32 [b*per_cloud], ent_gx [b*per_cloud,4] (w = bits of the rotation's anchor r),
+ *                                      code uint8 [na,16] (coset code table of the permutation table in force), anchors [na,3,3]
+ *                                      or NULL (backward: offset vectors rotated by A_r)
+ *                                      -> ent_pc uint32 [b*per_cloud,4,4] (byte offset of each 16-byte piece's source in a channel
+ *                                         row of the cloud, per anchor group and piece), ent_gx2 [b*per_cloud,4] (w = in-block
+ *                                         XOR bits of the 15 blocks; shadow neighbours get a dead offset vector)
+ *   eap_so3_inter_group_inv_perm2_f32  Z of the re-associated backward (replaces autograd of so3conv/functional.py:L1199-1261
+ *                                      for permuted clouds): gy [b,o,p,na] coset-major -> z [b,o,ks,rcap,na] coset-major */
+int eap_so3_group_perm_lists2(int on);
+int eap_so3_group_perm_lists2_takes(int channels, int na, int ks, int n_support);
+int eap_so3_perm_entries_f32(int b, int per_cloud, int na, int n_support, const int32_t *ent_p, const float *ent_gx, const uint8_t *code,
+                             const float *anchors, int identity_anchor, int32_t *ent_pc, float *ent_gx2, eap_stream_t stream);
+int eap_so3_inter_group_inv_perm2_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
+                                      const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_pc,
+                                      const float *ent_gx2, const float *rk, const uint8_t *order, float *z, eap_stream_t stream);
 /* Block -> XCD map of the two-tile kernel: mode 1 = an XCD (one L2) owns whole (channel slice, cloud) pairs, 2 = whole
  * (channel slice, cloud, anchor group) triples; which = 0 forward, 1 backward; mode 0 = query.  Same results either way. */
 int eap_so3_group_lists_xcd_map(int which, int mode);

@@ -23,10 +23,14 @@ part_pose = np.tile(np.eye(4, dtype=np.float32), (B, P, 1, 1))
 for bi in range(B):                                   # one rotation per rigid part (the articulated-object case)
     part_pose[bi, :, :3, :3] = R[bi, :2][lab[bi]]
 import vgtk.so3conv.functional as L
+from vgtk import _hip
 for name, ps in (('identity poses', torch.from_numpy(pose).to(dev)), ('one rotation per rigid part', torch.from_numpy(part_pose).to(dev)),
                  ('random per-point poses', torch.from_numpy(rand_pose).to(dev))):
-    for coset in ((True, False) if name != 'identity poses' else (True,)):
-        L.COSET_OPERAND = coset
+    for coset in ((2, True, False) if name != 'identity poses' else (True,)):
+        # 2 = coset-major operand on the two-tile kernel (csrc/so3_inter_lists2.hip PERM), True = on the whole-row kernel
+        # (csrc/so3_inter_inv.hip COSET), False = byte-table lookups
+        L.COSET_OPERAND = bool(coset)
+        _hip.lib.eap_so3_group_perm_lists2(1 if coset == 2 else 0)
         f = torch.randn(B, c, P, 60, device=dev, requires_grad=True)
         ts = []
         for it in range(4):
@@ -38,5 +42,6 @@ for name, ps in (('identity poses', torch.from_numpy(pose).to(dev)), ('one rotat
             e2.record(); torch.cuda.synchronize()
             ts.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
         fw, bw = sorted(t[0] for t in ts[1:])[1], sorted(t[1] for t in ts[1:])[1]
-        print(f'{name}{"" if name == "identity poses" else (", coset-major operand" if coset else ", byte-table lookups")}: forward {fw:.1f} ms, backward {bw:.1f} ms', flush=True)
+        print(f'{name}{"" if name == "identity poses" else (", two-tile kernel with block moves by DMA" if coset == 2 else ", coset-major operand" if coset else ", byte-table lookups")}: forward {fw:.1f} ms, backward {bw:.1f} ms', flush=True)
 L.COSET_OPERAND = True
+_hip.lib.eap_so3_group_perm_lists2(1)
