@@ -615,9 +615,10 @@ static int group_inv(int b, int o, int p, int nn, int na, int ks, int rcap, floa
 namespace {
 // dst[row, i] = src[row, order[i]]: the anchor axis of a [rows, na] tensor re-ordered (thread = one 16-byte word of dst)
 __global__ __launch_bounds__(256) void anchor_reorder_kernel(long long words, int npiece, int na, const float *__restrict__ src,
-                                                             const uint8_t *__restrict__ order, float4 *__restrict__ dst) {
+                                                             const uint8_t *__restrict__ order, float4 *__restrict__ dst,
+                                                             long long words_per_cloud = 0, const int32_t *__restrict__ nonident = nullptr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= words) return;
+    if (i >= words || (nonident != nullptr && nonident[i / words_per_cloud] == 0)) return;
     const long long row = i / npiece;
     const int pc = (int)(i - row * npiece);
     const float *r = src + row * na;
@@ -634,8 +635,20 @@ extern "C" int eap_anchor_reorder_f32(int64_t rows, int na, const float *src, co
         return eap::bad_arg("anchor_reorder: na must be a multiple of 4, order 4-byte and dst 16-byte aligned");
     const long long words = rows * (na >> 2);
     hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
-                       reinterpret_cast<float4 *>(dst));
+                       reinterpret_cast<float4 *>(dst), 0ll, (const int32_t *)nullptr);
     return eap::check_launch("anchor_reorder");
+}
+
+// the same for [b, rows_per_cloud, na] with a per-cloud flag: clouds whose nonident[b] is 0 are skipped (dst left unwritten)
+extern "C" int eap_anchor_reorder_clouds_f32(int b, int64_t rows_per_cloud, int na, const float *src, const uint8_t *order,
+                                             const int32_t *nonident, float *dst, eap_stream_t stream) {
+    if (b <= 0 || rows_per_cloud <= 0 || na <= 0) return 0;
+    if ((na & 3) != 0 || (reinterpret_cast<uintptr_t>(order) & 3) || (reinterpret_cast<uintptr_t>(dst) & 15))
+        return eap::bad_arg("anchor_reorder_clouds: na must be a multiple of 4, order 4-byte and dst 16-byte aligned");
+    const long long per = rows_per_cloud * (na >> 2), words = per * b;
+    hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
+                       reinterpret_cast<float4 *>(dst), per, nonident);
+    return eap::check_launch("anchor_reorder_clouds");
 }
 
 extern "C" int eap_so3_inter_group_inv_f32(int b, int o, int p, int nn, int na, int ks, int rcap,

@@ -580,7 +580,7 @@ int group_lists2_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, 
 // ---- clouds with anchor permutations on the two-tile kernel (PERM) ---------------------------------------------------
 namespace {
 // one thread per entry: everything the PERM kernel needs that depends on the entry's rotation r alone (see the kernel's header)
-__global__ __launch_bounds__(256) void perm_entries_kernel(long long total, int na, int PF, int ident, int rotate,
+__global__ __launch_bounds__(256) void perm_entries_kernel(long long total, int per_cloud, const int32_t *__restrict__ nonident, int na, int PF, int ident, int rotate,
                                                            const int32_t *__restrict__ ent_p, const float4 *__restrict__ ent_gx,
                                                            const uint8_t *__restrict__ code, const float *__restrict__ anchors,
                                                            uint4 *__restrict__ ent_off, float4 *__restrict__ ent_gx2) {
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void perm_entries_kernel(long long total, int 
     if (rotate) for (int i = threadIdx.x; i < na * 9; i += 256) s_A[i] = anchors[i];
     __syncthreads();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    if (i >= total || (nonident != nullptr && nonident[i / per_cloud] == 0)) return;      // (clouds without permutations: not needed)
     float4 g = ent_gx[i];
     const int p = ent_p[i];
     int r = __float_as_int(g.w);
@@ -624,15 +624,16 @@ extern "C" int eap_so3_group_perm_lists2_takes(int channels, int na, int ks, int
 // per-entry words of the PERM kernel.  ent_p int32 [b*per_cloud] (inverse lists: query point of the entry; forward: idx),
 // ent_gx [b*per_cloud,4] (offset vector, w = bits of the relative-rotation anchor r), code uint8 [na,16] = coset code table
 // of the permutation table in force (row-wise inverse of the multiplication table in the backward), anchors [na,3,3] or NULL:
-// offset vectors rotated by A_r (backward).  -> ent_pc uint32 [b*per_cloud,4,4], ent_gx2 [b*per_cloud,4].
+// offset vectors rotated by A_r (backward); nonident int32 [b] or NULL: clouds whose flag is 0 are skipped (their words stay
+// unwritten).  -> ent_pc uint32 [b*per_cloud,4,4], ent_gx2 [b*per_cloud,4].
 extern "C" int eap_so3_perm_entries_f32(int b, int per_cloud, int na, int n_support, const int32_t *ent_p, const float *ent_gx,
-                                        const uint8_t *code, const float *anchors, int identity_anchor, int32_t *ent_pc, float *ent_gx2,
-                                        eap_stream_t stream) {
+                                        const uint8_t *code, const float *anchors, int identity_anchor, const int32_t *nonident,
+                                        int32_t *ent_pc, float *ent_gx2, eap_stream_t stream) {
     if (b <= 0 || per_cloud <= 0) return 0;
     if ((na & 3) != 0 || na > 60 || (long long)n_support * na * 4 >= (1ll << 31) || (reinterpret_cast<uintptr_t>(code) & 3) != 0)
         return eap::bad_arg("so3_perm_entries: na a multiple of 4 up to 60, point rows within 2^31 bytes, code table 4-byte aligned");
     const long long total = (long long)b * per_cloud;
-    hipLaunchKernelGGL(perm_entries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eap::S(stream), total, na, n_support, identity_anchor,
+    hipLaunchKernelGGL(perm_entries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eap::S(stream), total, per_cloud, nonident, na, n_support, identity_anchor,
                        anchors != nullptr, ent_p, reinterpret_cast<const float4 *>(ent_gx), code, anchors, reinterpret_cast<uint4 *>(ent_pc),
                        reinterpret_cast<float4 *>(ent_gx2));
     return eap::check_launch("so3_perm_entries");
@@ -649,4 +650,22 @@ extern "C" int eap_so3_inter_group_inv_perm2_f32(int b, int o, int p, int nn, in
     if (!order || !eap_so3_group_perm_lists2_takes(o, na, ks, p)) return eap::bad_arg("so3_inter_group_inv_perm2: shape not taken (ask eap_so3_group_perm_lists2_takes)");
     return launch2<true>(0, b, o, p, na, na, ks, rcap, nn, p * nn, sigma, gy, rows, off, cnt, ent_pc, ent_gx2, rk, nullptr, z, eap::S(stream),
                          "so3_inter_group_inv (permuted clouds, two channel tiles)", order);
+}
+
+// Forward grouping, transposed output X^T [b][p*na + a][c*ks + k] (eap_so3_inter_group_fwd_t_f32), with the clouds WITH
+// anchor permutations (nonident[b] != 0) on the two-tile kernel: feats_c = feats with a coset-major anchor axis
+// (eap_anchor_reorder_clouds_f32 with the `order` of the multiplication table's coset tables), ent_pc / ent_gx2 from
+// eap_so3_perm_entries_f32 over (idx, gx) with that table's code and anchors = NULL.  Clouds without permutations take the
+// plain kernel on feats / idx / gx as before.  The output is in memory order (one row per anchor).
+extern "C" int eap_so3_inter_group_fwd_perm2_t_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                                                   const float *feats_c, const int32_t *idx, const float *gx, const int32_t *ent_pc,
+                                                   const float *ent_gx2, const float *rk, const uint8_t *order, const int32_t *nonident,
+                                                   float *out, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || p <= 0) return 0;
+    if (!order || !nonident || nn <= 0 || !eap_so3_group_perm_lists2_takes(c, na, ks, n) || (long long)c * n * na >= (1ll << 31))
+        return eap::bad_arg("so3_inter_group_fwd_perm2_t: shape not taken (ask eap_so3_group_perm_lists2_takes; flags and order are required)");
+    int e = eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, nonident, 2, out, eap::S(stream));
+    if (e) return e;
+    return launch2<false>(2, b, c, n, na, na, ks, p, nn, 0, sigma, feats_c, nullptr, nullptr, nullptr, ent_pc, ent_gx2, rk, nonident, out, eap::S(stream),
+                          "so3_inter_group_fwd (permuted clouds, two channel tiles)", order);
 }

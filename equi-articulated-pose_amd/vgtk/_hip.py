@@ -205,13 +205,25 @@ def so3_inter_group_fwd_can_block(c, n, na, ks, has_mult, has_flag):
     return bool(lib.eap_so3_inter_group_fwd_can_block(c, n, na, ks, int(has_mult), int(has_flag)))
 
 
-def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=False):
+def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=False, coset=None):
     """-> X [b,c,ks,p,na]; with `blocked` the same numbers as [b,p,na/4,c,ks,4] (returned with the
-    nominal shape: only eap_gemm_f32_xb may read it)."""
+    nominal shape: only eap_gemm_f32_xb may read it).  coset = the coset tables of `mult`
+    (vgtk.so3conv.functional._coset_tables): permuted clouds of the transposed layout take the two-tile kernel."""
     b, c, n, na = feats.shape
     p, nn = idx.shape[1], idx.shape[2]
     ks = rk.shape[1]
     out = torch.empty(b, c, ks, p, na, dtype=torch.float32, device=feats.device)
+    if (coset is not None and int(blocked) == 2 and mult is not None and nonident is not None and nn > 0
+            and so3_group_perm_lists2_takes(c, na, ks, n)):
+        # clouds with anchor permutations on the two-tile kernel (csrc/so3_inter_lists2.hip, PERM): their features with a coset-major
+        # anchor axis, the per-entry words of (idx, gx) prepared once; clouds whose flag is 0 cost three empty launches
+        feats_c = torch.empty_like(feats)
+        call('eap_anchor_reorder_clouds_f32', feats, b, _I64(c * n), na, _ptr(feats), _ptr(coset[0]), _ptr(nonident), _ptr(feats_c))
+        ent_pc, ent_gx2 = so3_perm_entries(idx.view(b, p * nn), gx.view(b, p * nn, 4), coset[1], None, 0, na, n, nonident)
+        call('eap_so3_inter_group_fwd_perm2_t_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(feats_c), _ptr(idx), _ptr(gx),
+             _ptr(ent_pc), _ptr(ent_gx2), _ptr(rk), _ptr(coset[0]), _ptr(nonident), _ptr(out),
+             tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd_perm2', b, c, p, nn, na, ks)})
+        return out
     call({0: 'eap_so3_inter_group_fwd_f32', 1: 'eap_so3_inter_group_fwd_xb_f32', 2: 'eap_so3_inter_group_fwd_t_f32'}[int(blocked)], out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
          _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out),
          tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd', b, c, p, nn, na, ks)})
@@ -286,14 +298,14 @@ def so3_group_perm_lists2_takes(channels, na, ks, n_support):
     return bool(lib.eap_so3_group_perm_lists2_takes(int(channels), int(na), int(ks), int(n_support)))
 
 
-def so3_perm_entries(ent_p, ent_gx, code, anchors, identity_anchor, na, n_support):
+def so3_perm_entries(ent_p, ent_gx, code, anchors, identity_anchor, na, n_support, nonident=None):
     """per-entry words of the permuted two-tile kernel (include/eap_hip.h): -> ent_pc int32 [b,per,4,4], ent_gx2 [b,per,4]."""
     b, per = ent_p.shape[0], ent_p[0].numel()
     ent_pc = torch.empty(b, per, 4, 4, dtype=torch.int32, device=ent_p.device)
     ent_gx2 = torch.empty(b, per, 4, dtype=torch.float32, device=ent_p.device)
     anchors = anchors.contiguous() if anchors is not None else None
     call('eap_so3_perm_entries_f32', ent_p, b, per, int(na), int(n_support), _ptr(ent_p), _ptr(ent_gx), _ptr(code),
-         _ptr(anchors), int(identity_anchor), _ptr(ent_pc), _ptr(ent_gx2))
+         _ptr(anchors), int(identity_anchor), _ptr(nonident), _ptr(ent_pc), _ptr(ent_gx2))
     return ent_pc, ent_gx2
 
 

@@ -530,8 +530,9 @@ class _InterConv(torch.autograd.Function):
         lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)
         keep = needs_grad and (not lists_ok or _keep_x_hint(W_param))
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
+        coset = _coset_tables(mult, ident) if (mult is not None and nonident is not None and layout == 2 and COSET_OPERAND) else None
         if keep:
-            x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=layout)   # [b,c,k,p,a] (nominal shape)
+            x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=layout, coset=coset)   # [b,c,k,p,a] (nominal shape)
             _contract_into(W, x, y.view(b, o, p * na), layout)
         else:
             x = None
@@ -539,7 +540,7 @@ class _InterConv(torch.autograd.Function):
             for b0 in range(0, b, step):
                 b1 = min(b, b0 + step)
                 xs = _hip.so3_inter_group_fwd(feats[b0:b1], idx[b0:b1], gx[b0:b1], rk, mult, sigma,
-                                              None if nonident is None else nonident[b0:b1], blocked=layout)
+                                              None if nonident is None else nonident[b0:b1], blocked=layout, coset=coset)
                 _contract_into(W, xs, y[b0:b1].view(b1 - b0, o, p * na), layout, epilogue, b0)
                 del xs
         ctx.layout = layout
@@ -586,7 +587,8 @@ class _InterConv(torch.autograd.Function):
         if Wp is not None:
             _set_keep_x_hint(Wp, head is None)            # the next forward of this layer keeps X iff this backward needed it
         if head is None and not ctx.kept_x:               # wrong guess (or the first step): one more run of the grouping kernel
-            x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, ctx.sigma, nonident, blocked=ctx.layout)
+            x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, ctx.sigma, nonident, blocked=ctx.layout,
+                                         coset=_coset_tables(mult, ctx.ident) if (mult is not None and ctx.layout == 2 and COSET_OPERAND) else None)
         if head is not None:
             # slots past a cloud's last referenced row are empty (rows = -1): a multiple of 4 rows makes K = rcap * na of the
             # gradient GEMMs a multiple of 16.  (A multiple of 32 would put the dF GEMM on the split kernel -- measured: the 18 %

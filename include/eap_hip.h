@@ -223,6 +223,7 @@ int eap_so3_group_perm_fwd(int on);
  *   eap_so3_group_perm_lists2(on)      1 (default) / 0: switch for A/B runs and tests; returns the previous setting
  *   eap_so3_group_perm_lists2_takes    1 if this shape goes there (else the whole-row kernel, eap_so3_inter_group_inv_coset_f32)
  *   eap_so3_perm_entries_f32           ent_p int32 [b*per_cloud], ent_gx [b*per_cloud,4] (w = bits of the rotation's anchor r),
+ *                                      nonident int32 [b] or NULL (clouds with flag 0 are skipped),
  *                                      code uint8 [na,16] (coset code table of the permutation table in force), anchors [na,3,3]
  *                                      or NULL (backward: offset vectors rotated by A_r)
  *                                      -> ent_pc uint32 [b*per_cloud,4,4] (byte offset of each 16-byte piece's source in a channel
@@ -233,7 +234,16 @@ int eap_so3_group_perm_fwd(int on);
 int eap_so3_group_perm_lists2(int on);
 int eap_so3_group_perm_lists2_takes(int channels, int na, int ks, int n_support);
 int eap_so3_perm_entries_f32(int b, int per_cloud, int na, int n_support, const int32_t *ent_p, const float *ent_gx, const uint8_t *code,
-                             const float *anchors, int identity_anchor, int32_t *ent_pc, float *ent_gx2, eap_stream_t stream);
+                             const float *anchors, int identity_anchor, const int32_t *nonident, int32_t *ent_pc, float *ent_gx2,
+                             eap_stream_t stream);
+/* the forward with the same kernel: eap_so3_inter_group_fwd_t_f32's output (X^T, memory order) where the clouds WITH
+ * permutations (nonident[b] != 0) read feats_c = feats with a coset-major anchor axis (eap_anchor_reorder_clouds_f32) and the
+ * per-entry words of (idx, gx) (eap_so3_perm_entries_f32 with the multiplication table's code, anchors = NULL, the flags); the
+ * other clouds take the plain kernel.  Replaces so3conv/functional.py:L1199-1261 for those clouds. */
+int eap_so3_inter_group_fwd_perm2_t_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                                        const float *feats_c, const int32_t *idx, const float *gx, const int32_t *ent_pc,
+                                        const float *ent_gx2, const float *rk, const uint8_t *order, const int32_t *nonident, float *out,
+                                        eap_stream_t stream);
 int eap_so3_inter_group_inv_perm2_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
                                       const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_pc,
                                       const float *ent_gx2, const float *rk, const uint8_t *order, float *z, eap_stream_t stream);
