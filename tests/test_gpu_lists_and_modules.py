@@ -1114,3 +1114,99 @@ def test_art_mode_conv_matches_the_reference(dev, golden, tag, pm):
     assert rel_err(y.feats.detach().cpu().numpy(), g[f'{tag}_out']) < 1e-5
     assert rel_err(gf.cpu().numpy(), g[f'{tag}_gfeats']) < 1e-5
     assert rel_err(gW.cpu().numpy(), g[f'{tag}_gW']) < 2e-5
+
+
+def _random_rotations(rng, shape):
+    q = rng.standard_normal(shape + (4,))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(shape + (3, 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize('kind', ['parts', 'random', 'mixed'])
+def test_permuted_clouds_on_the_two_tile_kernel(dev, monkeypatch, kind):
+    """Clouds WITH anchor permutations on csrc/so3_inter_lists2.hip (PERM: coset-major anchor axis, block moves by the DMA source
+    addresses, per-entry words from eap_so3_perm_entries_f32) against the whole-row kernels of csrc/so3_inter_inv.hip, which the
+    golden layers from the reference pin (tests/test_gpu_parity.py): output, feature gradient and weight gradient of a 64 -> 128
+    layer; 'mixed' = one cloud without rotations beside two with (both kernels launched, each skipping the other's clouds).
+    Bars: 2e-6 of the tensor's scale (the same products, summed in another order across anchors groups)."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    torch.manual_seed(5)
+    monkeypatch.setattr(L, 'BACKWARD_MODE', 'inverse')          # the re-associated backward whatever the number of referenced rows
+    B, P, c, o = 3, 640, 64, 128
+    xyz, lab, pose = synth_clouds.laptop_batch(11, B, P)
+    rng = np.random.default_rng(4)
+    pose = pose.copy()
+    if kind == 'parts':
+        R = _random_rotations(rng, (B, 2))
+        for bi in range(B):
+            pose[bi, :, :3, :3] = R[bi][lab[bi]]
+    else:
+        pose[:, :, :3, :3] = _random_rotations(rng, (B, P))
+        if kind == 'mixed':
+            pose[1] = np.eye(4, dtype=np.float32)
+    xyz, pose = T(xyz).to(dev), T(pose).to(dev)
+    conv = sptk.InterSO3PoseConv(c, o, 1, 1, 0.3, 0.05, 64, kanchor=60, permute_modes=1).to(dev)
+    assert _hip.so3_group_perm_lists2_takes(c, 60, 24, P) and _hip.so3_group_perm_lists2_takes(o, 60, 24, P)
+    gy = torch.randn(B, o, P, 60, device=dev)
+    res = {}
+    for two_tile in (1, 0):
+        was = _hip.lib.eap_so3_group_perm_lists2(two_tile)
+        launched = []
+        _hip.KERNEL_TIMES = launched
+        try:
+            f = torch.randn(B, c, P, 60, device=dev, generator=torch.Generator(device=dev).manual_seed(9), requires_grad=True)
+            y = conv(zptk.SphericalPointCloudPose(xyz, f, None, pose))[3].feats
+            gf, gw = torch.autograd.grad(y, [f, conv.basic_conv.W], gy)
+        finally:
+            _hip.KERNEL_TIMES = None
+            _hip.lib.eap_so3_group_perm_lists2(was)
+        res[two_tile] = (y.detach(), gf, gw, [n for n, *_ in launched])
+    names = res[1][3]
+    assert 'eap_so3_inter_group_fwd_perm2_t_f32' in names and 'eap_so3_perm_entries_f32' in names, names
+    assert 'eap_so3_inter_group_inv_perm2_f32' in names, names                 # (the re-associated backward took the lists)
+    assert not any('perm2' in n for n in res[0][3])
+    for a, b_, what in zip(res[1][:3], res[0][:3], ('output', 'feature gradient', 'weight gradient')):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < 2e-6, what
+
+
+def test_perm_entries_words(dev):
+    """eap_so3_perm_entries_f32 against the tables it packs (include/eap_hip.h): byte offsets = point row + 16 * source block of
+    each piece, XOR bits, rotated / dead offset vectors, skipped clouds."""
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    A = torch.from_numpy(np.ascontiguousarray(L.get_anchors())).to(dev)
+    mult, ident = L._group_tables(A)
+    order, code, pos = L._coset_tables(L._group_tables_inverse(mult), ident)
+    rng = np.random.default_rng(3)
+    b, per, n = 3, 500, 777
+    ent_p = rng.integers(0, n + 40, (b, per)).astype(np.int32)             # some past the last row: shadow neighbours
+    g = rng.standard_normal((b, per, 4)).astype(np.float32)
+    r = rng.integers(0, 60, (b, per)).astype(np.int32)
+    g[..., 3] = r.view(np.float32)
+    flags = torch.tensor([1, 0, 1], dtype=torch.int32, device=dev)
+    for anchors in (A, None):
+        pc, g2 = _hip.so3_perm_entries(T(ent_p).to(dev), T(g).to(dev), code, anchors, ident, 60, n, flags)
+        pc, g2 = pc.cpu().numpy().astype(np.int64), g2.cpu().numpy()
+        cd = code.cpu().numpy().astype(np.int64)
+        An = A.cpu().numpy()
+        for bi in (0, 2):
+            shadow = ent_p[bi] >= n
+            row = np.where(shadow, 0, ent_p[bi].astype(np.int64) * 240)
+            sig = cd[r[bi]] & 15                                              # [per,16]
+            want = (row[:, None] + 16 * sig).reshape(per, 4, 4)
+            live = np.ones((4, 4), bool); live[3, 3] = False                  # block 15 does not exist
+            assert np.array_equal(pc[bi][:, live], want[:, live])
+            xb = g2[bi, :, 3].view(np.uint32).astype(np.int64)
+            for blk in range(15):
+                assert np.array_equal((xb >> (2 * blk)) & 3, cd[r[bi], blk] >> 4)
+            vec = g[bi, :, :3]
+            if anchors is not None:
+                vec = np.einsum('eij,ej->ei', An[r[bi]], vec)
+            assert np.allclose(g2[bi, ~shadow, :3], vec[~shadow], atol=1e-6)
+            assert (g2[bi, shadow, :3] > 1e17).all()
