@@ -666,6 +666,9 @@ extern "C" int eap_so3_inter_group_fwd_perm2_t_f32(int b, int c, int p, int n, i
         return eap::bad_arg("so3_inter_group_fwd_perm2_t: shape not taken (ask eap_so3_group_perm_lists2_takes; flags and order are required)");
     int e = eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, nonident, 2, out, eap::S(stream));
     if (e) return e;
-    return launch2<false>(2, b, c, n, na, na, ks, p, nn, 0, sigma, feats_c, nullptr, nullptr, nullptr, ent_pc, ent_gx2, rk, nonident, out, eap::S(stream),
-                          "so3_inter_group_fwd (permuted clouds, two channel tiles)", order);
+    e = launch2<false>(2, b, c, n, na, na, ks, p, nn, 0, sigma, feats_c, nullptr, nullptr, nullptr, ent_pc, ent_gx2, rk, nonident, out, eap::S(stream),
+                       "so3_inter_group_fwd (permuted clouds, two channel tiles)", order);
+    // (which of the two launches did the work is only known on the device: the per-cloud flags)
+    eap::set_kernel(g_store16 != 0 && (ks & 3) == 0 ? "so3_group_lists2_kernel<false, 3> | <false, 3, true>" : "so3_group_lists2_kernel<false, 2> | <false, 2, true>");
+    return e;
 }
