@@ -383,16 +383,28 @@ def summarize_kernels(records):
     return by_name, shapes
 
 
-def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, warmup=2, partial=False):
-    """One more configuration of the same step on this GPU, a few steps: -> dict(value, ms_per_step, ...)."""
+def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, warmup=2, partial=False, part_poses=False):
+    """One more configuration of the same step on this GPU, a few steps: -> dict(value, ms_per_step, ...).
+    part_poses: every rigid part of a cloud carries its own rotation (articulated input: the relative rotations between
+    neighbours across the joint select real anchor permutations, vgtk/so3conv/functional.py:L1199-1204)."""
     import synth_clouds
     from vgtk import _hip
     torch.manual_seed(2913)
     model = Backbone(points, plan_points).to(dev)
     params = [p for p in model.parameters()]
     opt = torch.optim.Adam(params, lr=1e-4)
-    xyz_np, _, pose_np = synth_clouds.laptop_batch(0, batch, points, partial=partial)
-    xyz, pose = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(pose_np).to(dev)
+    xyz_np, lab_np, pose_np = synth_clouds.laptop_batch(0, batch, points, partial=partial)
+    if part_poses:
+        rng = np.random.default_rng(2913)
+        q = rng.standard_normal((batch, 2, 4))
+        q /= np.linalg.norm(q, axis=-1, keepdims=True)
+        w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        rot = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(batch, 2, 3, 3)
+        pose_np = pose_np.copy()
+        for bi in range(batch):
+            pose_np[bi, :, :3, :3] = rot[bi][lab_np[bi]]
+    xyz, pose = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(pose_np.astype(np.float32)).to(dev)
 
     def step():
         if fwd_only:
@@ -421,7 +433,7 @@ def quick_run(dev, batch, points, fwd_only=False, plan_points=None, steps=3, war
     kern, _ = summarize_kernels(records)
     top = sorted(kern.items(), key=lambda kv: -kv[1]['ms'])[:4]
     out = {'clouds_per_gpu': batch, 'points': points, 'clouds': 'partial (depth-buffer visible)' if partial else 'complete',
-           'backward_regimes': regimes, 'pass': 'fwd' if fwd_only else 'fwd+bwd+Adam',
+           'poses': 'one rotation per rigid part' if part_poses else 'identity', 'backward_regimes': regimes, 'pass': 'fwd' if fwd_only else 'fwd+bwd+Adam',
            'radii_of_input_size': plan_points or points, 'value': batch * steps / dt, 'unit': 'point-clouds/sec',
            'ms_per_step': dt / steps * 1e3, 'steps': steps,
            'top_kernels_ms_per_step': {n: round(k['ms'] / steps, 2) for n, k in top}}
@@ -441,6 +453,7 @@ def other_configs(dev):
         dict(name='config 5 per-GPU shape: 8 x 8192 partial (depth-buffer visible) clouds', **quick_run(dev, 8, 8192, partial=True)),
         dict(name='8 x 8192 complete clouds', **quick_run(dev, 8, 8192)),
         dict(name='8 x 4096 with the 512-point radii (textbook-backward regime)', **quick_run(dev, 8, 4096, plan_points=512)),
+        dict(name='8 x 4096, articulated input: one rotation per rigid part (anchor permutations on)', **quick_run(dev, 8, 4096, part_poses=True)),
     ]
 
 

@@ -242,12 +242,24 @@ def _coset_tables(table, ident):
             if H:
                 break
         if H:
+            # blocks that belong together stay together: the normaliser K of H (the tetrahedral subgroup of the icosahedral
+            # group, K / H cyclic of order 3) -- a left multiplication maps the three H-cosets of a K-coset onto the three
+            # H-cosets of ONE other K-coset, i.e. three of a 16-anchor group's four source blocks are neighbours in memory
+            inv = {a: next(b for b in range(na) if times(a, b) == ident) for a in range(na)}
+            K = [g for g in range(na) if sorted(times(times(g, h), inv[g]) for h in H) == sorted(H)]
+            reps, covered = [], set()
+            for k in K:
+                if k not in covered:
+                    reps.append(k)
+                    covered.update(times(k, h) for h in H)
             order, seen = [], set()
             for a in range(na):
                 if a not in seen:
-                    blk = [times(a, h) for h in H]
-                    order += blk
-                    seen.update(blk)
+                    for k in reps:
+                        blk = [times(times(a, k), h) for h in H]
+                        if blk[0] not in seen:
+                            order += blk
+                            seen.update(blk)
             pos = np.empty(na, np.int64)
             pos[order] = np.arange(na)
             code = np.zeros((na, 16), np.uint8)
