@@ -67,7 +67,8 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // Timing ablations (WRONG RESULTS), compiled only with `make ABLATION=1` and selected by EAP_LISTS2_DEBUG (bit mask):
 // 1 no feature DMA after the prologue, 2 constant weights (no weight evaluation), 4 no row-end stores, 8 no chunk barrier
 // (only together with 1), 16 no per-k-step LDS operand reads; PERM: 32 no block move (DMA pieces from the thread's own
-// block), 64 no in-block XOR (selects).  tools/lists2_ablation.py, tools/lists2_perm_ablation.py
+// block), 64 no in-block XOR (selects); 512 the feature DMA always fetches rows 0..7 (all requests hit in cache: the issue cost
+// without the misses).  tools/lists2_ablation.py, tools/lists2_perm_ablation.py
 #ifdef EAP_ABLATION
 #define ABL(bit) ((dbg & (bit)) != 0)
 #else
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
                 continue;
             }
             int pe = s_p[slot * NBK + u];
+            if (ABL(512)) pe = u;                                      // every chunk fetches the same eight rows: cache hits only
             if (!LISTS) pe = (unsigned)pe < (unsigned)PF ? pe : 0;     // shadow row: any valid row, weight 0
             src_off[u] = dma_off + __umul24((unsigned)pe, row_bytes);
         }

@@ -23,7 +23,7 @@ rk = L.rotated_kernels(conv.anchors, conv.kernels)
 rows, off, cnt, ent_p, ent_gx, rcap, _ = L._inverse_lists(idx, gx, P, 29, nonident)
 gy = torch.randn(B, o, P, NA, device=dev)
 feats = torch.randn(B, c, P, NA, device=dev)
-CASES = [('full kernel', 0), ('no feature DMA', 1), ('constant weights', 2), ('no row-end stores', 4), ('no LDS operand reads', 16),
+CASES = [('full kernel', 0), ('no feature DMA', 1), ('feature DMA of the same 8 rows (hits only)', 512), ('constant weights', 2), ('no row-end stores', 4), ('no LDS operand reads', 16),
          ('no DMA, no barrier', 9), ('no DMA, constant weights', 3), ('no DMA, no weights, no LDS reads', 19), ('MFMAs + barrier only', 23), ('MFMAs only', 31)]
 
 
@@ -50,7 +50,7 @@ for name, fn, fl in (('backward Z, O = 512', inv, 2.0 * B * o * KS * P * NN * NA
     os.environ['EAP_LISTS2_DEBUG'] = '0'
     for k, bits in CASES:
         v = sorted(res[k][1:])
-        print(f'{name}: {k:34s} (bits {bits:2d}): median {v[2]:7.2f} ms = {fl / v[2] / 1e9 / 157.3:.3f} of peak (algorithmic)', flush=True)
+        print(f'{name}: {k:44s} (bits {bits:2d}): median {v[2]:7.2f} ms = {fl / v[2] / 1e9 / 157.3:.3f} of peak (algorithmic)', flush=True)
     which = 1 if fn is inv else 0
     for mode in (1, 2):
         _hip.lib.eap_so3_group_lists_xcd_map(which, mode)
