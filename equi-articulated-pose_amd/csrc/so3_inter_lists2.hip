@@ -68,7 +68,8 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // 1 no feature DMA after the prologue, 2 constant weights (no weight evaluation), 4 no row-end stores, 8 no chunk barrier
 // (only together with 1), 16 no per-k-step LDS operand reads; PERM: 32 no block move (DMA pieces from the thread's own
 // block), 64 no in-block XOR (selects); 512 the feature DMA always fetches rows 0..7 (all requests hit in cache: the issue cost
-// without the misses).  tools/lists2_ablation.py, tools/lists2_perm_ablation.py
+// without the misses), 1024 the forward's row-end stores with the lanes in address order (the same bytes in 1 KB runs, wrong
+// places: what a transposed row end would issue).  tools/lists2_ablation.py, tools/lists2_perm_ablation.py
 #ifdef EAP_ABLATION
 #define ABL(bit) ((dbg & (bit)) != 0)
 #else
@@ -337,7 +338,11 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     auto store_row = [&](int row) {
         if (LAYOUT == 3) {
             // D[i = kernel point][j = channel]: lane column = channel lk of the tile, accumulator quad q holds kernel points
-            // 8 q + 4 lh .. + 3 -- 16 contiguous bytes of out[b][row*na + a][c*ks + k]
+            // 8 q + 4 lh .. + 3 -- 16 contiguous bytes of out[b][row*na + a][c*ks + k].
+            // (Every instruction is 64 separate 16-byte requests, 96 bytes apart; the same bytes written in address order take
+            // 11.6 instead of 12.6 ms (ABL 1024).  Bringing them into address order through a wave-private LDS scratch -- 24
+            // ds_write_b128 + 24 ds_read_b128 per row end, pipelined over the (tile, anchor) pairs -- measured 12.8 ms: the wave
+            // waits out the LDS round trips instead of issuing matrix instructions.  profiles/r04_row_order_experiment.txt)
             if (active && !ABL(4)) {
                 const size_t CK = (size_t)C * ks;
                 float *rb = obb + ((size_t)row * na + (PERM ? 0 : a0 + al_beg)) * CK + (size_t)c0 * ks;      // uniform
@@ -353,6 +358,10 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 #pragma unroll
                             for (int ai = 0; ai < APW; ++ai) {
                                 const f32x4 v = {acc[ct][ai][4 * q], acc[ct][ai][4 * q + 1], acc[ct][ai][4 * q + 2], acc[ct][ai][4 * q + 3]};
+                                if (ABL(1024))     // same bytes, same instructions, lanes in address order (1 KB runs; wrong places)
+                                    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"((unsigned)lane * 16u), "v"(v),
+                                                 "s"(rb + (size_t)(PERM ? am[ai] : ai) * CK + (size_t)(32 * ct) * ks + 256 * q) : "memory");
+                                else
                                 asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lo_b), "v"(v),
                                              "s"(rb + (size_t)(PERM ? am[ai] : ai) * CK + (size_t)(32 * ct) * ks + 8 * q) : "memory");
                             }

@@ -23,7 +23,7 @@ rk = L.rotated_kernels(conv.anchors, conv.kernels)
 rows, off, cnt, ent_p, ent_gx, rcap, _ = L._inverse_lists(idx, gx, P, 29, nonident)
 gy = torch.randn(B, o, P, NA, device=dev)
 feats = torch.randn(B, c, P, NA, device=dev)
-CASES = [('full kernel', 0), ('no feature DMA', 1), ('feature DMA of the same 8 rows (hits only)', 512), ('constant weights', 2), ('no row-end stores', 4), ('no LDS operand reads', 16),
+CASES = [('full kernel', 0), ('no feature DMA', 1), ('feature DMA of the same 8 rows (hits only)', 512), ('constant weights', 2), ('no row-end stores', 4), ('row-end stores in address order (wrong places)', 1024), ('no LDS operand reads', 16),
          ('no DMA, no barrier', 9), ('no DMA, constant weights', 3), ('no DMA, no weights, no LDS reads', 19), ('MFMAs + barrier only', 23), ('MFMAs only', 31)]
 
 
