@@ -83,7 +83,12 @@ __device__ inline void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 // points of one channel per accumulator quad, i.e. 16 contiguous bytes of an output row, so the row end is 24 dwordx4
 // stores per wave instead of 128 dword stores; both operands of v_mfma_f32_32x32x2_f32 use the same lane mapping, so the
 // k-loop is unchanged).  Needs ks % 4 == 0.
-#define EAP_MM(f, w, c, x, y, z) (LAYOUT == 3 ? __builtin_amdgcn_mfma_f32_32x32x2f32(w, f, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(f, w, c, 0, 0, 0))
+// 4 = LAYOUT 3 with the COLUMNS of a 32-channel tile in the order the lanes hold them: piece (q, lh, lk) -- kernel points
+// 8 q + 4 lh .. + 3 of channel lk -- goes to bytes [16 (64 q + 32 lh + lk), + 16) of the tile's 128 ks bytes, so a store
+// instruction writes one contiguous 1 KB run instead of 64 pieces 4 ks bytes apart (12.6 -> 11.6 ms at C = 128).  The
+// contraction that reads this matrix sums over the columns, so it only needs W's columns in the same order
+// (eap_so3_group_fwd_tp_columns).  Needs ks % 8 == 0 and whole 64-channel blocks.
+#define EAP_MM(f, w, c, x, y, z) (LAYOUT >= 3 ? __builtin_amdgcn_mfma_f32_32x32x2f32(w, f, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(f, w, c, 0, 0, 0))
 //
 // PERM = true: clouds WITH per-entry anchor permutations (articulated input: relative rotations between neighbours), round 4.
 // The permutation of an entry is a left multiplication in the anchor group; with the operand's anchor axis in COSET-MAJOR
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
     const unsigned lane_off = (unsigned)((size_t)(4 * lh) * o_cs + (size_t)min(lk, ks - 1) * o_ks) + (unsigned)al_beg;
     float *obb = out + (size_t)bi * C * o_cs;
     auto store_row = [&](int row) {
-        if (LAYOUT == 3) {
+        if (LAYOUT >= 3) {
             // D[i = kernel point][j = channel]: lane column = channel lk of the tile, accumulator quad q holds kernel points
             // 8 q + 4 lh .. + 3 -- 16 contiguous bytes of out[b][row*na + a][c*ks + k].
             // (Every instruction is 64 separate 16-byte requests, 96 bytes apart; the same bytes written in address order take
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(TM, 2) void so3_group_lists2_kernel(
 #pragma unroll
                             for (int ai = 0; ai < APW; ++ai) {
                                 const f32x4 v = {acc[ct][ai][4 * q], acc[ct][ai][4 * q + 1], acc[ct][ai][4 * q + 2], acc[ct][ai][4 * q + 3]};
-                                if (ABL(1024))     // same bytes, same instructions, lanes in address order (1 KB runs; wrong places)
+                                if (LAYOUT == 4 || ABL(1024))     // lanes in address order: 1 KB runs (LAYOUT 3 under ABL 1024: wrong places)
                                     asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"((unsigned)lane * 16u), "v"(v),
                                                  "s"(rb + (size_t)(PERM ? am[ai] : ai) * CK + (size_t)(32 * ct) * ks + 256 * q) : "memory");
                                 else
@@ -494,9 +499,11 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
         return eap::bad_arg("so3_group_lists2: output rows too far apart for 32-bit store offsets");
     const bool perm = order != nullptr;          // ent_p / ent_gx are then the per-entry words of eap_so3_perm_entries_f32
     if (perm && ((na & 3) != 0 || fpitch != na)) return eap::bad_arg("so3_group_lists2: the permuted variant takes unpadded rows of a multiple of 4 anchors");
+    const bool lane_order = !LISTS && layout == 4;
+    if (lane_order && ((ks & 7) != 0 || (C % CB) != 0)) return eap::bad_arg("so3_group_lists2: the store-order columns need ks % 8 == 0 and whole 64-channel blocks");
     const bool wide = !LISTS && layout == 2 && g_store16 != 0 && (ks & 3) == 0;
-    auto kern = perm ? (wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3, true> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2, true> : so3_group_lists2_kernel<LISTS, 0, true>)
-                     : (wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>);
+    auto kern = perm ? (lane_order ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 4, true> : wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3, true> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2, true> : so3_group_lists2_kernel<LISTS, 0, true>)
+                     : (lane_order ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 4> : wide ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 3> : layout == 2 ? so3_group_lists2_kernel<LISTS, LISTS ? 0 : 2> : so3_group_lists2_kernel<LISTS, 0>);
     const size_t shmem = perm ? SHMEM_PERM : SHMEM;
     int e = eap::hip_fail(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), what);
     if (e) return e;
@@ -510,6 +517,8 @@ int launch2(int layout, int b, int C, int PF, int na, int fpitch, int ks, int R,
 #endif
     hipLaunchKernelGGL(kern, grid, dim3(TM), shmem, s, C, PF, na, fpitch, ks, R, nn, ent_stride, AG, RPB, (LISTS ? g_xcd_map_inv : g_xcd_map_fwd) == 2, dbg, 1.0f / sigma, F,
                        rows, off, cnt, ent_p, reinterpret_cast<const float4 *>(ent_gx), rk, nonident, out, order);
+    if (lane_order) eap::set_kernel(perm ? "so3_group_lists2_kernel<false, 4, true>" : "so3_group_lists2_kernel<false, 4>");
+    else
     eap::set_kernel(perm ? (LISTS ? "so3_group_lists2_kernel<true, 0, true>" : wide ? "so3_group_lists2_kernel<false, 3, true>" : layout == 2 ? "so3_group_lists2_kernel<false, 2, true>" : "so3_group_lists2_kernel<false, 0, true>")
                          : (LISTS ? "so3_group_lists2_kernel<true, 0>" : wide ? "so3_group_lists2_kernel<false, 3>" : layout == 2 ? "so3_group_lists2_kernel<false, 2>" : "so3_group_lists2_kernel<false, 0>"));
     return eap::check_launch(what);
@@ -663,23 +672,56 @@ extern "C" int eap_so3_inter_group_inv_perm2_f32(int b, int o, int p, int nn, in
                          "so3_inter_group_inv (permuted clouds, two channel tiles)", order);
 }
 
+// ---- transposed output with the columns in store order (LAYOUT 4) -------------------------------------------------------
+// 1 if eap_so3_inter_group_fwd_tp_f32 takes this shape
+extern "C" int eap_so3_group_fwd_tp_takes(int c, int na, int ks) {
+    return g_store16 != 0 && (ks & 7) == 0 && ks <= 32 && (c % CB) == 0 && eap::group_lists_supported(na, ks) && eap::group_lists2_preferred(c, na, ks, 2);
+}
+
+// the column order: perm[j] (host array, c*ks entries) = the column c_*ks + k of the plain transposed matrix that sits at
+// position j of a row -- per 32-channel tile t: j = t*32*ks + ((q*2 + lh)*32 + lk)*4 + i  <->  channel 32 t + lk, kernel
+// point 8 q + 4 lh + i.  A contraction reads W[:, perm] beside this matrix.
+extern "C" int eap_so3_group_fwd_tp_columns(int c, int ks, int32_t *perm) {
+    if (c <= 0 || ks <= 0 || (ks & 7) != 0 || (c & 31) != 0 || !perm) return eap::bad_arg("so3_group_fwd_tp_columns: ks % 8 == 0, c % 32 == 0");
+    for (int t = 0; t < c / 32; ++t)
+        for (int q = 0; q < ks / 8; ++q)
+            for (int lh = 0; lh < 2; ++lh)
+                for (int lk = 0; lk < 32; ++lk)
+                    for (int i = 0; i < 4; ++i)
+                        perm[(size_t)t * 32 * ks + ((q * 2 + lh) * 32 + lk) * 4 + i] = (32 * t + lk) * ks + 8 * q + 4 * lh + i;
+    return 0;
+}
+
+// eap_so3_inter_group_fwd_t_f32 for clouds WITHOUT anchor permutations, columns in store order (above): out [b][p*na + a][c*ks]
+extern "C" int eap_so3_inter_group_fwd_tp_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                                              const int32_t *idx, const float *gx, const float *rk, float *out, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || p <= 0) return 0;
+    if (nn <= 0 || !eap_so3_group_fwd_tp_takes(c, na, ks) || (long long)c * n * na >= (1ll << 31))
+        return eap::bad_arg("so3_inter_group_fwd_tp: shape not taken (ask eap_so3_group_fwd_tp_takes)");
+    return eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, nullptr, 4, out, eap::S(stream));
+}
+
 // Forward grouping, transposed output X^T [b][p*na + a][c*ks + k] (eap_so3_inter_group_fwd_t_f32), with the clouds WITH
 // anchor permutations (nonident[b] != 0) on the two-tile kernel: feats_c = feats with a coset-major anchor axis
 // (eap_anchor_reorder_clouds_f32 with the `order` of the multiplication table's coset tables), ent_pc / ent_gx2 from
 // eap_so3_perm_entries_f32 over (idx, gx) with that table's code and anchors = NULL.  Clouds without permutations take the
-// plain kernel on feats / idx / gx as before.  The output is in memory order (one row per anchor).
+// plain kernel on feats / idx / gx as before.  The output is in memory order (one row per anchor); store_order_columns != 0:
+// its columns as eap_so3_inter_group_fwd_tp_f32 writes them.
 extern "C" int eap_so3_inter_group_fwd_perm2_t_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                                                    const float *feats_c, const int32_t *idx, const float *gx, const int32_t *ent_pc,
                                                    const float *ent_gx2, const float *rk, const uint8_t *order, const int32_t *nonident,
-                                                   float *out, eap_stream_t stream) {
+                                                   int store_order_columns, float *out, eap_stream_t stream) {
     if (b <= 0 || c <= 0 || p <= 0) return 0;
+    if (store_order_columns && !eap_so3_group_fwd_tp_takes(c, na, ks)) return eap::bad_arg("so3_inter_group_fwd_perm2_t: store-order columns not available for this shape");
+    const int lay = store_order_columns ? 4 : 2;
     if (!order || !nonident || nn <= 0 || !eap_so3_group_perm_lists2_takes(c, na, ks, n) || (long long)c * n * na >= (1ll << 31))
         return eap::bad_arg("so3_inter_group_fwd_perm2_t: shape not taken (ask eap_so3_group_perm_lists2_takes; flags and order are required)");
-    int e = eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, nonident, 2, out, eap::S(stream));
+    int e = eap::group_lists2_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, nonident, lay, out, eap::S(stream));
     if (e) return e;
-    e = launch2<false>(2, b, c, n, na, na, ks, p, nn, 0, sigma, feats_c, nullptr, nullptr, nullptr, ent_pc, ent_gx2, rk, nonident, out, eap::S(stream),
+    e = launch2<false>(lay, b, c, n, na, na, ks, p, nn, 0, sigma, feats_c, nullptr, nullptr, nullptr, ent_pc, ent_gx2, rk, nonident, out, eap::S(stream),
                        "so3_inter_group_fwd (permuted clouds, two channel tiles)", order);
     // (which of the two launches did the work is only known on the device: the per-cloud flags)
-    eap::set_kernel(g_store16 != 0 && (ks & 3) == 0 ? "so3_group_lists2_kernel<false, 3> | <false, 3, true>" : "so3_group_lists2_kernel<false, 2> | <false, 2, true>");
+    eap::set_kernel(store_order_columns ? "so3_group_lists2_kernel<false, 4> | <false, 4, true>"
+                    : g_store16 != 0 && (ks & 3) == 0 ? "so3_group_lists2_kernel<false, 3> | <false, 3, true>" : "so3_group_lists2_kernel<false, 2> | <false, 2, true>");
     return e;
 }

@@ -205,10 +205,33 @@ def so3_inter_group_fwd_can_block(c, n, na, ks, has_mult, has_flag):
     return bool(lib.eap_so3_inter_group_fwd_can_block(c, n, na, ks, int(has_mult), int(has_flag)))
 
 
-def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=False, coset=None):
+_TP_COLUMNS = {}
+
+
+def so3_group_fwd_tp_takes(c, na, ks):
+    return bool(lib.eap_so3_group_fwd_tp_takes(int(c), int(na), int(ks)))
+
+
+def so3_group_fwd_tp_columns(c, ks, device):
+    """int64 [c*ks] on `device`: position j of a row of the store-order transposed intermediate holds column perm[j] of the
+    plain one (include/eap_hip.h: eap_so3_group_fwd_tp_columns)."""
+    key = (int(c), int(ks), str(device))
+    hit = _TP_COLUMNS.get(key)
+    if hit is None:
+        import numpy as np
+        perm = np.empty(c * ks, np.int32)
+        if lib.eap_so3_group_fwd_tp_columns(int(c), int(ks), perm.ctypes.data_as(ctypes.c_void_p)) != 0:
+            raise RuntimeError(lib.eap_last_error().decode())
+        hit = _TP_COLUMNS[key] = torch.from_numpy(perm.astype(np.int64)).to(device)
+    return hit
+
+
+def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=False, coset=None, store_order=False):
     """-> X [b,c,ks,p,na]; with `blocked` the same numbers as [b,p,na/4,c,ks,4] (returned with the
     nominal shape: only eap_gemm_f32_xb may read it).  coset = the coset tables of `mult`
-    (vgtk.so3conv.functional._coset_tables): permuted clouds of the transposed layout take the two-tile kernel."""
+    (vgtk.so3conv.functional._coset_tables): permuted clouds of the transposed layout take the two-tile kernel.
+    store_order: the transposed intermediate with its columns in the kernel's store order (so3_group_fwd_tp_columns) -- only a
+    contraction with W[:, columns] may read it."""
     b, c, n, na = feats.shape
     p, nn = idx.shape[1], idx.shape[2]
     ks = rk.shape[1]
@@ -221,8 +244,14 @@ def so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident=None, blocked=
         call('eap_anchor_reorder_clouds_f32', feats, b, _I64(c * n), na, _ptr(feats), _ptr(coset[0]), _ptr(nonident), _ptr(feats_c))
         ent_pc, ent_gx2 = so3_perm_entries(idx.view(b, p * nn), gx.view(b, p * nn, 4), coset[1], None, 0, na, n, nonident)
         call('eap_so3_inter_group_fwd_perm2_t_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(feats_c), _ptr(idx), _ptr(gx),
-             _ptr(ent_pc), _ptr(ent_gx2), _ptr(rk), _ptr(coset[0]), _ptr(nonident), _ptr(out),
+             _ptr(ent_pc), _ptr(ent_gx2), _ptr(rk), _ptr(coset[0]), _ptr(nonident), int(bool(store_order)), _ptr(out),
              tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd_perm2', b, c, p, nn, na, ks)})
+        return out
+    if store_order:
+        if mult is not None or int(blocked) != 2:
+            raise RuntimeError('store-order columns: transposed layout, clouds without permutation (or the coset tables for the flagged ones)')
+        call('eap_so3_inter_group_fwd_tp_f32', out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx), _ptr(gx), _ptr(rk), _ptr(out),
+             tag={'flops': 2.0 * b * c * ks * p * nn * na, 'shape': ('group_fwd_tp', b, c, p, nn, na, ks)})
         return out
     call({0: 'eap_so3_inter_group_fwd_f32', 1: 'eap_so3_inter_group_fwd_xb_f32', 2: 'eap_so3_inter_group_fwd_t_f32'}[int(blocked)], out, b, c, p, n, nn, na, ks, _F32(sigma), _ptr(feats), _ptr(idx),
          _ptr(gx), _ptr(rk), _ptr(mult), _ptr(nonident), _ptr(out),

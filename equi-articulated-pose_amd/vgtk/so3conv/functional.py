@@ -204,6 +204,7 @@ def _group_tables_inverse(mult):
 
 
 _COSETS = {}
+STORE_ORDER_COLUMNS = True     # streamed forward: the transposed intermediate's columns in the grouping kernel's store order
 COSET_OPERAND = True      # permuted-pose backward: coset-major LDS operand (False: per-anchor byte-table lookups, for A/B runs)
 
 
@@ -549,11 +550,16 @@ class _InterConv(torch.autograd.Function):
         else:
             x = None
             step = max(1, X_CHUNK_CLOUDS)
+            # X is scratch between the grouping and the contraction here: its columns may be in the order the grouping kernel's
+            # lanes hold them (1 KB store runs, csrc/so3_inter_lists2.hip LAYOUT 4) with W's columns permuted to match
+            tp = (STORE_ORDER_COLUMNS and layout == 2 and _hip.so3_group_fwd_tp_takes(c, na, ks)
+                  and (mult is None or (coset is not None and _hip.so3_group_perm_lists2_takes(c, na, ks, n))))
+            Wc = W.index_select(1, _hip.so3_group_fwd_tp_columns(c, ks, W.device)) if tp else W
             for b0 in range(0, b, step):
                 b1 = min(b, b0 + step)
                 xs = _hip.so3_inter_group_fwd(feats[b0:b1], idx[b0:b1], gx[b0:b1], rk, mult, sigma,
-                                              None if nonident is None else nonident[b0:b1], blocked=layout, coset=coset)
-                _contract_into(W, xs, y[b0:b1].view(b1 - b0, o, p * na), layout, epilogue, b0)
+                                              None if nonident is None else nonident[b0:b1], blocked=layout, coset=coset, store_order=tp)
+                _contract_into(Wc, xs, y[b0:b1].view(b1 - b0, o, p * na), layout, epilogue, b0)
                 del xs
         ctx.layout = layout
         ctx.kept_x = x is not None

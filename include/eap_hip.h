@@ -242,8 +242,17 @@ int eap_so3_perm_entries_f32(int b, int per_cloud, int na, int n_support, const 
  * other clouds take the plain kernel.  Replaces so3conv/functional.py:L1199-1261 for those clouds. */
 int eap_so3_inter_group_fwd_perm2_t_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                                         const float *feats_c, const int32_t *idx, const float *gx, const int32_t *ent_pc,
-                                        const float *ent_gx2, const float *rk, const uint8_t *order, const int32_t *nonident, float *out,
-                                        eap_stream_t stream);
+                                        const float *ent_gx2, const float *rk, const uint8_t *order, const int32_t *nonident,
+                                        int store_order_columns, float *out, eap_stream_t stream);
+/* eap_so3_inter_group_fwd_t_f32 (clouds without anchor permutations) with the COLUMNS of the transposed matrix in the order the
+ * kernel's lanes hold them, so that every store instruction writes one contiguous 1 KB run (round 4; the intermediate is
+ * scratch between the grouping and the contraction, and a contraction sums over the columns: it reads W[:, perm] beside it).
+ * eap_so3_group_fwd_tp_takes: 1 if the shape is taken (whole 64-channel blocks, ks % 8 == 0); eap_so3_group_fwd_tp_columns
+ * fills the HOST array perm [c*ks]: position j of a row holds column perm[j] = channel * ks + kernel point of the plain matrix. */
+int eap_so3_group_fwd_tp_takes(int c, int na, int ks);
+int eap_so3_group_fwd_tp_columns(int c, int ks, int32_t *perm);
+int eap_so3_inter_group_fwd_tp_f32(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                                   const int32_t *idx, const float *gx, const float *rk, float *out, eap_stream_t stream);
 int eap_so3_inter_group_inv_perm2_f32(int b, int o, int p, int nn, int na, int ks, int rcap, float sigma, const float *gy,
                                       const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_pc,
                                       const float *ent_gx2, const float *rk, const uint8_t *order, float *z, eap_stream_t stream);

@@ -897,6 +897,15 @@ def test_two_tile_grouping_kernel_equals_one_tile_kernel(dev, vg, shape):
     # transposed layout holds the same numbers: [b, p*na + a, c*ks + k]
     xt = out[2][1].view(b, p * na, c * ks)
     assert torch.equal(xt.view(b, p, na, c, ks).permute(0, 3, 4, 1, 2), out[2][0])
+    # ... and with its columns in the kernel's store order (LAYOUT 4: 1 KB store runs) the same bits at the positions
+    # eap_so3_group_fwd_tp_columns names
+    if _hip.so3_group_fwd_tp_takes(c, na, ks):
+        tp = _hip.so3_inter_group_fwd(feats, idx, gx, rk, None, sigma, blocked=2, store_order=True).view(b, p * na, c * ks)
+        cols = _hip.so3_group_fwd_tp_columns(c, ks, dev)
+        assert sorted(cols.tolist()) == list(range(c * ks))
+        assert torch.equal(tp, xt.index_select(2, cols))
+    else:
+        assert c % 64 != 0 or ks % 8 != 0
 
 
 @pytest.mark.gpu
