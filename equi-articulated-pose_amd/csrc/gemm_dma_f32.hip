@@ -360,7 +360,10 @@ int launch_debug(DmaArgs g, int zcount, hipStream_t s) {
 template <bool AKM, bool BKN>
 int launch_shape(const DmaArgs &g, int zcount, hipStream_t s) {
     // block tile 256 x 256 (wave tile 128 x 128); for M <= 128: 128 x 512 (the same wave tile) when that still leaves
-    // four workgroups per CU, else 128 x 256; 256 x 128 for N <= 128
+    // four workgroups per CU, else 128 x 256; 256 x 128 for N <= 128; 64 x 512 / 512 x 64 for a side of at most 64
+    // a 64-wide side: 64 x 512 / 512 x 64 tiles (half of a 128-row tile would be padding)
+    if (g.M <= 64 && g.N > 64) return launch_one<1, 4, 2, 4, AKM, BKN>(g, zcount, s);
+    if (g.N <= 64 && g.M > 64) return launch_one<4, 1, 4, 2, AKM, BKN>(g, zcount, s);
     if (g.M <= 128 && (long long)((g.N + 511) / 512) * zcount >= 1024) return launch_one<1, 4, 4, 4, AKM, BKN>(g, zcount, s);
     if (g.M <= 128) return launch_one<1, 4, 4, 2, AKM, BKN>(g, zcount, s);
     if (g.N <= 128) return launch_one<4, 1, 2, 4, AKM, BKN>(g, zcount, s);
@@ -394,7 +397,8 @@ bool supported(int transA, int transB, int M, int N, int K, const float *A, int6
 
 int pick_splits(int M, int N, int K, int batch) {
     // one workgroup per CU: enough blocks to fill 256 CUs about four times over, at least 8 k-tiles per split
-    const int bm = M <= 128 ? 128 : 256, bn = N <= 128 ? 128 : 256;
+    const int bm = (M <= 64 && N > 64) ? 64 : (N <= 64 && M > 64) ? 512 : M <= 128 ? 128 : 256;
+    const int bn = (N <= 64 && M > 64) ? 64 : (M <= 64 && N > 64) ? 512 : N <= 128 ? 128 : 256;
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
     int splits = (1024 + tiles - 1) / tiles;
     const int max_splits = K / (8 * BK) > 0 ? K / (8 * BK) : 1;

@@ -97,6 +97,7 @@ def suffix(t):
 # EAP_DMA_GEMM=0 forces the older kernel everywhere (A/B runs).
 USE_DMA_GEMM = os.environ.get('EAP_DMA_GEMM', '1') != '0'
 lib.eap_gemm_dma_f32_reduce_workspace.restype = ctypes.c_int64
+lib.eap_gemm_skinny_reduce_workspace.restype = ctypes.c_int64
 lib.eap_gemm_bf16x3_reduce_workspace.restype = ctypes.c_int64
 
 
@@ -162,6 +163,13 @@ def gemm_reduce(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ld
         ws = torch.empty(int(lib.eap_gemm_bf16x3_reduce_workspace(M, N, K, batch)), dtype=torch.float32, device=C.device)
         call('eap_gemm_bf16x3_reduce_f32', C, M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C),
              _I64(ldc), batch, _ptr(ws), tag=tag)
+        return
+    if not b_blocked and not transA and transB and lib.eap_gemm_skinny_reduce_f32_supported(M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B),
+                                                                                         _I64(ldb), _I64(strideB)):
+        # a small output over a long contraction (the first layer's weight gradient): streaming reduction, csrc/gemm_skinny.hip
+        ws = torch.empty(max(int(lib.eap_gemm_skinny_reduce_workspace(M, N, K, batch)), 1), dtype=torch.float32, device=C.device)
+        call('eap_gemm_skinny_reduce_f32', C, M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc),
+             batch, _ptr(ws), tag=tag)
         return
     if not b_blocked and _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
         ws = torch.empty(max(int(lib.eap_gemm_dma_f32_reduce_workspace(M, N, K, batch)), 1), dtype=torch.float32, device=C.device)

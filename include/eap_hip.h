@@ -405,6 +405,16 @@ int64_t eap_gemm_dma_f32_reduce_workspace(int M, int N, int K, int batch);
 int eap_gemm_dma_f32_reduce(int transA, int transB, int M, int N, int K, const float *A, int64_t lda,
                             int64_t strideA, const float *B, int64_t ldb, int64_t strideB, float *C, int64_t ldc,
                             int batch, float *workspace, eap_stream_t stream);
+/* C[M,N] = sum_z A_z[M,K] B_z[N,K]^T for a SMALL output and a long contraction (M <= 64, N <= 32, K >= 4096; both operands
+ * k-contiguous, 16-byte aligned, pitches and strides multiples of 4 floats): the first layer's weight gradient
+ * dW[64, 24] = sum_b dY_b X_b^T (textbook backward of so3conv/modules.py:L48-55 at C = 1).  A streaming reduction -- 16-byte
+ * loads straight into the MFMA operand registers, per-wave partial sums added in a fixed order (bit-reproducible); the tiled
+ * kernels pad this product to 5 % useful work.  workspace: eap_gemm_skinny_reduce_workspace floats. */
+int eap_gemm_skinny_reduce_f32_supported(int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B,
+                                         int64_t ldb, int64_t strideB);
+int64_t eap_gemm_skinny_reduce_workspace(int M, int N, int K, int batch);
+int eap_gemm_skinny_reduce_f32(int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B, int64_t ldb,
+                               int64_t strideB, float *C, int64_t ldc, int batch, float *workspace, eap_stream_t stream);
 
 /* ---- blocked intermediate: the forward's grouped tensor X with coalesced row-end stores --------
  * X_blocked[b][p][a/4][c][k][4] holds the same numbers as X[b][c][k][p][a].  The grouping kernels

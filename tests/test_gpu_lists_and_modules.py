@@ -189,7 +189,8 @@ def test_zpconv_wrappers_pooling_and_index_helpers(dev):
 
 
 @pytest.mark.parametrize('M,N,K,batch', [(512, 1920, 3072, 1), (128, 2040, 1536, 2), (256, 128, 32, 1), (130, 260, 48, 2),
-                                        (64, 4, 16, 1), (300, 1000, 160, 3), (12288, 128, 960, 2)])
+                                        (64, 4, 16, 1), (300, 1000, 160, 3), (12288, 128, 960, 2),
+                                        (64, 1680, 384, 2), (52, 1000, 96, 1), (1536, 64, 320, 2), (700, 60, 160, 1)])   # 64 x 512 / 512 x 64 tiles
 def test_gemm_dma_all_operand_layouts(dev, M, N, K, batch):
     """csrc/gemm_dma_f32.hip (DMA-fed ring) in its four operand layouts + the k-split batch reduction, against
     float64 matmul; ragged M / N tiles, a single k-tile, K = 2 k-tiles (ring shorter than its depth)."""
@@ -1261,3 +1262,34 @@ def test_store_order_columns_of_the_streamed_intermediate(dev, monkeypatch, pose
 
     assert rel_err(res[True][0].cpu().numpy(), res[False][0].cpu().numpy()) < 4e-6
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+
+
+@pytest.mark.parametrize('M,N,K,batch', [(64, 24, 245760, 2), (64, 24, 20004, 3), (40, 17, 9000, 1), (32, 32, 4096, 5), (7, 3, 5000, 2)])
+def test_gemm_skinny_reduce(dev, M, N, K, batch):
+    """csrc/gemm_skinny.hip: C[M,N] = sum_b A_b[M,K] B_b[N,K]^T for a small output over a long contraction (the first layer's
+    weight gradient at the bench shape first) against float64; ragged M, N and K tails; run-to-run bit equality; and
+    vgtk._hip.gemm_reduce routes such operands there."""
+    from vgtk import _hip
+    gen = torch.Generator().manual_seed(5)
+    A = torch.randn(batch, M, K, generator=gen).to(dev)
+    B = torch.randn(batch, N, K, generator=gen).to(dev)
+    ref = torch.einsum('bmk,bnk->mn', A.double(), B.double())
+    assert _hip.lib.eap_gemm_skinny_reduce_f32_supported(M, N, K, _hip._ptr(A), _hip._I64(K), _hip._I64(M * K), _hip._ptr(B), _hip._I64(K), _hip._I64(N * K))
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N + 3), float('nan'), device=dev)                # a row pitch wider than N
+        ws = torch.empty(int(_hip.lib.eap_gemm_skinny_reduce_workspace(M, N, K, batch)), device=dev)
+        _hip.call('eap_gemm_skinny_reduce_f32', C, M, N, K, _hip._ptr(A), _hip._I64(K), _hip._I64(M * K), _hip._ptr(B), _hip._I64(K), _hip._I64(N * K),
+                  _hip._ptr(C), _hip._I64(N + 3), batch, _hip._ptr(ws))
+        outs.append(C)
+    assert torch.equal(outs[0][:, :N], outs[1][:, :N]) and torch.isnan(outs[0][:, N:]).all()
+    scale = float((A.double().abs().unsqueeze(2) * B.double().abs().unsqueeze(1)).sum((0, 3)).max())
+    assert float((outs[0][:, :N].double() - ref).abs().max()) < 1e-6 * scale
+    launched = []
+    _hip.KERNEL_TIMES = launched
+    try:
+        C2 = torch.empty(M, N, device=dev)
+        _hip.gemm_reduce(0, 1, M, N, K, A, K, M * K, B, K, N * K, C2, N, batch)
+    finally:
+        _hip.KERNEL_TIMES = None
+    assert [n for n, *_ in launched] == ['eap_gemm_skinny_reduce_f32'] and torch.equal(C2, outs[0][:, :N].contiguous())
