@@ -416,6 +416,18 @@ def _inv_lists_supported(idx, n_sup, na, ks):
     return na % 4 == 0 and ks <= 32 and n_sup <= INV_LISTS_MAX_ROWS and (idx.shape[1] * idx.shape[2]) % 4 == 0
 
 
+LISTS_ON_SIDE_STREAM = True     # inverse neighbour lists built beside the forward's grouping / contraction kernels
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class _ListHead:
     """First half of the inverse neighbour lists of idx [b,p,nn] (csrc/inv_lists.hip): per cloud the
     referenced support rows (longest list first), their counts and offsets -- all on the device -- plus an
@@ -423,14 +435,32 @@ class _ListHead:
     number of referenced rows of a cloud; whether any cloud carries non-identity relative rotations).
     Built in the forward, read in the backward: by then the copy has long landed, so nothing stalls."""
 
-    def __init__(self, idx, n_sup, nonident):
-        self.rows, self.off, self.cnt, self.n_rows = _hip.inv_lists_rows(idx, n_sup)
-        flag = nonident.max() if nonident is not None else torch.ones((), dtype=torch.int32, device=idx.device)
-        stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32)])
-        self.host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        self.host.copy_(stats, non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(idx.device))
+    def __init__(self, idx, n_sup, nonident, gx=None, prefill=False):
+        """prefill (with gx): also the second half (csrc/inv_lists.hip fill: the entries of every referenced row) right away,
+        for all rows -- the launch needs no host value that way.  Everything runs on a SIDE stream (LISTS_ON_SIDE_STREAM): these
+        are small latency-bound kernels (0.3 + 0.45 ms per layer) that nothing in the forward waits for, and the grouping and
+        contraction kernels that follow on the main stream leave them room; the backward waits for `event`."""
+        dev = idx.device
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if LISTS_ON_SIDE_STREAM else main
+        if side is not main:
+            side.wait_stream(main)                        # idx / gx / nonident were produced on the main stream
+        with torch.cuda.stream(side):
+            self.rows, self.off, self.cnt, self.n_rows = _hip.inv_lists_rows(idx, n_sup)
+            flag = nonident.max() if nonident is not None else torch.ones((), dtype=torch.int32, device=dev)
+            stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32)])
+            self.host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            self.host.copy_(stats, non_blocking=True)
+            self.entries = _hip.inv_lists_fill(idx, gx, self.rows, self.off, n_sup) if (prefill and gx is not None) else None
+            self.event = torch.cuda.Event()
+            self.event.record(side)
+        if side is not main:                              # allocated under the side stream, used (and freed) under the main one
+            for t in (self.rows, self.off, self.cnt, self.n_rows) + (self.entries or ()):
+                t.record_stream(main)
+
+    def wait(self):
+        """the current stream waits for the lists (device side; no host stall)"""
+        torch.cuda.current_stream(self.rows.device).wait_event(self.event)
 
     def decide(self):
         """-> (rcap, any_nonident) as Python values."""
@@ -449,6 +479,7 @@ def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
         nonident = (gx[..., 3].contiguous().view(torch.int32) != ident).flatten(1).any(1).to(torch.int32)
     head = _ListHead(idx, n_sup, nonident)
     rcap, any_nonident = head.decide()
+    head.wait()
     ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
     return (head.rows[:, :rcap].contiguous(), head.off[:, :rcap].contiguous(), head.cnt[:, :rcap].contiguous(),
             ent_p, ent_gx, rcap, not any_nonident)
@@ -542,6 +573,9 @@ class _InterConv(torch.autograd.Function):
             raise RuntimeError('a folded epilogue is an inference-time fusion: build and use it under torch.no_grad()')
         lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)
         keep = needs_grad and (not lists_ok or _keep_x_hint(W_param))
+        # inverse neighbour lists (device only; the host-side numbers arrive asynchronously), started before the grouping so that
+        # they run beside it; the entries too when the previous backward of this layer took the lists
+        ctx.head = _ListHead(idx, n, nonident, gx, prefill=not keep) if (lists_ok and needs_grad) else None
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
         coset = _coset_tables(mult, ident) if (mult is not None and nonident is not None and layout == 2 and COSET_OPERAND) else None
         if keep:
@@ -571,10 +605,6 @@ class _InterConv(torch.autograd.Function):
         ctx.has_mult = mult is not None
         ctx.has_flag = nonident is not None
         ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
-        # inverse neighbour lists, first half (device only; the host-side numbers arrive asynchronously)
-        ctx.head = None
-        if lists_ok and needs_grad:
-            ctx.head = _ListHead(idx, feats.shape[2], nonident)
         return y
 
     @staticmethod
@@ -612,9 +642,10 @@ class _InterConv(torch.autograd.Function):
             # gradient GEMMs a multiple of 16.  (A multiple of 32 would put the dF GEMM on the split kernel -- measured: the 18 %
             # more rows at 136 referenced rows cost what the faster kernel gains.)
             rcap = min((rcap + 3) & ~3, n)
+            head.wait()
             rows = head.rows[:, :rcap].contiguous()
             off, cnt = head.off[:, :rcap].contiguous(), head.cnt[:, :rcap].contiguous()
-            ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
+            ent_p, ent_gx = head.entries if head.entries is not None else _hip.inv_lists_fill(idx, gx, head.rows, head.off, rcap)
             multinv = _group_tables_inverse(mult) if (mult is not None and any_nonident) else None
             coset = _coset_tables(multinv, ctx.ident) if (multinv is not None and COSET_OPERAND) else None
             z_order = None
