@@ -20,6 +20,7 @@
 // VGPRs, 8 waves (2 per SIMD).  With an anchor permutation the weight's anchor changes per entry,
 // so the rotated kernel points come from an LDS table instead of registers.
 #include "common.h"
+#include <algorithm>
 
 #ifdef EAP_INV_TRACE
 __device__ unsigned long long eap_inv_trace[8 * 16];
@@ -617,13 +618,15 @@ namespace {
 __global__ __launch_bounds__(256) void anchor_reorder_kernel(long long words, int npiece, int na, const float *__restrict__ src,
                                                              const uint8_t *__restrict__ order, float4 *__restrict__ dst,
                                                              long long words_per_cloud = 0, const int32_t *__restrict__ nonident = nullptr) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= words || (nonident != nullptr && nonident[i / words_per_cloud] == 0)) return;
-    const long long row = i / npiece;
-    const int pc = (int)(i - row * npiece);
-    const float *r = src + row * na;
-    const uchar4 o4 = *reinterpret_cast<const uchar4 *>(order + 4 * pc);
-    dst[i] = make_float4(r[o4.x], r[o4.y], r[o4.z], r[o4.w]);
+    // grid-stride: a launch over clouds that are all skipped costs a few thousand workgroups, not one per 256 words
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256) {
+        if (nonident != nullptr && nonident[i / words_per_cloud] == 0) continue;
+        const long long row = i / npiece;
+        const int pc = (int)(i - row * npiece);
+        const float *r = src + row * na;
+        const uchar4 o4 = *reinterpret_cast<const uchar4 *>(order + 4 * pc);
+        dst[i] = make_float4(r[o4.x], r[o4.y], r[o4.z], r[o4.w]);
+    }
 }
 }  // namespace
 
@@ -634,7 +637,7 @@ extern "C" int eap_anchor_reorder_f32(int64_t rows, int na, const float *src, co
     if ((na & 3) != 0 || (reinterpret_cast<uintptr_t>(order) & 3) || (reinterpret_cast<uintptr_t>(dst) & 15))
         return eap::bad_arg("anchor_reorder: na must be a multiple of 4, order 4-byte and dst 16-byte aligned");
     const long long words = rows * (na >> 2);
-    hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
+    hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)std::min<long long>((words + 255) / 256, 16384)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
                        reinterpret_cast<float4 *>(dst), 0ll, (const int32_t *)nullptr);
     return eap::check_launch("anchor_reorder");
 }
@@ -646,7 +649,7 @@ extern "C" int eap_anchor_reorder_clouds_f32(int b, int64_t rows_per_cloud, int 
     if ((na & 3) != 0 || (reinterpret_cast<uintptr_t>(order) & 3) || (reinterpret_cast<uintptr_t>(dst) & 15))
         return eap::bad_arg("anchor_reorder_clouds: na must be a multiple of 4, order 4-byte and dst 16-byte aligned");
     const long long per = rows_per_cloud * (na >> 2), words = per * b;
-    hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
+    hipLaunchKernelGGL(anchor_reorder_kernel, dim3((unsigned)std::min<long long>((words + 255) / 256, 16384)), dim3(256), 0, eap::S(stream), words, na >> 2, na, src, order,
                        reinterpret_cast<float4 *>(dst), per, nonident);
     return eap::check_launch("anchor_reorder_clouds");
 }
