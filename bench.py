@@ -33,6 +33,7 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import re  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -336,7 +337,8 @@ def pmc_of_kernel(kname):
     names its source file)."""
     path, d = pmc_file()
     for pat, v in d.get('per_kernel', {}).items():
-        if kname.startswith(pat):
+        # (the profiler prints defaulted template arguments, eap_last_kernel() does not: '<true, 0, false>' is '<true, 0>')
+        if kname.startswith(pat) or kname.startswith(re.sub(r',\s*false>$', '>', pat)):
             return dict(v, source=os.path.relpath(path, ROOT), collected=d.get('collected'))
     return None
 
