@@ -346,6 +346,15 @@ def pmc_of_kernel(kname):
 def roofline_object(kname, k, default_cfg):
     ach = k['flops'] / (k['ms'] * 1e-3) / 1e12 if k['ms'] > 0 else 0.0
     pmc = pmc_of_kernel(kname) if default_cfg else None
+    if 'f16x2' in kname:
+        # fp32 operands, fp32 accumulation, every product as three fp16 MFMA products of two-plane splits (csrc/gemm_bf16x3.hip,
+        # gemm_f16x2_kernel): the roofline is the fp16 matrix pipe (same dense peak as bf16), 3 x the algorithmic flops on it
+        peak = PEAK_BF16_MFMA_TFLOPS
+        return {'bound': 'mfma', 'pipe': 'fp16 (2 x fp16 split of scaled fp32 operands: 3 fp16 MFMAs per fp32-equivalent product, fp32 accumulate)',
+                'kernel': kname, 'entries': sorted(k['entries']), 'achieved': 3.0 * ach, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': 3.0 * ach / peak, 'fp32_equivalent_TFLOPs': ach, 'fp32_equivalent_over_fp32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS,
+                'traffic': (pmc['fetch'] + pmc['write']) if pmc else None, 'traffic_detail': pmc, 'launches': k['launches'],
+                'avg_launch_ms': k['ms'] / max(k['launches'], 1)}
     if 'bf16x3' in kname:
         # fp32 operands, fp32 accumulation, every product as six bf16 MFMA products (csrc/gemm_bf16x3.hip): the roofline of
         # this kernel is the bf16 matrix pipe, and it executes 6 x the algorithmic flops on it
@@ -708,8 +717,8 @@ def main(argv=None):
     _hip.KERNEL_TIMES = []
     dt_attr = timed(attr_steps)
     records, _hip.KERNEL_TIMES = _hip.KERNEL_TIMES, None
-    # same-run A/B of the forward contraction: the fp32-MFMA kernel instead of the 3 x bf16 split
-    ab = None
+    # same-run A/B of the forward contraction: the fp32-MFMA kernel, and the three-bf16-plane split, instead of the two-fp16-plane split
+    ab = ab3 = None
     if not args.fwd_only and not args.separable and _hip.SPLIT_BF16_CONTRACTION:
         _hip.SPLIT_BF16_CONTRACTION = False
         step()
@@ -717,6 +726,13 @@ def main(argv=None):
         _hip.SPLIT_BF16_CONTRACTION = True
         ab = {'value': args.batch * world * attr_steps / dt_ab, 'ms_per_step': dt_ab / attr_steps * 1e3, 'steps': attr_steps,
               'note': 'same run, vgtk._hip.SPLIT_BF16_CONTRACTION = False: the forward contraction on the fp32 matrix pipe (csrc/gemm_dma_f32.hip)'}
+        if _hip.SPLIT_PLANES == 2:
+            _hip.SPLIT_PLANES = 3
+            step()
+            dt_ab3 = timed(attr_steps)
+            _hip.SPLIT_PLANES = 2
+            ab3 = {'value': args.batch * world * attr_steps / dt_ab3, 'ms_per_step': dt_ab3 / attr_steps * 1e3, 'steps': attr_steps,
+                   'note': 'same run, vgtk._hip.SPLIT_PLANES = 3: the forward contraction with three bf16 planes per operand (six products, exact splits: round 3)'}
 
     if rank == 0:
         kern, shapes = summarize_kernels(records)
@@ -737,9 +753,12 @@ def main(argv=None):
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'rccl_ranks': world if backend == 'nccl' and world > 1 else 0,
-            'dtype_note': 'fp32 tensors, fp32 accumulation everywhere; the forward contraction forms its fp32 products on the bf16 '
-                          'matrix cores from exact 3 x bf16 splits of both operands (as accurate as the fp32 MFMA: tests compare '
-                          'both with fp64; vgtk._hip.SPLIT_BF16_CONTRACTION = False selects the fp32-MFMA kernel)',
+            'dtype_note': 'fp32 tensors, fp32 accumulation everywhere; the forward contraction forms its fp32 products on the fp16 matrix '
+                          'cores from two-plane splits x = h + l of both operands after a power-of-two scale per operand row (representation '
+                          'error <= 2^-23 per element; three exact partial products, fp32 accumulate).  Measured against fp64 it is MORE accurate '
+                          'than the fp32-MFMA kernel on the same operands (rms 0.6 x at K = 3072; both are dominated by the fp32 accumulation): '
+                          'tests/test_gpu_split_planes.py.  Same-run A/B legs: bf16x3_contraction (three bf16 planes, exact splits, six products) '
+                          'and fp32_mfma_contraction (vgtk._hip.SPLIT_PLANES = 3 / SPLIT_BF16_CONTRACTION = False)',
             'config': {'workload': f'{args.batch} x {args.points}-pt synthetic ' + ('partial (depth-buffer visible) ' if args.partial else '') + 'laptop clouds per GPU, 3-block '
                                    + ('separable (inter+intra+skip) glb_backbone' if args.separable else 'inter backbone')
                                    + f' 1->64->128->512 (NN=64,K=24,A=60), '
@@ -756,7 +775,7 @@ def main(argv=None):
                                  if k['flops'] > 0 and k['ms'] / total_kernel_ms > 0.05],
             'whole_step': {'algorithmic_flops_per_gpu': step_flops, 'achieved_TFLOPs_per_gpu': step_flops / (dt / args.steps) / 1e12,
                            'frac_of_fp32_mfma_peak': step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                           'note': 'algorithmic fp32 flops over the fp32-MFMA peak; part of them (the forward contraction) run as 3 x bf16 split products on the bf16 pipe',
+                           'note': 'algorithmic fp32 flops over the fp32-MFMA peak; part of them (the forward contraction) run as split products on the fp16 / bf16 pipe',
                            'kernel_time_share_of_step': total_kernel_ms / (dt_attr * 1e3)},
             'kernels': {n: {'ms_per_step': k['ms'] / attr_steps, 'launches_per_step': k['launches'] / attr_steps,
                             'tflops': (k['flops'] / (k['ms'] * 1e-3) / 1e12) if k['flops'] > 0 else None}
@@ -770,6 +789,8 @@ def main(argv=None):
         progress('timed steps done')
         if ab is not None:
             line['fp32_mfma_contraction'] = ab
+        if ab3 is not None:
+            line['bf16x3_contraction'] = ab3
         if world > 1 and backend != 'nccl':
             line['functional_check_only'] = (f'{world} ranks over {backend} on {n_dev} device(s): the N > 1 code path runs, '
                                              f'this is NOT a scaling measurement')

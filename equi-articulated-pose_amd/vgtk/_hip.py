@@ -111,18 +111,89 @@ def _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
 # split operands: fp32 in, fp32 accumulate, products as accurate as fp32's (csrc/gemm_bf16x3.hip).  False: the fp32-MFMA
 # kernels everywhere.
 SPLIT_BF16_CONTRACTION = True
+# Planes per operand on those kernels: 3 = three bf16 planes, six products (exact splits); 2 = two fp16 planes after a
+# power-of-two scale per tensor, three products (include/eap_hip.h, eap_gemm_f16x2_f32: representation error <= 2^-23 per
+# element, bounded against fp64 by the fp32-MFMA kernel's error in tests/test_gpu_split_planes.py).
+SPLIT_PLANES = int(os.environ.get('EAP_SPLIT_PLANES', '2'))      # (the environment switch is for A/B runs)
 
 
-def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, b_blocked=False):
-    """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored."""
+SPLIT_PLANES_SCAN_ROWS = 384     # see _planes2 (tests set it to 0 to reach the two-plane kernel at every shape)
+
+
+def _pieces_ok(t, *dims):
+    return not any(int(d) & 3 for d in dims) and t.data_ptr() % 16 == 0
+
+
+def absmax_rows(t, batch, rows, cols, ld, stride):
+    """Largest magnitude of every row of a [batch][rows][cols] view (row pitch ld, item stride) -> int32 [batch, rows] holding
+    float bit patterns, or None when the view is not made of whole, aligned 16-byte pieces."""
+    if not _pieces_ok(t, cols, ld, stride):
+        return None
+    out = torch.empty(batch, rows, dtype=torch.int32, device=t.device)
+    call('eap_absmax_rows_f32', t, _ptr(t), batch, rows, cols, _I64(ld), _I64(stride), _ptr(out))
+    return out
+
+
+def absmax_colgroups(t, batch, rows, cols, ld, stride, grp):
+    """Largest magnitude over the rows and over each group of grp consecutive columns -> int32 [batch, cols // grp], or None."""
+    if not _pieces_ok(t, cols, ld, stride, grp) or cols % grp:
+        return None
+    out = torch.empty(batch, cols // grp, dtype=torch.int32, device=t.device)
+    call('eap_absmax_colgroups_f32', t, _ptr(t), batch, rows, cols, _I64(ld), _I64(stride), grp, _ptr(out))
+    return out
+
+
+def so3_grouped_bound(feats, idx):
+    """A bound per point on the inter conv's grouped tensor, from the features' per-point maxima (include/eap_hip.h,
+    eap_so3_grouped_bound_f32): feats [b,c,n,na], idx int32 [b,p,nn] -> int32 [b, p] (float bit patterns), or None."""
+    b, c, n, na = feats.shape
+    pm = absmax_colgroups(feats, b, c, n * na, n * na, c * n * na, na) if na % 4 == 0 else None
+    if pm is None:
+        return None
+    out = torch.empty(b, idx.shape[1], dtype=torch.int32, device=feats.device)
+    call('eap_so3_grouped_bound_f32', feats, b, idx.shape[1], idx.shape[2], n, _ptr(pm), _ptr(idx), _ptr(out))
+    return out
+
+
+def _planes2(transB, M, N, K, A, lda, batch, B, ldb, strideB, b_bound):
+    """The magnitude words of eap_gemm_f16x2_f32 -> (abs_a, abs_b, grp_b, mult_b), or None: take the three-plane kernel.
+    b_bound = (words [batch, N // grp], grp, factor) when the caller knows a bound on B's columns."""
+    if SPLIT_PLANES != 2:
+        return None
+    if b_bound is None and M < SPLIT_PLANES_SCAN_ROWS:
+        # without a bound the kernel needs a pass over B first: 4 bytes per element at ~5 TB/s against the M / 2 fp32-equivalent
+        # products per element it saves at ~245 TFLOP/s -- pays from M = 384 rows upwards
+        return None
+    abs_a = absmax_rows(A, 1, M, K, lda, 0)
+    if abs_a is None:
+        return None
+    if b_bound is not None:
+        return abs_a, b_bound[0], int(b_bound[1]), float(b_bound[2])
+    abs_b = absmax_rows(B, batch, N, K, ldb, strideB) if transB else absmax_colgroups(B, batch, K, N, ldb, strideB, 4)
+    return None if abs_b is None else (abs_a, abs_b, 1 if transB else 4, 1.0)
+
+
+def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, b_blocked=False, b_bound=None):
+    """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored.  b_bound = (device word, factor): a
+    known bound on the columns of B, see _planes2 (saves the two-plane kernel its pass over B)."""
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)}
     if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and (strideA == 0 or batch == 1) and \
             lib.eap_gemm_bf16x3_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB)):
+        two = _planes2(1, M, N, K, A, lda, batch, B, ldb, strideB, b_bound)
+        if two is not None:
+            call('eap_gemm_f16x2_f32', C, 1, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
+                 batch, _ptr(two[0]), _ptr(two[1]), two[2], _F32(two[3]), None, None, _F32(0.0), None, _I64(0), tag=tag)
+            return
         call('eap_gemm_bf16x3_f32', C, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
              batch, tag=tag)
         return
     if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and not transB and (strideA == 0 or batch == 1) and \
             lib.eap_gemm_bf16x3_nn_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB)):
+        two = _planes2(0, M, N, K, A, lda, batch, B, ldb, strideB, b_bound)
+        if two is not None:
+            call('eap_gemm_f16x2_f32', C, 0, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
+                 batch, _ptr(two[0]), _ptr(two[1]), two[2], _F32(two[3]), None, None, _F32(0.0), None, _I64(0), tag=tag)
+            return
         call('eap_gemm_bf16x3_nn_f32', C, M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC),
              batch, tag=tag)
         return
@@ -134,7 +205,7 @@ def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, stri
          _ptr(B), _I64((N if transB else K) if b_blocked else ldb), _I64(strideB), _ptr(C), _I64(ldc), _I64(strideC), batch, tag=tag)
 
 
-def gemm_epilogue(transB, M, N, K, A, lda, B, ldb, strideB, C, ldc, strideC, batch, scale, shift, slope, residual=None):
+def gemm_epilogue(transB, M, N, K, A, lda, B, ldb, strideB, C, ldc, strideC, batch, scale, shift, slope, residual=None, b_bound=None):
     """C_z = leaky_relu(scale[row] * (A B_z) + shift[row], slope) (+ residual_z, laid out like C) on the split kernel
     (eap_gemm_bf16x3_ep_f32): an inference-mode BatchNorm + activation folded into the contraction.  -> False when the
     operands do not qualify for that kernel (nothing launched: the caller runs product and epilogue separately)."""
@@ -145,6 +216,12 @@ def gemm_epilogue(transB, M, N, K, A, lda, B, ldb, strideB, C, ldc, strideC, bat
     if not ok:
         return False
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm_epilogue', 0, int(transB), M, N, K, batch)}
+    two = _planes2(int(transB), M, N, K, A, lda, batch, B, ldb, strideB, b_bound)
+    if two is not None:
+        call('eap_gemm_f16x2_f32', C, int(transB), M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc),
+             _I64(strideC), batch, _ptr(two[0]), _ptr(two[1]), two[2], _F32(two[3]), _ptr(scale), _ptr(shift), _F32(slope), _ptr(residual),
+             _I64(strideC), tag=tag)
+        return True
     call('eap_gemm_bf16x3_ep_f32', C, int(transB), M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB), _ptr(C), _I64(ldc),
          _I64(strideC), batch, _ptr(scale), _ptr(shift), _F32(slope), _ptr(residual), _I64(strideC), tag=tag)
     return True
@@ -467,6 +544,14 @@ def so3_intra_conv(feats, W, intra_idx32):
     o, nt = W.shape[0], intra_idx32.shape[1]
     out = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
     split = SPLIT_BF16_CONTRACTION and W.data_ptr() % 16 == 0 and lib.eap_so3_intra_conv_bf16x3_f32_supported(b, o, c, p, na, nt)
+    tag = {'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)}
+    if split and SPLIT_PLANES == 2 and feats.data_ptr() % 16 == 0:
+        abs_w = absmax_rows(W, 1, o, c * nt, c * nt, 0)
+        abs_f = absmax_colgroups(feats, b, c, p * na, p * na, c * p * na, na) if na % 4 == 0 else None
+        if abs_w is not None and abs_f is not None:
+            call('eap_so3_intra_conv_f16x2_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats), _ptr(intra_idx32), _ptr(out), _ptr(abs_w),
+                 _ptr(abs_f), tag=tag)
+            return out
     call('eap_so3_intra_conv_bf16x3_f32' if split else 'eap_so3_intra_conv_f32', out, b, o, c, p, na, nt, _ptr(W), _ptr(feats),
-         _ptr(intra_idx32), _ptr(out), tag={'flops': 2.0 * b * o * c * nt * p * na, 'shape': ('intra_conv', b, o, c, p, na, nt)})
+         _ptr(intra_idx32), _ptr(out), tag=tag)
     return out

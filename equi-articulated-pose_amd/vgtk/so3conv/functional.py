@@ -527,23 +527,34 @@ class FoldedEpilogue:
         self.inference = not torch.is_grad_enabled()      # made under torch.no_grad(): the only place it may be applied
 
 
-def _contract_into(W, x, y, layout, epilogue=None, b0=0):
+def _contract_into(W, x, y, layout, epilogue=None, b0=0, x_bound=None):
     """y[b,o,pa] = W . x for the intermediate in one of its three layouts (epilogue: see FoldedEpilogue; b0 = first
-    cloud of this slab, for the residual)."""
+    cloud of this slab, for the residual; x_bound = (words [b, p], anchors per point, factor) bounding x per point, see
+    _grouped_bound)."""
     b, c, ks, p, na = x.shape
     o = W.shape[0]
     if epilogue is not None and layout == 2:
         res = None if epilogue.residual is None else epilogue.residual[b0:b0 + b]
         if _hip.gemm_epilogue(1, o, p * na, c * ks, W, c * ks, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b,
-                              epilogue.scale, epilogue.shift, epilogue.slope, res):
+                              epilogue.scale, epilogue.shift, epilogue.slope, res, b_bound=x_bound):
             epilogue.applied = True
             return
         if b0 > 0 and epilogue.applied:
             raise RuntimeError('folded epilogue: the slabs of one contraction took different kernels')
     if layout == 2:                              # Y = W . (X^T)^T, both operands k-contiguous (csrc/gemm_dma_f32.hip)
-        _hip.gemm(0, 1, o, p * na, c * ks, W, c * ks, 0, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b)
+        _hip.gemm(0, 1, o, p * na, c * ks, W, c * ks, 0, x, c * ks, c * ks * p * na, y, p * na, o * p * na, b, b_bound=x_bound)
     else:
         _hip.gemm(0, 0, o, p * na, c * ks, W, c * ks, 0, x, p * na, c * ks * p * na, y, p * na, o * p * na, b, b_blocked=layout == 1)
+
+
+def _grouped_bound(feats, idx):
+    """A bound on the grouped tensor per point without a pass over it: X[c,k,p,a] = sum over the neighbours of a feature times
+    an interpolation weight in [0, 1] (so3conv/functional.py:L1112-1261), so |X[.,.,p,.]| <= sum_n max_{c,a} |feats[c,idx[p,n],a]|
+    -- the two-plane contraction takes the scales of its operand's columns from it (vgtk/_hip.py SPLIT_PLANES).
+    -> int32 [b, p] (float bit patterns) or None."""
+    if not (_hip.SPLIT_BF16_CONTRACTION and _hip.SPLIT_PLANES == 2):
+        return None
+    return _hip.so3_grouped_bound(feats, idx)
 
 
 BACKWARD_LOG = None      # a list while someone wants to know the backward regime of every inter conv (bench.py, tests)
@@ -578,9 +589,10 @@ class _InterConv(torch.autograd.Function):
         ctx.head = _ListHead(idx, n, nonident, gx, prefill=not keep) if (lists_ok and needs_grad) else None
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
         coset = _coset_tables(mult, ident) if (mult is not None and nonident is not None and layout == 2 and COSET_OPERAND) else None
+        x_bound = _grouped_bound(feats, idx) if layout == 2 else None          # [b, p] words
         if keep:
             x = _hip.so3_inter_group_fwd(feats, idx, gx, rk, mult, sigma, nonident, blocked=layout, coset=coset)   # [b,c,k,p,a] (nominal shape)
-            _contract_into(W, x, y.view(b, o, p * na), layout)
+            _contract_into(W, x, y.view(b, o, p * na), layout, x_bound=None if x_bound is None else (x_bound, na, 1.0))
         else:
             x = None
             step = max(1, X_CHUNK_CLOUDS)
@@ -593,7 +605,8 @@ class _InterConv(torch.autograd.Function):
                 b1 = min(b, b0 + step)
                 xs = _hip.so3_inter_group_fwd(feats[b0:b1], idx[b0:b1], gx[b0:b1], rk, mult, sigma,
                                               None if nonident is None else nonident[b0:b1], blocked=layout, coset=coset, store_order=tp)
-                _contract_into(Wc, xs, y[b0:b1].view(b1 - b0, o, p * na), layout, epilogue, b0)
+                _contract_into(Wc, xs, y[b0:b1].view(b1 - b0, o, p * na), layout, epilogue, b0,
+                               x_bound=None if x_bound is None else (x_bound[b0:b1], na, 1.0))
                 del xs
         ctx.layout = layout
         ctx.kept_x = x is not None

@@ -390,6 +390,40 @@ int eap_gemm_bf16x3_reduce_f32(int M, int N, int K, const float *A, int64_t lda,
 int eap_so3_intra_conv_bf16x3_f32_supported(int b, int o, int c, int p, int na, int nt);
 int eap_so3_intra_conv_bf16x3_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
                                   const int32_t *intra_idx, float *out, eap_stream_t stream);
+/* The same contractions (torch.matmul in BasicSO3Conv.forward, vgtk/vgtk/so3conv/modules.py:L48-55; the 1 x 1 convs; the intra
+ * conv, so3conv/functional.py:L2553-2602) with TWO fp16 planes per operand instead of three bf16 planes: three matrix
+ * instructions per k-tile instead of six (round 4).  Every ROW of A and every COLUMN of B_z is first multiplied by a power of
+ * two that puts its largest magnitude (or a bound on it) at 2^14..2^15 -- the scales come off again per output row and column
+ * in the epilogue --, then split x = h + l, h = fp16(x), l = fp16(x - h), round to nearest: |x - h - l| <= 2^-23 |x| (rms
+ * 2^-25 |x|) for elements down to 2^-17 of that magnitude, <= 2^-40 of it below; the products h h' + h l' + l h' are exact in
+ * the fp32 accumulator, l l' (<= 2^-22 |x x'|) is dropped.  tests/test_gpu_split_planes.py bounds the error against fp64 by that
+ * of the fp32-MFMA kernel on the same operands, per output element.  The magnitudes are device words holding the bit pattern
+ * of a non-negative float (unsigned maxima: order-independent), so nothing waits for the host:
+ *   eap_absmax_rows_f32        x [batch][rows][cols] (row pitch ld, item stride `stride`; cols / ld / stride multiples of 4, 16-byte
+ *                              aligned) -> out [batch][rows]: largest magnitude of every row
+ *   eap_absmax_colgroups_f32   the same tensor -> out [batch][cols / grp]: largest magnitude over the rows and over each group of grp
+ *                              consecutive columns (grp a multiple of 4 dividing cols)
+ *   eap_so3_grouped_bound_f32  a bound on the inter conv's grouped tensor per point, without a pass over it: X[c,k,p,a] is a sum over
+ *                              the nn neighbours of a feature times a weight in [0, 1] (so3conv/functional.py:L1112-1261), so
+ *                              |X[.,.,p,.]| <= sum_n point_max[idx[p,n]] with point_max [b][n_sup] = eap_absmax_colgroups_f32 of
+ *                              feats [b][c][n_sup*na] in groups of na; idx int32 [b,p,nn] (entries >= n_sup: no neighbour) -> out [b][p]
+ *   eap_gemm_f16x2_f32         C_z = A B_z, trans_b = 1: B_z [N,K] k-contiguous (operands as eap_gemm_bf16x3_f32_supported says), 0: B_z
+ *                              [K,N] row-major (eap_gemm_bf16x3_nn_f32_supported); abs_a [M] = eap_absmax_rows_f32 of A; abs_b
+ *                              [batch][N / grp_b]: float(word) * mult_b >= the largest magnitude in those grp_b columns of C's operand
+ *                              B_z; scale / shift / slope / residual: the row epilogue of eap_gemm_bf16x3_ep_f32, or scale = shift = NULL
+ *   eap_so3_intra_conv_f16x2_f32   eap_so3_intra_conv_bf16x3_f32 likewise: abs_w [o] of W's rows, abs_f [b][p] = per-point maxima of feats
+ *                              (eap_absmax_colgroups_f32 in groups of na: a column gathers 12 anchors of its point) */
+int eap_absmax_rows_f32(const float *x, int batch, int rows, int cols, int64_t ld, int64_t stride, int32_t *out_bits, eap_stream_t stream);
+int eap_absmax_colgroups_f32(const float *x, int batch, int rows, int cols, int64_t ld, int64_t stride, int grp, int32_t *out_bits,
+                             eap_stream_t stream);
+int eap_so3_grouped_bound_f32(int b, int p, int nn, int n_sup, const int32_t *point_max_bits, const int32_t *idx, int32_t *out_bits,
+                              eap_stream_t stream);
+int eap_gemm_f16x2_f32(int trans_b, int M, int N, int K, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t strideB,
+                       float *C, int64_t ldc, int64_t strideC, int batch, const int32_t *abs_a, const int32_t *abs_b, int grp_b, float mult_b,
+                       const float *scale, const float *shift, float slope, const float *residual, int64_t strideRes,
+                       eap_stream_t stream);
+int eap_so3_intra_conv_f16x2_f32(int b, int o, int c, int p, int na, int nt, const float *W, const float *feats,
+                                 const int32_t *intra_idx, float *out, const int32_t *abs_w, const int32_t *abs_f, eap_stream_t stream);
 
 
 /* The same GEMMs with both operands fed by global -> LDS DMA through a three-stage ring (csrc/gemm_dma_f32.hip);
