@@ -69,6 +69,14 @@ int group_lists_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, i
 bool group_lists2_preferred(int c, int na, int ks, int layout);
 #ifdef EAP_EXPERIMENTS   // tools/experiments/kernels/so3_inter_lists3.hip (`make EXPERIMENTS=1`): the same on the bf16 matrix cores (3 x bf16 split operands)
 bool group_lists3_preferred(int c, int na, int ks, int layout);
+// tools/experiments/kernels/so3_inter_lists_h2.hip: the same on the fp16 matrix cores (two fp16 planes per operand), eap_so3_group_lists_tiles(4)
+bool group_listsh_preferred(int c, int na, int ks, int layout);
+int group_listsh_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
+                     const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
+                     hipStream_t s);
+int group_listsh_inv(int b, int o, int p, int nn, int na, int gy_pitch, int ks, int rcap, float sigma, const float *gy,
+                     const int32_t *rows, const int32_t *off, const int32_t *cnt, const int32_t *ent_p,
+                     const float *ent_gx, const float *rk, float *z, hipStream_t s);
 int group_lists3_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,
                      const int32_t *idx, const float *gx, const float *rk, const int32_t *nonident, int layout, float *out,
                      hipStream_t s);

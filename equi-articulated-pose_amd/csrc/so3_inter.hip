@@ -353,6 +353,8 @@ static int group_fwd_dispatch(int blocked, int b, int c, int p, int n, int nn, i
         if (lists && (!mult || nonident)) {
             int e =
 #ifdef EAP_EXPERIMENTS
+                    eap::group_listsh_preferred(c, na, ks, blocked)
+                        ? eap::group_listsh_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream)) :
                     eap::group_lists3_preferred(c, na, ks, blocked)
                         ? eap::group_lists3_fwd(b, c, p, n, nn, na, ks, sigma, feats, idx, gx, rk, mult ? nonident : nullptr, blocked, out, eap::S(stream)) :
 #endif

@@ -600,6 +600,8 @@ extern "C" int eap_so3_inter_group_inv_pitch_f32(int b, int o, int p, int nn, in
     if (b <= 0 || o <= 0 || rcap <= 0 || na <= 0 || ks <= 0) return 0;
     if (!eap::group_lists_supported(na, ks)) return eap::bad_arg("so3_inter_group_inv_pitch: unsupported anchor / kernel-point count");
 #ifdef EAP_EXPERIMENTS
+    if (eap::group_listsh_preferred(o, na, ks, 0))
+        return eap::group_listsh_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
     if (eap::group_lists3_preferred(o, na, ks, 0))
         return eap::group_lists3_inv(b, o, p, nn, na, gy_pitch, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, eap::S(stream));
 #endif
@@ -690,6 +692,8 @@ static int group_inv(int b, int o, int p, int nn, int na, int ks, int rcap, floa
     // no anchor permutation: the two-workgroups-per-CU kernel of csrc/so3_inter_lists.hip
     if (!multinv && eap::group_lists_supported(na, ks)) {
 #ifdef EAP_EXPERIMENTS
+        if (eap::group_listsh_preferred(o, na, ks, 0))
+            return eap::group_listsh_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
         if (eap::group_lists3_preferred(o, na, ks, 0))
             return eap::group_lists3_inv(b, o, p, nn, na, na, ks, rcap, sigma, gy, rows, off, cnt, ent_p, ent_gx, rk, z, s);
 #endif

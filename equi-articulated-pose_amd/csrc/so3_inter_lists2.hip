@@ -533,7 +533,7 @@ static int g_tiles = 2;       // eap_so3_group_lists_tiles
 // slower on real neighbour lists, the grouping is bound by the L2 -> LDS gather, not by the matrix pipe); 0 = query.  Returns the value in force.  Process-wide, not thread-safe (set it before launching).
 extern "C" int eap_so3_group_lists_tiles(int tiles) {
 #ifdef EAP_EXPERIMENTS
-    if (tiles >= 1 && tiles <= 3) g_tiles = tiles;
+    if (tiles >= 1 && tiles <= 4) g_tiles = tiles;
 #else
     if (tiles >= 1 && tiles <= 2) g_tiles = tiles;
 #endif
@@ -579,6 +579,8 @@ bool group_lists2_preferred(int c, int na, int ks, int layout) {
 // mode 3 (eap_so3_group_lists_tiles, `make EXPERIMENTS=1` builds only): the 3 x bf16 split kernel of
 // tools/experiments/kernels/so3_inter_lists3.hip wherever the two-tile kernel would run
 bool group_lists3_preferred(int c, int na, int ks, int layout) { return g_tiles == 3 && group_lists2_preferred(c, na, ks, layout); }
+// mode 4: the two-fp16-plane kernel of tools/experiments/kernels/so3_inter_lists_h2.hip
+bool group_listsh_preferred(int c, int na, int ks, int layout) { return g_tiles == 4 && group_lists2_preferred(c, na, ks, layout); }
 #endif
 
 int group_lists2_fwd(int b, int c, int p, int n, int nn, int na, int ks, float sigma, const float *feats,

@@ -37,9 +37,18 @@ for layer in (2, 1):
     fl = 2.0 * B * o * KS * P * NN * NA
     cn = cnt.flatten().float()
     print(f'layer {layer} O={o} rcap={rcap}: list lengths mean {cn[cn > 0].mean().item():.0f} max {cn.max().item():.0f} min {cn[cn > 0].min().item():.0f}', flush=True)
-    for tiles, xmap in ((1, 1), (2, 1), (3, 1)):   # so3_inter_lists.hip (one channel tile per wave) / so3_inter_lists2.hip (two), XCD owns (slice, cloud) / (slice, cloud, anchor group)
-        _hip.lib.eap_so3_group_lists_tiles(tiles)
+    zref = None
+    for tiles, xmap in ((2, 1), (3, 1), (4, 1)):   # 3, 4: `make EXPERIMENTS=1` builds (3 x bf16 planes / 2 x fp16 planes on the 16-bit matrix cores)
+        if _hip.lib.eap_so3_group_lists_tiles(tiles) != tiles:
+            continue
         _hip.lib.eap_so3_group_lists_xcd_map(1, xmap)
+        run(variants['real'])
+        zd = z.double()
+        if zref is None:
+            zref = zd.clone()
+        else:
+            print(f'   tiles {tiles}: max |z - z(tiles 2)| / max |z| = {(zd - zref).abs().max().item() / zref.abs().max().item():.3e}   rms {((zd - zref).pow(2).mean().sqrt() / zref.pow(2).mean().sqrt()).item():.3e}', flush=True)
+        del zd
         for ep in variants.values():
             run(ep)
         torch.cuda.synchronize()
