@@ -557,6 +557,21 @@ __global__ __launch_bounds__(256) void grouped_bound_kernel(long long total, int
 
 int g_presplit = 1;      // eap_gemm_bf16x3_presplit(0): split the weights in the k-loop like the other operand (A/B runs, tests)
 
+// the stream-ordered pool keeps what it has been given: with the default release threshold (0) the scratch of every call goes
+// back to the driver at the next synchronisation point and is mapped again by the next call
+void keep_pool_memory() {
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+}
+
 template <int BMODE, int PL = 3>
 int launch_split(Args &g, int batch, hipStream_t stream, const char *who) {
     // pays from a few thousand k-tiles per workgroup column upwards (+2.7 % on the deepest layer's contraction; on the 1-2 ms
@@ -566,6 +581,7 @@ int launch_split(Args &g, int batch, hipStream_t stream, const char *who) {
     void *scratch = nullptr;
     if (pre) {
         const long long pieces = (long long)g.M * (g.K / 4);
+        keep_pool_memory();
         if (hipMallocAsync(&scratch, (size_t)pieces * (PL == 3 ? 32 : 16), stream) != hipSuccess) {      // no stream-ordered pool on this device / out of
             (void)hipGetLastError();                                                      // memory: split in the k-loop instead
             scratch = nullptr;
