@@ -253,3 +253,16 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--check-launch'], env=env,
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and 'refusing' in bad.stderr
+
+
+def test_bench_rooflines_price_the_split_contractions_on_their_pipe():
+    """bench.roofline_object: the two-plane contraction executes 3 fp16 MFMA flops per algorithmic flop, the three-plane one 6
+    bf16 flops, both against the 2.5 PFLOP/s dense 16-bit peak; every other kernel against the fp32-MFMA peak (no GPU needed)."""
+    import bench
+    k = {'flops': 2.0e12, 'ms': 10.0, 'launches': 2, 'entries': {'x'}}
+    two = bench.roofline_object('gemm_f16x2_kernel<4, 4>', k, False)
+    three = bench.roofline_object('gemm_bf16x3_kernel<4, 4>', k, False)
+    plain = bench.roofline_object('so3_group_lists2_kernel<true, 0>', k, False)
+    assert abs(two['achieved'] - 600.0) < 1e-6 and abs(two['frac'] - 600.0 / bench.PEAK_BF16_MFMA_TFLOPS) < 1e-12 and 'fp16' in two['pipe']
+    assert abs(three['achieved'] - 1200.0) < 1e-6 and abs(three['fp32_equivalent_TFLOPs'] - 200.0) < 1e-9
+    assert abs(plain['achieved'] - 200.0) < 1e-9 and plain['peak'] == bench.PEAK_F32_MFMA_TFLOPS and plain['avg_launch_ms'] == 5.0
