@@ -1,0 +1,648 @@
+// csrc/so3_dense.hip -- the fused inter conv RE-ASSOCIATED OVER ITS REFERENCED SUPPORT ROWS as a dense product on the
+// fp16 matrix cores (round 5).
+//
+//   reference (vgtk/vgtk/so3conv/functional.py:L1112-1261 + so3conv/modules.py:L48-55), identity poses:
+//       Y[o,p,a] = sum_{c,k} W[o,c,k] sum_n F[c,idx[p,n],a] w(p,a,k,n),   w = relu(1 - |x_idx[p,n] - x_p - A_a kappa_k|^2 / sigma)
+//
+// The reference's ball query keeps the FIRST nsample hits in index order (grouping_cuda_kernel.cu:L68-113); with the large
+// radii of the deep layers a cloud's lists name only R ~ 76..280 of its support rows, and every point's nsample = 64
+// neighbours are 64 of those R.  Written over the referenced rows r = 0..R-1 the operator is a DENSE matrix with a mask,
+//       Wd[p,(k,r),a] = m[p,r] relu(1 - |x_r - x_p - A_a kappa_k|^2 / sigma),      m[p,r] = 1 iff row r is in p's list,
+// and both directions are plain GEMMs per (cloud, anchor) whose second operand is GENERATED IN REGISTERS:
+//       backward  Z[o,(k,r)]  = sum_p      dY[o,p]     Wd[p,(k,r)]        M = O, N = K R, contraction over the P points
+//       forward   Y[o,p]      = sum_(k,r)  G[o,(k,r)]  Wd[p,(k,r)]        G[o,(k,r),a] = sum_c W[o,c,k] F[c,r,a]  (a small GEMM)
+// (dF, dW follow from Z exactly as from the inverse-list kernel's, vgtk/so3conv/functional.py _InterConv.backward).  That is
+// 2.1 x the flops of the sparse form at R = 136 -- on a pipe that is 16 x faster than the fp32 MFMA the sparse kernels
+// (csrc/so3_inter_lists2.hip) are tied to, with every dY row fetched ~13 x instead of 64 x.
+//
+// Arithmetic: fp32-accurate products from TWO fp16 PLANES per operand, exactly as csrc/gemm_bf16x3.hip (PL = 2): the stored
+// operand is scaled per row by a power of two and split h = fp16(x), l = fp16(x - h) once (dense_split_kernel); the
+// generated operand w in [0, 1] is split in registers; a product is h h' + h l' + l h' -- three
+// v_mfma_f32_32x32x16_f16 -- with fp32 accumulation, |error| <= 2^-21 sum |a||b| + 2^-25 sum |a|.
+//
+// The generated operand.  With x~ = x - centre (the cloud's centroid) and u = x~_r - A_a kappa_k, one float4 table per side
+// (kr[a][(k,r)] and pt[p], both evaluated in float64 and rounded once), two forms (template FORM, eap_so3_dense_form):
+//   1 (default)  w = clamp(1 - |u - x~_p|^2 / sigma): 3 subtractions, 3 multiply-adds for the square, one fma with the [0, 1]
+//                clamp as its output modifier -- the reference's own order of operations up to the association of
+//                x_r - x_p - A_a kappa_k, absolute error ~2e-7 on a weight (what the reference's fp32 evaluation has itself);
+//   0            the square expanded: w = clamp([1 - |u|^2/sigma] + [-|x~_p|^2/sigma] + u . [2 x~_p / sigma]): 1 add + 3 fma, but
+//                partial sums up to ~6.5 at the bench radii -> ~7e-7 absolute (bar on the weights: 2e-6, tests/test_gpu_dense.py).
+// The weights are NOT scaled: l = fp16(w - fp16(w)) is a subnormal for w < 0.12 and then carries an absolute error <= 2^-25,
+// below the evaluation error above.  The mask arrives as one 64-bit word per (32-column tile, k-step element) through the
+// SCALAR cache and is applied by v_cndmask with the word as its lane mask: no per-lane mask traffic at all.
+//
+// Geometry (kc_gemm_kernel): 4 waves, one per SIMD; block tile 256 x 256, wave tile 256 x 64 = 256 accumulator registers;
+// k-step 32 (two MFMA k-blocks).  The stored operand lives in HBM already in FRAGMENT ORDER ([k-block][row tile][plane][lane]
+// 16-byte pieces, written by dense_split_kernel), so a k-step of a block is 32 contiguous KB moved by 32 global->LDS DMA
+// instructions and read back with conflict-free ds_read_b128; the side of the generated operand that runs along k (16 float4
+// per k-block) rides in the same ring; three stages, one barrier per k-step.  Every wave generates the operand of ITS 64
+// columns for all 256 rows: 16 weights per lane and k-block against 48 matrix instructions, ~2.5 vector instructions per
+// matrix instruction, issued in their shadow.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+typedef const __attribute__((address_space(4))) unsigned long long *cu64p;      // constant address space: uniform loads go through the scalar cache
+
+constexpr int KC_BK = 32;                 // contraction elements per k-step (two MFMA k-blocks of 16)
+
+__device__ inline unsigned lds_addr(const void *ptr) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
+}
+// wave-wide global -> LDS DMA (16 / 4 bytes per lane, destination = lds_dst + 16 / 4 * lane), invisible to hipcc's waitcnt
+// bookkeeping on purpose: the k-loop waits with its own counted s_waitcnt before the step's barrier
+__device__ inline void glds16s(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ inline void glds4s(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// the scale 2^(14 - e) of a row whose largest magnitude is v in [2^e, 2^(e+1)); 1 for 0, inf, nan (as csrc/gemm_bf16x3.hip)
+__device__ __forceinline__ float pow2_scale(float v) {
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    const int e = (int)(b >> 23) - 127;
+    if (b == 0u || e == 128) return 1.0f;
+    const int se = max(-120, min(120, 14 - max(e, -126)));
+    return __uint_as_float((unsigned)(se + 127) << 23);
+}
+
+// x (scaled) = h + l + e, h = fp16(x), l = fp16(x - h), both to nearest even; two values -> the packed h word and l word.
+// v_fma_mix{lo,hi}_f16 form fp16(-1 * h + x) in one instruction each, reading h's half straight from the packed word.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &l) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+#ifdef EAP_DENSE_PLAIN_SPLIT
+    const f16x2 hh = __builtin_bit_cast(f16x2, h);
+    const f16x2 ll = __builtin_convertvector((f32x2){x0 - (float)hh.x, x1 - (float)hh.y}, f16x2);
+    l = __builtin_bit_cast(unsigned, ll);
+#else
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// membership of the referenced rows in every point's neighbour list
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_slots_kernel(int n_sup, int rp, int rows_ld, const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ n_rows, int32_t *__restrict__ slot_of) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= min(n_rows[b], rp)) return;
+    const int r = rows[(size_t)b * rows_ld + j];
+    if ((unsigned)r < (unsigned)n_sup) slot_of[(size_t)b * n_sup + r] = j;
+}
+
+// memb[b][p][w] (w < MEMB_WORDS = 16 words per point, whatever rp) bit i = row slot 32 w + i is named by p's list; flags[b] |= 1 when a list names a row twice (the ball
+// query pads short lists with their first hit, grouping_cuda_kernel.cu:L98-107: such clouds stay on the list kernels),
+// |= 2 when a list names a row without a slot (more referenced rows than `rp`)
+constexpr int MEMB_WORDS = 16;           // rp <= 512
+__global__ __launch_bounds__(256) void dense_member_kernel(int p, int n_sup, int nn, int rp, const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ slot_of, unsigned *__restrict__ memb,
+                                                           int32_t *__restrict__ flags) {
+    __shared__ unsigned sw[256][MEMB_WORDS + 1];
+    const int b = blockIdx.y, pt = blockIdx.x * 256 + threadIdx.x;
+    if (pt >= p) return;
+    constexpr int W = MEMB_WORDS;
+    unsigned *w = sw[threadIdx.x];
+    for (int k = 0; k < W; ++k) w[k] = 0u;
+    const int32_t *list = idx + ((size_t)b * p + pt) * nn;
+    int valid = 0, bad = 0;
+    for (int n = 0; n < nn; ++n) {
+        const int i = list[n];
+        if ((unsigned)i >= (unsigned)n_sup) continue;          // shadow entry: a zero feature row
+        const int s = slot_of[(size_t)b * n_sup + i];
+        if (s < 0 || s >= rp) { bad |= 2; continue; }
+        ++valid;
+        w[s >> 5] |= 1u << (s & 31);
+    }
+    int bits = 0;
+    for (int k = 0; k < W; ++k) { bits += __popc(w[k]); memb[((size_t)b * p + pt) * W + k] = w[k]; }
+    if (bits != valid) bad |= 1;
+    if (bad) atomicOr(&flags[b], bad);
+}
+
+// mask[b][tile][step][16]: word 8 t + e, bit l  <->  column n = 32 tile + (l & 31), contraction index kk = 32 step + 16 t + 8 (l >> 5) + e
+//   dir 0 (backward): kk = point, n = (k, r) = (n / rp, n % rp), n < ks rp        dir 1 (forward): kk = (k, r), n = point
+// one wave per (tile, step): 16 ballots
+__global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, int dir, int tiles, int steps,
+                                                         const unsigned *__restrict__ memb, u64 *__restrict__ mask) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long long)tiles * steps) return;
+    const int tile = (int)(wv / steps), step = (int)(wv - (long long)tile * steps);
+    constexpr int W = MEMB_WORDS;
+    const int n = 32 * tile + (lane & 31);
+    const int nkr = ks * rp;
+    u64 mine = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int kk = 32 * step + 16 * (i >> 3) + 8 * (lane >> 5) + (i & 7);
+        const int pt = dir ? n : kk, kr = dir ? kk : n;
+        bool bit = false;
+        if (pt < p && kr < nkr) {
+            const int r = kr % rp;
+            bit = (memb[((size_t)b * p + pt) * W + (r >> 5)] >> (r & 31)) & 1u;
+        }
+        const u64 word = __ballot(bit);
+        if (lane == i) mine = word;
+    }
+    if (lane < 16) mask[(((size_t)b * tiles + tile) * steps + step) * 16 + lane] = mine;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// the two float4 tables of the generated operand (evaluated in float64, rounded once)
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_centre_kernel(int n, const float *__restrict__ xyz, float *__restrict__ centre) {
+    __shared__ double s[3][256];
+    const int b = blockIdx.x;
+    double a[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256)
+        for (int d = 0; d < 3; ++d) a[d] += xyz[((size_t)b * 3 + d) * n + i];
+    for (int d = 0; d < 3; ++d) s[d][threadIdx.x] = a[d];
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (threadIdx.x < h)
+            for (int d = 0; d < 3; ++d) s[d][threadIdx.x] += s[d][threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) centre[b * 4 + threadIdx.x] = (float)(s[threadIdx.x][0] / n);
+    if (threadIdx.x == 3) centre[b * 4 + 3] = 0.f;
+}
+
+// pt[b][i] for the query points: FORM 1 (x~, 0); FORM 0 (2 x~/sigma, -|x~|^2/sigma); entries i >= p: zeros
+__global__ __launch_bounds__(256) void dense_points_kernel(int p, int p_pad, int form, float inv_sigma, const float *__restrict__ q_xyz,
+                                                           const float *__restrict__ centre, f32x4 *__restrict__ pt) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p_pad) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < p) {
+        const double is = (double)inv_sigma;
+        const double x = (double)q_xyz[((size_t)b * 3 + 0) * p + i] - (double)centre[b * 4 + 0];
+        const double y = (double)q_xyz[((size_t)b * 3 + 1) * p + i] - (double)centre[b * 4 + 1];
+        const double z = (double)q_xyz[((size_t)b * 3 + 2) * p + i] - (double)centre[b * 4 + 2];
+        if (form) v = (f32x4){(float)x, (float)y, (float)z, 0.f};
+        else v = (f32x4){(float)(2.0 * is * x), (float)(2.0 * is * y), (float)(2.0 * is * z), (float)(-is * (x * x + y * y + z * z))};
+    }
+    pt[(size_t)b * p_pad + i] = v;
+}
+
+// kr[b][a][k rp + r], u = x~_row(r) - rk[a][k]: FORM 1 (u, 0); FORM 0 (u, 1 - |u|^2/sigma); entries past ks rp and empty
+// slots: far away (FORM 1) / zeros (FORM 0) -- weight 0 either way, and their mask bits are 0
+__global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int ks, int rp, int kd_pad, int rows_ld, int form, float inv_sigma,
+                                                         const float *__restrict__ s_xyz, const float *__restrict__ centre,
+                                                         const int32_t *__restrict__ rows, const float *__restrict__ rk,
+                                                         f32x4 *__restrict__ kr) {
+    const int b = blockIdx.z, a = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kd_pad) return;
+    f32x4 v = form ? (f32x4){1e4f, 1e4f, 1e4f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < ks * rp) {
+        const int k = i / rp, r = i - k * rp;
+        const int row = rows[(size_t)b * rows_ld + r];
+        if ((unsigned)row < (unsigned)n_sup) {
+            const double is = (double)inv_sigma;
+            const float *kp = rk + ((size_t)a * ks + k) * 3;
+            const double x = (double)s_xyz[((size_t)b * 3 + 0) * n_sup + row] - (double)centre[b * 4 + 0] - (double)kp[0];
+            const double y = (double)s_xyz[((size_t)b * 3 + 1) * n_sup + row] - (double)centre[b * 4 + 1] - (double)kp[1];
+            const double z = (double)s_xyz[((size_t)b * 3 + 2) * n_sup + row] - (double)centre[b * 4 + 2] - (double)kp[2];
+            v = (f32x4){(float)x, (float)y, (float)z, form ? 0.f : (float)(1.0 - is * (x * x + y * y + z * z))};
+        }
+    }
+    kr[((size_t)b * na + a) * kd_pad + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// the stored operand: T[b][m][l][na] (dY [b,o,p,a] or G [b,o,(k,r),a]) -> per (cloud, anchor) the row scales and the two
+// fp16 planes in fragment order
+// ------------------------------------------------------------------------------------------------------------------------
+// scale[(b na + a) m + row] = 2^(14 - e) for max_l |T[b][row][l][a]| in [2^e, 2^(e+1)).  One block per (b, row): thread
+// (anchor quad aq, lane group pg) walks the row's float4 pieces aq + nq (pg + G j): consecutive threads, consecutive pieces
+__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, const f32x4 *__restrict__ T, float *__restrict__ scale) {
+    __shared__ unsigned s[256][4];
+    const int nq = na >> 2, G = 256 / nq, b = blockIdx.y, row = blockIdx.x, t = threadIdx.x;
+    const int aq = t % nq, pg = t / nq;
+    unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (pg < G) {
+        const f32x4 *src = T + ((size_t)b * m + row) * (size_t)l * nq;
+        for (int i = pg; i < l; i += G) {
+            const f32x4 q = src[(size_t)i * nq + aq];
+            v0 = max(v0, __float_as_uint(q.x) & 0x7fffffffu);
+            v1 = max(v1, __float_as_uint(q.y) & 0x7fffffffu);
+            v2 = max(v2, __float_as_uint(q.z) & 0x7fffffffu);
+            v3 = max(v3, __float_as_uint(q.w) & 0x7fffffffu);
+        }
+    }
+    s[t][0] = v0; s[t][1] = v1; s[t][2] = v2; s[t][3] = v3;
+    __syncthreads();
+    if (t < na) {
+        unsigned v = 0;
+        for (int g = 0; g < G; ++g) v = max(v, s[g * nq + (t >> 2)][t & 3]);
+        scale[((size_t)b * na + t) * m + row] = pow2_scale(__uint_as_float(v));
+    }
+}
+
+// planes[z = b na + a][k-block kb][row tile mt][plane][lane] (16 bytes): lane (i = lane & 31, kg = lane >> 5) holds the 8
+// contraction elements 16 kb + 8 kg .. + 7 of row 32 mt + i -- what a lane of v_mfma_f32_32x32x16_f16 takes as its A operand.
+// One wave per (b, mt, kb); a lane reads its row's 8 x 16-byte pieces per anchor quad (240-byte stride: the lines are
+// shared with the wave's next iterations) and writes whole 1 KB runs.
+__global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, const f32x4 *__restrict__ T,
+                                                          const float *__restrict__ scale, u32x4 *__restrict__ planes) {
+    const int lane = threadIdx.x & 63, b = blockIdx.z, mt = blockIdx.y;
+    const int kb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (kb >= kb_total) return;
+    const int nq = na >> 2, row = 32 * mt + (lane & 31), l0 = 16 * kb + 8 * (lane >> 5);
+    const int MT = m >> 5;
+    const f32x4 *src = T + ((size_t)b * m + row) * (size_t)l * nq;
+    for (int aq = 0; aq < nq; ++aq) {
+        f32x4 q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = (l0 + e < l) ? src[(size_t)(l0 + e) * nq + aq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = 4 * aq + j;
+            const float sc = scale[((size_t)b * na + a) * m + row];
+            unsigned h[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(q[2 * e][j] * sc, q[2 * e + 1][j] * sc, h[e], lo[e]);
+            u32x4 *dst = planes + ((((size_t)b * na + a) * kb_total + kb) * MT + mt) * 128 + lane;
+            dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
+            dst[64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+}
+
+// Yt[b][a][o][p] -> Y[b][o][p][a]: block (p chunk of 64, o, b) through a [na][65] LDS tile
+__global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int p, int na, const float *__restrict__ yt, float *__restrict__ y) {
+    extern __shared__ float tile[];
+    const int b = blockIdx.z, o = blockIdx.y, p0 = blockIdx.x * 64, t = threadIdx.x;
+    const int np = min(64, p - p0);
+    for (int i = t; i < na * 64; i += 256) {
+        const int a = i >> 6, pp = i & 63;
+        if (pp < np) tile[a * 65 + pp] = yt[(((size_t)b * na + a) * o_total + o) * p + p0 + pp];
+    }
+    __syncthreads();
+    float *dst = y + (((size_t)b * o_total + o) * p + p0) * na;
+    for (int i = t; i < np * na; i += 256) {
+        const int pp = i / na, a = i - pp * na;
+        dst[i] = tile[a * 65 + pp];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// the product
+// ------------------------------------------------------------------------------------------------------------------------
+struct KcArgs {
+    int MT, N, KS, na, zcount;            // row tiles of the stored operand, columns, k-steps, anchors per cloud, clouds x anchors
+    int tiles_m, blocks_n, mask_tiles;    // row blocks (MT / MI), column blocks (of 4 wave tiles), 32-column tiles in the mask table
+    const u32x4 *A;                       // planes [z][2 KS][MT][2][64]
+    const float *scale;                   // [z][32 MT]
+    const f32x4 *strT; long long strB, strA;     // k-side table: element kk of (cloud, anchor) at strT[b strB + a strA + kk]
+    const f32x4 *colT; long long colB, colA;     // column-side table
+    const u64 *mask;                      // [b][mask_tiles][KS][16]
+    float neg_inv_sigma;                  // FORM 1
+    float *C; long long cB, cA, ldm; int rp; long long kstride;     // element (row, n) of (b, a) at C[b cB + a cA + row ldm + (n / rp) kstride + n % rp]
+};
+
+template <int MI, int FORM>
+__global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
+    constexpr unsigned SUB_A = MI * 2048u;                 // bytes of the stored operand per k-block (16 k) of a block
+    constexpr unsigned STR_OFF = 2 * SUB_A;                // the k-side table's slice: 2 x 256 bytes (+ 2 x 256 of duplicate landing space)
+    constexpr unsigned STAGE = 2 * SUB_A + 1024u;
+    constexpr int PIECES = 4 * MI, PPW = PIECES / 4;       // 1 KB DMA pieces per k-step / per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- block -> (z, row block, column block): an XCD owns whole (cloud, anchor) pairs, so the stored operand of a pair is
+    //      fetched into ONE L2 and shared there by the pair's tiles_m x blocks_n workgroups, which run at the same time ----
+    const int per_z = g.tiles_m * g.blocks_n;
+    int id = blockIdx.x, z, local;
+    {
+        const int groups = g.zcount / 8 * 8;
+        if (id < groups * per_z) {
+            const int xcd = id & 7, slot = id >> 3;
+            z = (slot / per_z) * 8 + xcd;
+            local = slot % per_z;
+        } else {
+            const int r = id - groups * per_z;
+            z = groups + r / per_z;
+            local = r % per_z;
+        }
+    }
+    const int bm = local % g.tiles_m, bn = local / g.tiles_m;
+    const int b = z / g.na, a = z - b * g.na;
+
+    const int t = threadIdx.x, lane = t & 63, li = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wt = bn * 4 + wave;                          // this wave's 64 columns
+    const bool active = 64 * wt < g.N;                     // (wave-uniform)
+
+    // ---- per-lane column constants ----
+    const f32x4 *colz = g.colT + b * g.colB + a * g.colA;
+    f32x4 cc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cc[j] = colz[min(64 * wt + 32 * j + li, g.N - 1)];
+    cu64p mrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mrow[j] = (cu64p)(uintptr_t)(g.mask + ((size_t)b * g.mask_tiles + min(2 * wt + j, g.mask_tiles - 1)) * (size_t)g.KS * 16);
+
+    // ---- DMA: piece q of a k-step = k-block q / (2 MI), 1 KB run q % (2 MI) of the block's 2 MI KB; wave w moves pieces w PPW .. ----
+    const unsigned char *Az = reinterpret_cast<const unsigned char *>(g.A) + ((size_t)z * 2 * g.KS * g.MT + (size_t)bm * MI) * 2048u;
+    const size_t kb_bytes = (size_t)g.MT * 2048u;
+    const unsigned char *strz = reinterpret_cast<const unsigned char *>(g.strT + b * g.strB + a * g.strA);
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned voff16 = (unsigned)lane * 16u, voff4 = (unsigned)lane * 4u;
+    auto issue = [&](int step, int stage) __attribute__((always_inline)) {
+        const unsigned dst = lds0 + (unsigned)stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave * PPW + i, sub = q / (2 * MI), r = q % (2 * MI);
+            glds16s(Az + (size_t)(2 * step + sub) * kb_bytes + (size_t)r * 1024u, voff16, dst + (unsigned)sub * SUB_A + (unsigned)r * 1024u);
+        }
+        // the k-side table: 2 x 16 float4; waves 0, 1 land k-block `wave`, waves 2, 3 a duplicate nobody reads (uniform piece counts)
+        glds4s(strz + (size_t)(2 * step + (wave & 1)) * 256u, voff4, dst + STR_OFF + (unsigned)wave * 256u);
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B operand of one k-block: [tile j][plane] 8 halves per lane
+    struct BFrag { u32x4 h[2], l[2]; };
+    auto frag_a = [&](const unsigned char *st, int sub, int plane, u32x4 (&f)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) f[i] = *reinterpret_cast<const u32x4 *>(st + (unsigned)sub * SUB_A + (unsigned)(2 * i + plane) * 1024u + (unsigned)lane * 16u);
+    };
+    const float nis = g.neg_inv_sigma;
+    // weights of tile j, elements e0, e0 + 1 of a k-block (k-side entries sv[e]) -> word e0 / 2 of h, l
+    auto gen2 = [&](const f32x4 (&sv)[8], cu64p mk, int j, int e0, BFrag &f) __attribute__((always_inline)) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x4 s = sv[e0 + e];
+            float x;
+            if constexpr (FORM == 1) {
+                const float tx = cc[j].x - s.x, ty = cc[j].y - s.y, tz = cc[j].z - s.z;
+                const float d2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+                asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(x) : "v"(d2), "v"(nis));
+            } else {
+                const float y = fmaf(cc[j].y, s.y, fmaf(cc[j].x, s.x, cc[j].w + s.w));
+                asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(x) : "v"(cc[j].z), "v"(s.z), "v"(y));
+            }
+            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(v[e]) : "v"(x), "s"(mk[e0 + e]));
+        }
+        unsigned h, l;
+        split2(v[0], v[1], h, l);
+        f.h[j][e0 / 2] = h;
+        f.l[j][e0 / 2] = l;
+    };
+    auto load_sv = [&](const f32x4 *str, f32x4 (&sv)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sv[e] = str[8 * kg + e];
+    };
+    auto mm = [&](const u32x4 &fa, const u32x4 &fb, f32x16 &c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), c, 0, 0, 0);
+    };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    // issue order inside a product: one matrix instruction, then NV vector instructions in its shadow (hipcc on its own puts the
+    // weight evaluation in front of the sixteen matrix instructions; one wave per SIMD has nobody else to fill the pipe)
+#define PIPE(NV)                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2 * MI; ++i_) {                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                       \
+    }
+    // One k-block: acc += A(st, sub) x Bc; meanwhile the weights of the NEXT k-block (k-side entries `nstr`, mask words `nm0`,
+    // `nm1`) are generated into Bn in eight portions and the next k-block's first plane fragments are read into `ah`.
+    auto kblock = [&](const unsigned char *st, int sub, const unsigned char *nst, int nsub, const f32x4 *nstr, cu64p nm0, cu64p nm1,
+                      const BFrag &Bc, BFrag &Bn, u32x4 (&ah)[MI]) __attribute__((always_inline)) {
+        u32x4 al[MI];
+        f32x4 sv[8];
+        frag_a(st, sub, 1, al);
+        load_sv(nstr, sv);
+        SB();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.h[0], acc[i][0]); mm(ah[i], Bc.h[1], acc[i][1]); }
+        gen2(sv, nm0, 0, 0, Bn); gen2(sv, nm0, 0, 2, Bn); gen2(sv, nm0, 0, 4, Bn);
+        PIPE(FORM ? 4 : 3)
+        SB();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.l[0], acc[i][0]); mm(ah[i], Bc.l[1], acc[i][1]); }
+        gen2(sv, nm0, 0, 6, Bn); gen2(sv, nm1, 1, 0, Bn); gen2(sv, nm1, 1, 2, Bn);
+        PIPE(FORM ? 4 : 3)
+        SB();
+        frag_a(nst, nsub, 0, ah);
+        SB();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { mm(al[i], Bc.h[0], acc[i][0]); mm(al[i], Bc.h[1], acc[i][1]); }
+        gen2(sv, nm1, 1, 4, Bn); gen2(sv, nm1, 1, 6, Bn);
+        PIPE(FORM ? 3 : 2)
+        SB();
+    };
+
+    // ---- prologue: stages 0, 1 <- k-steps 0, 1 ----
+    issue(0, 0);
+    if (g.KS > 1) issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // (a wave whose 64 columns lie past N runs the same instruction stream on clamped columns and an all-zero mask: a branch
+    // around the k-blocks would put the 256 accumulators across a control-flow join)
+    BFrag B0, B1;
+    u32x4 ah[MI];
+    {
+        f32x4 sv[8];
+        load_sv(reinterpret_cast<const f32x4 *>(smem + STR_OFF), sv);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) { gen2(sv, mrow[0], 0, e, B0); gen2(sv, mrow[1], 1, e, B0); }
+        frag_a(smem, 0, 0, ah);
+    }
+
+    // ---- k-loop: the barrier that opens step s certifies stage (s + 1) % 3 (its DMA was issued a whole step ago) and frees
+    //      stage (s + 2) % 3 (read during step s - 1) for the DMA of step s + 2 ----
+    unsigned s0 = 0, s1 = STAGE, s2 = 2 * STAGE;
+    for (int s = 0; s < g.KS; ++s) {
+        if (s > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (s + 2 < g.KS) issue(s + 2, (s + 2) % 3);
+        {
+            const f32x4 *str0 = reinterpret_cast<const f32x4 *>(smem + s0 + STR_OFF);
+            const f32x4 *str1 = reinterpret_cast<const f32x4 *>(smem + s1 + STR_OFF);
+            cu64p m0 = mrow[0] + (size_t)s * 16, m1 = mrow[1] + (size_t)s * 16;
+            // k-block 0 of the step; generates k-block 1 (this stage's second table slice, mask words 8..15)
+            kblock(smem + s0, 0, smem + s0, 1, str0 + 16, m0 + 8, m1 + 8, B0, B1, ah);
+            // k-block 1; generates k-block 0 of step s + 1 (the certified next stage; past the end: stale data nobody uses)
+            kblock(smem + s0, 1, smem + s1, 0, str1, m0 + 16, m1 + 16, B1, B0, ah);
+        }
+        { const unsigned r = s0; s0 = s1; s1 = s2; s2 = r; }
+    }
+#undef SB
+#undef PIPE
+
+    // ---- epilogue: the scales come off (two factors), D[i][j] of a 32 x 32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 kg ----
+    __syncthreads();
+    float *isc = reinterpret_cast<float *>(smem);
+    if (t < 32 * MI) isc[t] = 1.0f / g.scale[(size_t)z * (32 * g.MT) + 32 * MI * bm + t];
+    __syncthreads();
+    if (!active) return;
+    float *Cz = g.C + b * g.cB + a * g.cA + (long long)(32 * MI * bm) * g.ldm;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = 64 * wt + 32 * j + li;
+        if (n >= g.N) continue;
+        const int k = n / g.rp;
+        const long long coff = (long long)k * g.kstride + (n - k * g.rp);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                Cz[(long long)row * g.ldm + coff] = acc[i][j][r] * isc[row];
+            }
+    }
+}
+
+template <int MI, int FORM>
+int kc_launch(const KcArgs &g, hipStream_t s) {
+    constexpr size_t shmem = 3 * (2 * (size_t)MI * 2048u + 1024u);
+    static bool set = false;
+    if (!set) {
+        if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_gemm_kernel<MI, FORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)shmem), "so3_dense: shared memory attribute"))
+            return e;
+        set = true;
+    }
+    const long long blocks = (long long)g.zcount * g.tiles_m * g.blocks_n;
+    if (blocks > 0x7fffffffLL) return eap::bad_arg("so3_dense: too many workgroups");
+    hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
+    eap::set_kernel(FORM ? "kc_gemm_kernel<8,1>" : "kc_gemm_kernel<8,0>");
+    return eap::check_launch("so3_dense product");
+}
+
+int g_dense_form = 1;
+
+inline int ceil_to(int v, int q) { return (v + q - 1) / q * q; }
+
+}  // namespace
+
+// 1 (default): the weights from the squared distance; 0: from the expanded square (see the head of this file).  The tables and the
+// product of one layer must be built under the same setting.  -> the previous setting
+extern "C" int eap_so3_dense_form(int form) {
+    const int old = g_dense_form;
+    if (form == 0 || form == 1) g_dense_form = form;
+    return old;
+}
+
+extern "C" int eap_so3_dense_supported(int p, int na, int ks, int rp, int o) {
+    return p > 0 && (p % 32) == 0 && na > 0 && (na % 4) == 0 && na <= 64 && ks > 0 && rp > 0 && (rp % 4) == 0 && rp <= 32 * MEMB_WORDS &&
+           (o % 256) == 0;
+}
+
+extern "C" int64_t eap_so3_dense_mask_words(int b, int p, int ks, int rp, int dir) {
+    const int n = dir ? p : ks * rp, kd = dir ? ceil_to(ks * rp, KC_BK) : p;
+    const int tiles = 8 * ((n + 255) / 256), steps = kd / KC_BK;
+    return (int64_t)b * tiles * steps * 16 + 16;
+}
+
+extern "C" int eap_so3_dense_member(int b, int p, int n_sup, int nn, int rp, int rows_ld, const int32_t *idx, const int32_t *rows,
+                                    const int32_t *n_rows, int32_t *slot_of, uint32_t *memb, int32_t *flags, eap_stream_t stream) {
+    if (b <= 0 || p <= 0) return 0;
+    if (rp <= 0 || rp > 32 * MEMB_WORDS || b > 65535) return eap::bad_arg("so3_dense_member: 0 < rp <= 512, b <= 65535");
+    hipStream_t s = eap::S(stream);
+    if (int e = eap::hip_fail(hipMemsetAsync(slot_of, 0xff, sizeof(int32_t) * (size_t)b * n_sup, s), "so3_dense_member memset")) return e;
+    if (int e = eap::hip_fail(hipMemsetAsync(flags, 0, sizeof(int32_t) * (size_t)b, s), "so3_dense_member memset")) return e;
+    hipLaunchKernelGGL(dense_slots_kernel, dim3(eap::cdiv(rp, 256), b), dim3(256), 0, s, n_sup, rp, rows_ld, rows, n_rows, slot_of);
+    hipLaunchKernelGGL(dense_member_kernel, dim3(eap::cdiv(p, 256), b), dim3(256), 0, s, p, n_sup, nn, rp, idx, slot_of, memb, flags);
+    return eap::check_launch("so3_dense_member");
+}
+
+extern "C" int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const uint32_t *memb, uint64_t *mask, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (!eap_so3_dense_supported(p, 4, ks, rp, 256) || b > 65535) return eap::bad_arg("so3_dense_masks: shape not taken");
+    const int n = dir ? p : ks * rp, kd = dir ? ceil_to(ks * rp, KC_BK) : p;
+    const int tiles = 8 * ((n + 255) / 256), steps = kd / KC_BK;
+    hipStream_t s = eap::S(stream);
+    // the 16 words past the end: read (never used) by the last k-step's look-ahead
+    if (int e = eap::hip_fail(hipMemsetAsync(mask + (size_t)b * tiles * steps * 16, 0, 16 * sizeof(uint64_t), s), "so3_dense_masks memset")) return e;
+    hipLaunchKernelGGL(dense_mask_kernel, dim3(eap::cdiv((long long)tiles * steps, 4), b), dim3(256), 0, s, p, ks, rp, dir, tiles, steps, memb,
+                       reinterpret_cast<u64 *>(mask));
+    return eap::check_launch("so3_dense_masks");
+}
+
+extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
+                                        const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
+                                        eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (b > 65535 || na > 65535 || !(sigma > 0.f)) return eap::bad_arg("so3_dense_tables: b, na <= 65535, sigma > 0");
+    hipStream_t s = eap::S(stream);
+    const int p_pad = ceil_to(p, KC_BK), kd_pad = ceil_to(ks * rp, KC_BK);
+    hipLaunchKernelGGL(dense_centre_kernel, dim3(b), dim3(256), 0, s, n_sup, s_xyz, centre);
+    hipLaunchKernelGGL(dense_points_kernel, dim3(eap::cdiv(p_pad, 256), b), dim3(256), 0, s, p, p_pad, g_dense_form, 1.0f / sigma, q_xyz, centre,
+                       reinterpret_cast<f32x4 *>(pt));
+    hipLaunchKernelGGL(dense_rows_kernel, dim3(eap::cdiv(kd_pad, 256), na, b), dim3(256), 0, s, n_sup, na, ks, rp, kd_pad, rows_ld, g_dense_form, 1.0f / sigma, s_xyz,
+                       centre, rows, rk, reinterpret_cast<f32x4 *>(kr));
+    return eap::check_launch("so3_dense_tables");
+}
+
+extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, const float *src, float *scale, void *planes, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || (reinterpret_cast<uintptr_t>(src) & 15))
+        return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source");
+    hipStream_t s = eap::S(stream);
+    const int kb_total = ceil_to(l, KC_BK) / 16;
+    hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, reinterpret_cast<const f32x4 *>(src), scale);
+    hipLaunchKernelGGL(dense_split_kernel, dim3(eap::cdiv(kb_total, 4), m / 32, b), dim3(256), 0, s, m, l, na, kb_total,
+                       reinterpret_cast<const f32x4 *>(src), scale, reinterpret_cast<u32x4 *>(planes));
+    return eap::check_launch("so3_dense_split");
+}
+
+// dir 0: Z[b][o][k][a][r] = sum_p dY Wd (planes of dY [b,o,p,a]);  dir 1: Yt[b][a][o][p] = sum_(k,r) G Wd (planes of G [b,o,(k,r),a])
+extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, float sigma, const void *planes, const float *scale,
+                                         const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (!eap_so3_dense_supported(p, na, ks, rp, o)) return eap::bad_arg("so3_dense_product: shape not taken (eap_so3_dense_supported)");
+    const int p_pad = ceil_to(p, KC_BK), kd_pad = ceil_to(ks * rp, KC_BK);
+    KcArgs g;
+    g.MT = o / 32; g.na = na; g.zcount = b * na;
+    g.N = dir ? p : ks * rp;
+    g.KS = (dir ? kd_pad : p) / KC_BK;
+    g.tiles_m = o / 256;
+    g.blocks_n = (g.N + 255) / 256;
+    g.mask_tiles = 8 * g.blocks_n;
+    g.A = reinterpret_cast<const u32x4 *>(planes);
+    g.scale = scale;
+    const f32x4 *ptT = reinterpret_cast<const f32x4 *>(pt), *krT = reinterpret_cast<const f32x4 *>(kr);
+    if (dir == 0) {
+        g.strT = ptT; g.strB = p_pad; g.strA = 0;
+        g.colT = krT; g.colB = (long long)na * kd_pad; g.colA = kd_pad;
+        g.cB = (long long)o * ks * na * rp; g.cA = rp; g.ldm = (long long)ks * na * rp; g.rp = rp; g.kstride = (long long)na * rp;
+    } else {
+        g.strT = krT; g.strB = (long long)na * kd_pad; g.strA = kd_pad;
+        g.colT = ptT; g.colB = p_pad; g.colA = 0;
+        g.cB = (long long)na * o * p; g.cA = (long long)o * p; g.ldm = p; g.rp = p; g.kstride = 0;
+    }
+    g.mask = reinterpret_cast<const u64 *>(mask);
+    g.C = out;
+    g.neg_inv_sigma = -1.0f / sigma;
+    return g_dense_form ? kc_launch<8, 1>(g, eap::S(stream)) : kc_launch<8, 0>(g, eap::S(stream));
+}
+
+extern "C" int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (o > 65535 || b > 65535) return eap::bad_arg("so3_dense_untranspose: o, b <= 65535");
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, yt, y);
+    return eap::check_launch("so3_dense_untranspose");
+}

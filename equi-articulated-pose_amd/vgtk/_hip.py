@@ -473,6 +473,93 @@ def rows_scatter(src, rows, n):
 
 # ---- block-layer epilogue (csrc/bn_act.hip) -------------------------------------------------------
 
+# ---- the inter conv re-associated over its referenced rows as a dense product (csrc/so3_dense.hip) ----------------------
+lib.eap_so3_dense_mask_words.restype = ctypes.c_int64
+
+
+def so3_dense_supported(p, na, ks, rp, o):
+    return bool(lib.eap_so3_dense_supported(int(p), int(na), int(ks), int(rp), int(o)))
+
+
+DENSE_MAX_ROWS = 512        # csrc/so3_dense.hip MEMB_WORDS * 32
+
+
+def so3_dense_member(idx, rows, n_rows, n):
+    """Which of a cloud's referenced rows (rows [b, >= 512], n_rows [b]; eap_inv_lists_rows) every neighbour list names:
+    -> memb int32 [b,p,16] (bit masks), flags int32 [b] (non-zero: the cloud cannot take the dense product -- a list names a row
+    twice, or more than 512 rows are referenced).  No host value is needed: runs before the row count is known."""
+    b, p, nn = idx.shape
+    dev = idx.device
+    memb = torch.empty(b, p, 16, dtype=torch.int32, device=dev)
+    flags = torch.empty(b, dtype=torch.int32, device=dev)
+    slot_of = torch.empty(b, n, dtype=torch.int32, device=dev)
+    call('eap_so3_dense_member', idx, b, p, n, nn, min(DENSE_MAX_ROWS, n), rows.stride(0), _ptr(idx), _ptr(rows), _ptr(n_rows), _ptr(slot_of),
+         _ptr(memb), _ptr(flags))
+    return memb, flags
+
+
+class DenseGeometry:
+    """What the dense product needs besides its stored operand, for one neighbourhood of a batch of clouds WITHOUT pose
+    rotations: the lane masks of both directions (built on demand from the membership bits) and the two float4 tables of the
+    expanded weight, for the first rp referenced rows of every cloud."""
+
+    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn):
+        b, p = memb.shape[:2]
+        n = s_xyz.shape[2]
+        na, ks, _ = rk.shape
+        dev = memb.device
+        self.b, self.p, self.na, self.ks, self.rp, self.nn, self.memb, self.sigma = b, p, na, ks, int(rp), int(nn), memb, float(sigma)
+        p_pad, kd_pad = (p + 31) // 32 * 32, (ks * self.rp + 31) // 32 * 32
+        self.centre = torch.empty(b, 4, dtype=torch.float32, device=dev)
+        self.pt = torch.empty(b, p_pad, 4, dtype=torch.float32, device=dev)
+        self.kr = torch.empty(b, na, kd_pad, 4, dtype=torch.float32, device=dev)
+        call('eap_so3_dense_tables_f32', memb, b, p, n, na, ks, self.rp, rows.stride(0), _F32(sigma), _ptr(q_xyz), _ptr(s_xyz), _ptr(rows),
+             _ptr(rk), _ptr(self.centre), _ptr(self.pt), _ptr(self.kr))
+        self._masks = {}
+
+    def mask(self, direction):
+        m = self._masks.get(direction)
+        if m is None:
+            words = int(lib.eap_so3_dense_mask_words(self.b, self.p, self.ks, self.rp, int(direction)))
+            m = torch.empty(words, dtype=torch.int64, device=self.memb.device)
+            call('eap_so3_dense_masks', m, self.b, self.p, self.ks, self.rp, int(direction), _ptr(self.memb), _ptr(m))
+            self._masks[direction] = m
+        return m
+
+
+def so3_dense_split(src):
+    """src [b,m,l,na] -> (scale [b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
+    fragment order)."""
+    b, m, l, na = src.shape
+    scale = torch.empty(b, na, m, dtype=torch.float32, device=src.device)
+    planes = torch.empty(b * na * m * ((l + 31) // 32 * 32), dtype=torch.int32, device=src.device)       # 4 bytes per element
+    call('eap_so3_dense_split_f32', src, b, m, l, na, _ptr(src), _ptr(scale), _ptr(planes))
+    return scale, planes
+
+
+def so3_dense_bwd(gy, geo):
+    """gy [b,o,p,na] -> Z [b,o,ks,na,rp] (the inverse-list kernel's Z with the anchor axis in front of the row axis)."""
+    b, o, p, na = gy.shape
+    scale, planes = so3_dense_split(gy)
+    z = torch.empty(b, o, geo.ks, na, geo.rp, dtype=torch.float32, device=gy.device)
+    call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr), _ptr(geo.mask(0)),
+         _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp})
+    return z
+
+
+def so3_dense_fwd(g, geo, p):
+    """g [b,o,ks*rp,na] (= W . F over the referenced rows) -> y [b,o,p,na]."""
+    b, o, kd, na = g.shape
+    scale, planes = so3_dense_split(g)
+    yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
+    call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr), _ptr(geo.mask(1)),
+         _ptr(yt), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp})
+    del planes
+    y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
+    call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y))
+    return y
+
+
 def _partials(x, b, c, n):
     nseg = int(lib.eap_bn_act_segments(_I64(n)))
     return (torch.empty(c, b * nseg, dtype=torch.float32, device=x.device),

@@ -431,31 +431,60 @@ def _side_stream(dev):
 class _ListHead:
     """First half of the inverse neighbour lists of idx [b,p,nn] (csrc/inv_lists.hip): per cloud the
     referenced support rows (longest list first), their counts and offsets -- all on the device -- plus an
-    ASYNCHRONOUS copy of the two numbers the backward's launch decisions need on the host (the largest
-    number of referenced rows of a cloud; whether any cloud carries non-identity relative rotations).
+    ASYNCHRONOUS copy of the numbers the launch decisions need on the host (the largest number of referenced rows of a
+    cloud; whether any cloud carries non-identity relative rotations; whether any cloud cannot take the dense product).
     Built in the forward, read in the backward: by then the copy has long landed, so nothing stalls."""
 
-    def __init__(self, idx, n_sup, nonident, gx=None, prefill=False):
+    def __init__(self, idx, n_sup, nonident, gx=None, prefill=False, dense_probe=None):
         """prefill (with gx): also the second half (csrc/inv_lists.hip fill: the entries of every referenced row) right away,
         for all rows -- the launch needs no host value that way.  Everything runs on a SIDE stream (LISTS_ON_SIDE_STREAM): these
         are small latency-bound kernels (0.3 + 0.45 ms per layer) that nothing in the forward waits for, and the grouping and
-        contraction kernels that follow on the main stream leave them room; the backward waits for `event`."""
+        contraction kernels that follow on the main stream leave them room; the backward waits for `event`.
+        dense_probe = (rotation blocks or None, ...): also the membership bits of the dense product (csrc/so3_dense.hip) and
+        whether every cloud can take it (no list names a row twice, at most 512 referenced rows, every given pose rotation
+        EXACTLY the identity -- the dense operand has no rotation in it)."""
         dev = idx.device
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if LISTS_ON_SIDE_STREAM else main
+        self.memb = None
         if side is not main:
             side.wait_stream(main)                        # idx / gx / nonident were produced on the main stream
+            for t in (idx, gx, nonident) + tuple(dense_probe or ()):
+                if t is not None:
+                    t.record_stream(side)                 # (read on the side stream: the allocator must not recycle them under it)
         with torch.cuda.stream(side):
             self.rows, self.off, self.cnt, self.n_rows = _hip.inv_lists_rows(idx, n_sup)
             flag = nonident.max() if nonident is not None else torch.ones((), dtype=torch.int32, device=dev)
-            stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32)])
-            self.host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            dense_bad = torch.ones((), dtype=torch.int32, device=dev)
+            if dense_probe is not None:
+                self.memb, dflags = _hip.so3_dense_member(idx, self.rows, self.n_rows, n_sup)
+                dense_bad = dflags.max()
+                eye = torch.eye(3, dtype=torch.float32, device=dev)
+                for rot in dense_probe:
+                    if rot is not None:
+                        dense_bad = dense_bad + (rot[:, :, :3, :3] != eye).any().to(torch.int32)
+            stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32), dense_bad.to(torch.int32)])
+            self.host = torch.empty(3, dtype=torch.int32, pin_memory=True)
             self.host.copy_(stats, non_blocking=True)
             self.entries = _hip.inv_lists_fill(idx, gx, self.rows, self.off, n_sup) if (prefill and gx is not None) else None
             self.event = torch.cuda.Event()
             self.event.record(side)
         if side is not main:                              # allocated under the side stream, used (and freed) under the main one
-            for t in (self.rows, self.off, self.cnt, self.n_rows) + (self.entries or ()):
+            for t in (self.rows, self.off, self.cnt, self.n_rows, self.memb) + (self.entries or ()):
+                if t is not None:
+                    t.record_stream(main)
+
+    def fill(self, idx, gx, n_sup):
+        """the second half of the lists after all (a forward that probed for the dense product and did not take it)"""
+        dev = idx.device
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if LISTS_ON_SIDE_STREAM else main
+        with torch.cuda.stream(side):
+            self.entries = _hip.inv_lists_fill(idx, gx, self.rows, self.off, n_sup)
+            self.event = torch.cuda.Event()
+            self.event.record(side)
+        if side is not main:
+            for t in self.entries:
                 t.record_stream(main)
 
     def wait(self):
@@ -465,8 +494,13 @@ class _ListHead:
     def decide(self):
         """-> (rcap, any_nonident) as Python values."""
         self.event.synchronize()
-        rcap, flag = self.host.tolist()
+        rcap, flag, _ = self.host.tolist()
         return int(rcap), bool(flag)
+
+    def dense_possible(self):
+        """every cloud can take the dense product (see __init__); blocks on the host like decide()"""
+        self.event.synchronize()
+        return self.memb is not None and int(self.host[2]) == 0
 
 
 def _inverse_lists(idx, gx, n_sup, ident, nonident=None):
@@ -560,12 +594,62 @@ def _grouped_bound(feats, idx):
 BACKWARD_LOG = None      # a list while someone wants to know the backward regime of every inter conv (bench.py, tests)
 
 
+# The dense product over the referenced rows (csrc/so3_dense.hip): 'auto' takes it when every cloud of the batch can (no pose
+# rotation, no padded lists), the output width fills its 256-row blocks and a cloud references at most DENSE_ROW_FACTOR x
+# nsample rows (it does rows / nsample times the flops of the list kernels on a pipe ~4.5 x as fast); 'off' never; 'force'
+# whenever the shapes are taken (tests).
+DENSE_MODE = os.environ.get('EAP_DENSE', 'auto')
+DENSE_ROW_FACTOR = 4.0
+
+
+def _dense_rows(rcap, n):
+    return min((rcap + 3) & ~3, n)
+
+
+def _dense_wanted(head, o, p, na, ks, nn, n):
+    """-> rp (rows per cloud of the dense product) or 0.  Blocks on the host for the row count."""
+    if DENSE_MODE == 'off' or head is None or head.memb is None:
+        return 0
+    rcap, _ = head.decide()
+    rp = _dense_rows(rcap, n)
+    if rp <= 0 or rp % 4 or not head.dense_possible() or not _hip.so3_dense_supported(p, na, ks, rp, o):
+        return 0
+    if DENSE_MODE != 'force' and rp > DENSE_ROW_FACTOR * nn:
+        return 0
+    return rp
+
+
+def _weight_grad_from_z(z, fc, b, c, o, ks, ra):
+    """dW[o,(c,k)] = sum_{b,(r,a)} Z[b,o,k,(r,a)] Fc[b,c,(r,a)] for Z [b, o*ks, ra] and the referenced feature rows Fc [b, c, ra]
+    (any order of the (row, anchor) axis, the same in both)."""
+    if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, o * ks):
+        # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
+        # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe
+        dt = torch.empty(c, o * ks, dtype=torch.float32, device=z.device)
+        _hip.gemm_reduce(0, 1, c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, dt, o * ks, b)
+        return dt.view(c, o, ks).permute(1, 0, 2).reshape(o, c * ks).contiguous()
+    d = torch.empty(o * ks, c, dtype=torch.float32, device=z.device)    # sum_b Z_b Fc_b^T
+    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
+    return d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
+
+
+def _dense_forward(feats, W, rows, geo, p):
+    """y [b,o,p,a] = sum_(k,r) G[o,(k,r),a] Wd[p,(k,r),a] with G = W F over the referenced rows (csrc/so3_dense.hip)."""
+    b, c, n, na = feats.shape
+    o, ks, rp = W.shape[0], geo.ks, geo.rp
+    fc = _hip.rows_gather(feats, rows, rp)                                        # [b,c,rp,na]; empty slots: zeros
+    W3 = W.view(o, c, ks).permute(0, 2, 1).reshape(o * ks, c).contiguous()
+    g = torch.empty(b, o * ks, rp * na, dtype=torch.float32, device=feats.device)
+    _hip.gemm(0, 0, o * ks, rp * na, c, W3, c, 0, fc, rp * na, c * rp * na, g, rp * na, o * ks * rp * na, b)
+    return _hip.so3_dense_fwd(g.view(b, o, ks * rp, na), geo, p)
+
+
 class _InterConv(torch.autograd.Function):
     """Fused inter conv  y = W . group(feats)  (functional.py:L1221-1261 + modules.py:L48-55)
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None, grad_mode=True):
+    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None, grad_mode=True, geometry=None):
         feats = feats.contiguous()
         W = W_param.contiguous()
         ctx.anchors = anchors.detach().contiguous() if anchors is not None else None   # the rotations `mult` was built from
@@ -586,7 +670,37 @@ class _InterConv(torch.autograd.Function):
         keep = needs_grad and (not lists_ok or _keep_x_hint(W_param))
         # inverse neighbour lists (device only; the host-side numbers arrive asynchronously), started before the grouping so that
         # they run beside it; the entries too when the previous backward of this layer took the lists
-        ctx.head = _ListHead(idx, n, nonident, gx, prefill=not keep) if (lists_ok and needs_grad) else None
+        # geometry = (q_xyz, xyz, q_rot, rot): what the dense product over the referenced rows is built from (csrc/so3_dense.hip);
+        # whether the batch can take it is known on the host once the lists' first half has run -- one host wait per layer,
+        # only for layers whose width fills the dense kernel's blocks
+        probe = None
+        if (DENSE_MODE != 'off' and geometry is not None and lists_ok and epilogue is None
+                and _hip.so3_dense_supported(p, na, ks, 4, o) and n <= _hip.DENSE_MAX_ROWS * 64):
+            probe = (geometry[2], geometry[3])
+        head = None
+        if (lists_ok and needs_grad) or probe is not None:
+            head = _ListHead(idx, n, nonident, gx, prefill=(not keep) and probe is None, dense_probe=probe)
+        rp = _dense_wanted(head, o, p, na, ks, idx.shape[2], n) if probe is not None else 0
+        ctx.dense = None
+        if rp > 0:
+            head.wait()
+            geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2])
+            y = _dense_forward(feats, W, head.rows, geo, p)
+            ctx.head = head if needs_grad else None
+            ctx.dense = geo if needs_grad else None
+            ctx.layout, ctx.kept_x = 0, False
+            ctx.W_param = weakref.ref(W_param)
+            ctx.save_for_backward(W, torch.empty(0), idx, gx, rk, mult if mult is not None else torch.empty(0),
+                                  nonident if nonident is not None else torch.empty(0), feats)
+            ctx.has_mult = mult is not None
+            ctx.has_flag = nonident is not None
+            ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
+            return y
+        if head is not None and not (lists_ok and needs_grad):
+            head = None
+        elif head is not None and probe is not None and not keep:
+            head.fill(idx, gx, n)                          # (the probe postponed it)
+        ctx.head = head
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
         coset = _coset_tables(mult, ident) if (mult is not None and nonident is not None and layout == 2 and COSET_OPERAND) else None
         x_bound = _grouped_bound(feats, idx) if layout == 2 else None          # [b, p] words
@@ -637,6 +751,22 @@ class _InterConv(torch.autograd.Function):
         # two small GEMMs over the referenced rows only -- no dX = W^T dY, no scatter, and the
         # [O x P*A] x [P*A x C*K] weight-gradient GEMM shrinks by P / (referenced rows).
         head, rcap, any_nonident = ctx.head, 0, True
+        if ctx.dense is not None:
+            geo = ctx.dense
+            if BACKWARD_LOG is not None:
+                BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(geo.rp), 'regime': 'dense rows'})
+            z = _hip.so3_dense_bwd(gy, geo)                                          # [b,o,ks,na,rp]: the lists' Z with the anchor axis in front
+            rp = geo.rp
+            ra = na * rp
+            if ctx.needs_input_grad[0]:
+                W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
+                gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
+                _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
+                gF = _hip.rows_scatter(gFc.view(b, c, na, rp).transpose(2, 3).contiguous(), head.rows, n)
+            if ctx.needs_input_grad[1]:
+                fc = _hip.rows_gather(feats, head.rows, rp).transpose(2, 3).contiguous().view(b, c, ra)      # [b,c,(a,r)]
+                gW = _weight_grad_from_z(z, fc, b, c, o, ks, ra)
+            return gF, gW, None, None, None, None, None, None, None, None, None, None, None
         if head is not None:
             rcap, any_nonident = head.decide()
             if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
@@ -684,17 +814,7 @@ class _InterConv(torch.autograd.Function):
                 fc = _hip.rows_gather(feats, rows, rcap)                             # [b,c,rcap,na]; unused slots: zeros
                 if z_order is not None:
                     fc = _hip.anchor_reorder(fc, z_order)
-                fc = fc.view(b, c, ra)
-                if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, o * ks):
-                    # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
-                    # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe
-                    dt = torch.empty(c, o * ks, dtype=torch.float32, device=gy.device)
-                    _hip.gemm_reduce(0, 1, c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, dt, o * ks, b)
-                    gW = dt.view(c, o, ks).permute(1, 0, 2).reshape(o, c * ks).contiguous()
-                else:
-                    d = torch.empty(o * ks, c, dtype=torch.float32, device=gy.device)    # sum_b Z_b Fc_b^T
-                    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
-                    gW = d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
+                gW = _weight_grad_from_z(z, fc.view(b, c, ra), b, c, o, ks, ra)
         else:
             if ctx.needs_input_grad[1]:
                 gW = torch.empty_like(W)          # sum_b gy_b x_b^T
@@ -706,7 +826,7 @@ class _InterConv(torch.autograd.Function):
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
-        return gF, gW, None, None, None, None, None, None, None, None, None, None
+        return gF, gW, None, None, None, None, None, None, None, None, None, None, None
 
 
 INTRA_DW_SLICE = 64      # channels whose 12-tap gather is materialised at a time for the intra weight gradient
@@ -879,7 +999,8 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
     gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
     y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident,
-                         anchors if mult is not None else None, epilogue, torch.is_grad_enabled())
+                         anchors if mult is not None else None, epilogue, torch.is_grad_enabled(),
+                         (q_xyz.contiguous(), xyz.contiguous(), q_rot, rot))
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 

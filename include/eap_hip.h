@@ -320,6 +320,44 @@ int eap_rows_gather_f32(int b, int c, int n, int na, int rcap, int rows_ld, cons
 int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, const int32_t *rows,
                          const float *src, float *dst, eap_stream_t stream);
 
+/* ---- the fused inter conv re-associated over its referenced rows as a dense product (csrc/so3_dense.hip) ----
+ * Replaces, for clouds WITHOUT pose rotations whose neighbour lists name few support rows, the grouping einsum +
+ * contraction of so3conv/functional.py:L1112-1261 + so3conv/modules.py:L48-55 (forward) and their autograd transpose
+ * (backward).  With rows[b, 0..rp) the referenced support rows of cloud b (eap_inv_lists_rows; rp a multiple of 4, empty
+ * slots = -1) and m[p,r] = 1 iff row r is in idx[b,p,:]:
+ *     Wd[p,(k,r),a] = m[p,r] relu(1 - |x_row(r) - x_p - rk[a,k]|^2 / sigma)
+ *     dir 0 (backward)  Z [b,o,k,a,r]   = sum_p      dY[b,o,p,a]     Wd[p,(k,r),a]
+ *     dir 1 (forward)   Yt[b,a,o,p]     = sum_(k,r)  G [b,o,(k,r),a] Wd[p,(k,r),a]      (G = W F over the referenced rows)
+ * on the fp16 matrix cores with two planes per operand and fp32 accumulation (the arithmetic of eap_gemm_f16x2_f32).
+ *   eap_so3_dense_form        how the weights are evaluated: 1 (default) from the squared distance, 0 from the expanded square
+ *                             (fewer instructions, ~3 x the rounding error); tables and product under the same setting; -> old setting
+ *   eap_so3_dense_supported   p % 32 == 0, na % 4 == 0, na <= 64, rp % 4 == 0, rp <= 512, o % 256 == 0
+ *   eap_so3_dense_member      slot_of int32 [b,n] (scratch), memb uint32 [b,p,16] (bit r of point p = m[p,r]; rp <= 512),
+ *                             flags int32 [b]: 1 = a list names a row twice (padded short lists, grouping_cuda_kernel.cu:L98-107:
+ *                             not representable by a 0/1 mask), 2 = a list names a row outside rows[:, :rp] -- such clouds
+ *                             must take the list kernels
+ *   eap_so3_dense_mask_words  uint64 words of the mask table of one direction; eap_so3_dense_masks fills it:
+ *                             [b][32-column tile][k-step of 32][16] lane masks of the product kernel
+ *   eap_so3_dense_tables_f32  centre [b,4] (centroid of the support points), pt float4 [b, ceil32(p)] and
+ *                             kr float4 [b, na, ceil32(ks rp)]: the two sides of the weight (centred coordinates), evaluated in float64
+ *   eap_so3_dense_split_f32   src [b,m,l,na] -> scale [b,na,m] (power of two per row) and the two fp16 planes of the scaled
+ *                             rows in the product kernel's fragment order: 4 b na m ceil32(l) bytes
+ *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1)
+ *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na] */
+int eap_so3_dense_supported(int p, int na, int ks, int rp, int o);
+int eap_so3_dense_form(int form);
+int eap_so3_dense_member(int b, int p, int n, int nn, int rp, int rows_ld, const int32_t *idx, const int32_t *rows,
+                         const int32_t *n_rows, int32_t *slot_of, uint32_t *memb, int32_t *flags, eap_stream_t stream);
+int64_t eap_so3_dense_mask_words(int b, int p, int ks, int rp, int dir);
+int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const uint32_t *memb, uint64_t *mask, eap_stream_t stream);
+int eap_so3_dense_tables_f32(int b, int p, int n, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
+                             const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
+                             eap_stream_t stream);
+int eap_so3_dense_split_f32(int b, int m, int l, int na, const float *src, float *scale, void *planes, eap_stream_t stream);
+int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, float sigma, const void *planes, const float *scale,
+                              const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream);
+int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, eap_stream_t stream);
+
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 
 /* so3_intra_group_fwd: intra_so3conv_grouping, so3conv/functional.py:L2553-2602.

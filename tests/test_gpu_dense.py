@@ -1,0 +1,238 @@
+"""GPU: the inter conv re-associated over its referenced rows as a dense product (csrc/so3_dense.hip, round 5).
+
+Oracle here = float64 torch expressions of the reference's formulas on the same inputs (the weights
+relu(1 - |x_n - x_p - A_a kappa_k|^2 / sigma) of so3conv/functional.py:L2508-2549, the einsum of L1261 and its autograd
+transpose) and, for whole layers, the list kernels the golden fixtures pin (DENSE_MODE 'off'); the slab comparisons against
+oracle/so3_ref.py at the bench shapes run the dense path too (tests/test_gpu_bench_shapes.py, DENSE_MODE 'auto').
+
+Bars: stored-operand split 2^-21 of a row's maximum; generated weights 5e-7 absolute (the bar of the list kernels' weights: 2e-6);
+Z and y 1e-5 of their scale against float64; gradients as tests/test_gpu_bench_shapes.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NN, NA, KS = 64, 60, 24
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def _setup(dev, B, P, layer=2, plan=4096, seed=11, radius=None):
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.so3conv.functional as L
+    import vgtk.cuda.grouping as cuda_nn
+    from vgtk import _hip
+    c, o, r, sigma = synth_clouds.backbone_layers(plan)[layer]
+    radius = r if radius is None else radius
+    xyz_np, _, _ = synth_clouds.laptop_batch(seed, B, P)
+    xyz = torch.from_numpy(xyz_np).to(dev).contiguous()
+    anchors = torch.from_numpy(np.asarray(L.get_anchors(NA), dtype=np.float32)).to(dev)
+    kernels = torch.from_numpy(L.get_sphereical_kernel_points_from_ply(0.7 * radius, 1)).to(dev)
+    rk = L.rotated_kernels(anchors, kernels)
+    idx = cuda_nn.ball_query(xyz, xyz, radius, NN)
+    return dict(xyz=xyz, idx=idx, rk=rk, sigma=float(sigma), c=c, o=o, radius=radius, anchors=anchors, kernels=kernels)
+
+
+def _geometry(s, dev):
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    xyz, idx = s['xyz'], s['idx']
+    n = xyz.shape[2]
+    head = L._ListHead(idx, n, None, None, dense_probe=(None, None))
+    rcap, _ = head.decide()
+    assert head.dense_possible()
+    rp = L._dense_rows(rcap, n)
+    head.wait()
+    geo = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, s['rk'], s['sigma'], NN)
+    return head, geo, rp
+
+
+def _dense_weights64(s, rows, rp):
+    """Wd[b,p,k,r,a] in float64 from the reference's formula + the membership of row r in p's list."""
+    xyz, idx, rk = s['xyz'].double(), s['idx'].long(), s['rk'].double()
+    B, _, P = xyz.shape
+    out = []
+    for b in range(B):
+        rw = rows[b, :rp].long()
+        ok = rw >= 0
+        xr = xyz[b][:, rw.clamp(min=0)]                                   # [3, rp]
+        g = xr[:, None, :] - xyz[b][:, :, None]                           # [3, P, rp]  x_r - x_p
+        d = g.permute(1, 2, 0)[:, :, None, None, :] - rk[None, None]      # [P, rp, A, K, 3]
+        w = torch.relu(1.0 - (d * d).sum(-1) / s['sigma'])                # [P, rp, A, K]
+        member = (idx[b][:, :, None] == rw[None, None, :]).any(1) & ok[None, :]      # [P, rp]
+        out.append(w * member[:, :, None, None].double())
+    return torch.stack(out)                                               # [B, P, rp, A, K]
+
+
+def _member(s, rows, rp):
+    idx = s['idx'].long()
+    return torch.stack([((idx[b][:, :, None] == rows[b, :rp].long()[None, None, :]).any(1) & (rows[b, :rp] >= 0)[None, :]).double()
+                        for b in range(idx.shape[0])])                    # [B, P, rp]
+
+
+def test_split_planes_reconstruct_the_operand(dev):
+    """dense_split_kernel: (h + l) / scale == x to 2^-21 of the row maximum (two fp16 planes after the row's power-of-two
+    scale; an element 2^-17 below the maximum keeps the relative bound), planes in the fragment order the product reads."""
+    from vgtk import _hip
+    gen = torch.Generator(device=dev).manual_seed(3)
+    b, m, l, na = 2, 64, 80, 60
+    x = torch.randn(b, m, l, na, device=dev, generator=gen) * torch.exp(3 * torch.randn(b, m, 1, na, device=dev, generator=gen))
+    x[0, 3] = 0.0
+    scale, planes = _hip.so3_dense_split(x)
+    lp = (l + 31) // 32 * 32
+    pl = planes.view(torch.float16).view(b, na, lp // 16, m // 32, 2, 64, 8).float()       # [b,a,kb,mt,plane,lane,e]
+    v = pl[:, :, :, :, 0] + pl[:, :, :, :, 1]                                              # [b,a,kb,mt,lane,e]
+    v = v.view(b, na, lp // 16, m // 32, 2, 32, 8)                                         # lane = 32 kg + i
+    v = v.permute(0, 1, 3, 5, 2, 4, 6).reshape(b, na, m, lp)                               # [b,a,row,k] with k = 16 kb + 8 kg + e
+    rec = (v / scale[:, :, :, None])[:, :, :, :l].permute(0, 2, 3, 1)
+    rowmax = x.abs().amax(dim=2, keepdim=True)
+    assert float(((rec - x).abs() / rowmax.clamp(min=1e-30)).max()) < 2.0 ** -21
+    assert float(v[:, :, :, l:].abs().max()) == 0.0                                         # the padding past l
+    s = scale[rowmax[:, :, 0].permute(0, 2, 1) > 0]
+    top = (rowmax[:, :, 0].permute(0, 2, 1)[rowmax[:, :, 0].permute(0, 2, 1) > 0] * s)
+    assert float(top.min()) >= 2.0 ** 14 and float(top.max()) < 2.0 ** 15
+    assert float(scale[0, :, 3].min()) == 1.0 and float(scale[0, :, 3].max()) == 1.0       # an all-zero row
+
+
+@pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1)])
+def test_generated_weights_and_backward_product(dev, P, layer):
+    """Z[b,o,k,a,r] = sum_p dY[b,o,p,a] Wd[p,(k,r),a]: with dY = one-hot rows the product IS the generated operand -> the bar on
+    the weights; with random dY against the float64 sum."""
+    from vgtk import _hip
+    s = _setup(dev, 2, P, layer=layer)
+    head, geo, rp = _geometry(s, dev)
+    B, o = 2, 256
+    wd = _dense_weights64(s, head.rows, rp)                                   # [B,P,rp,A,K]
+    # one-hot: dY[b,o,p,a] = 1 iff p == p0 + o  ->  Z[b,o,k,a,r] = Wd[p0 + o,(k,r),a]
+    for p0 in (0, P - 256):
+        gy = torch.zeros(B, o, P, NA, device=dev)
+        gy[:, torch.arange(o), p0 + torch.arange(o), :] = 1.0
+        z = _hip.so3_dense_bwd(gy, geo)                                       # [B,o,K,A,rp]
+        ref = wd[:, p0:p0 + o].permute(0, 1, 4, 3, 2)                         # [B,o,K,A,rp]
+        err = float((z.double() - ref).abs().max())
+        assert err < 5e-7, (p0, err)                                           # (bar of the list kernels' weights: 2e-6)
+        assert float(ref.max()) > 0.5                                          # not vacuous
+    gen = torch.Generator(device=dev).manual_seed(5)
+    gy = torch.randn(B, o, P, NA, device=dev, generator=gen) * torch.exp(2 * torch.randn(B, o, 1, NA, device=dev, generator=gen))
+    z = _hip.so3_dense_bwd(gy, geo)
+    ref = torch.einsum('bopa,bprak->bokar', gy.double(), wd)
+    # bound: the products (1e-6 of sum |dY| w) + the weights' own evaluation error (5e-7 absolute, 4 x below the bar above) on
+    # every list member
+    mag = torch.einsum('bopa,bprak->bokar', gy.double().abs(), wd)
+    magm = torch.einsum('bopa,bpr->boar', gy.double().abs(), _member(s, head.rows, rp))[:, :, None]
+    assert float(((z.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
+    z2 = _hip.so3_dense_bwd(gy, geo)
+    assert torch.equal(z, z2)                                                  # bit-reproducible
+
+
+def test_backward_product_matches_the_list_kernel(dev):
+    """Same Z as eap_so3_inter_group_inv_f32 (rows in the same order, anchor and row axes exchanged)."""
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    s = _setup(dev, 2, 512)
+    head, geo, rp = _geometry(s, dev)
+    xyz, idx = s['xyz'], s['idx']
+    gx, _ = _hip.so3_prep(xyz, xyz, idx, None, None, s['anchors'].contiguous(), 0)
+    ent_p, ent_gx = _hip.inv_lists_fill(idx, gx, head.rows, head.off, rp)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    gy = torch.randn(2, 256, 512, NA, device=dev, generator=gen)
+    z_list = _hip.so3_inter_group_inv(gy, head.rows[:, :rp].contiguous(), head.off[:, :rp].contiguous(), head.cnt[:, :rp].contiguous(),
+                                      ent_p, ent_gx, s['rk'], None, s['sigma'], NN)                  # [b,o,ks,rp,na]
+    z = _hip.so3_dense_bwd(gy, geo)
+    scale = float(z_list.abs().max())
+    assert float((z.transpose(3, 4) - z_list).abs().max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1)])
+def test_forward_product(dev, P, layer):
+    """Yt[b,a,o,p] = sum_(k,r) G[b,o,(k,r),a] Wd[p,(k,r),a] against the float64 sum, and back in the reference layout."""
+    from vgtk import _hip
+    s = _setup(dev, 2, P, layer=layer)
+    head, geo, rp = _geometry(s, dev)
+    B, o = 2, 256
+    wd = _dense_weights64(s, head.rows, rp)                                   # [B,P,rp,A,K]
+    gen = torch.Generator(device=dev).manual_seed(9)
+    g = torch.randn(B, o, KS, rp, NA, device=dev, generator=gen) * torch.exp(2 * torch.randn(B, o, 1, 1, NA, device=dev, generator=gen))
+    y = _hip.so3_dense_fwd(g.view(B, o, KS * rp, NA), geo, P)
+    assert y.shape == (B, o, P, NA)
+    ref = torch.einsum('bokra,bprak->bopa', g.double(), wd)
+    mag = torch.einsum('bokra,bprak->bopa', g.double().abs(), wd)
+    magm = torch.einsum('bokra,bpr->bopa', g.double().abs(), _member(s, head.rows, rp))
+    assert float(((y.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
+    assert torch.equal(y, _hip.so3_dense_fwd(g.view(B, o, KS * rp, NA), geo, P))
+
+
+def _layer_run(dev, monkeypatch, mode, xyz, pose, feats0, W0, c, o, radius, sigma):
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    monkeypatch.setattr(L, 'DENSE_MODE', mode)
+    torch.manual_seed(2913)
+    conv = sptk.InterSO3PoseConv(c, o, 1, 1, radius, sigma, NN, kanchor=NA, permute_modes=1).to(dev)
+    with torch.no_grad():
+        conv.basic_conv.W.copy_(W0)
+    feats = feats0.clone().requires_grad_(True)
+    L.BACKWARD_LOG = []
+    y = conv(zptk.SphericalPointCloudPose(xyz, feats, None, pose))[3].feats
+    gen = torch.Generator(device=dev).manual_seed(21)
+    gy = torch.randn(y.shape, device=dev, generator=gen)
+    gF, gW = torch.autograd.grad(y, [feats, conv.basic_conv.W], gy)
+    log, L.BACKWARD_LOG = L.BACKWARD_LOG, None
+    with torch.no_grad():
+        y_ng = conv(zptk.SphericalPointCloudPose(xyz, feats0, None, pose))[3].feats
+    return y.detach(), gF, gW, log, y_ng
+
+
+@pytest.mark.parametrize('with_pose', [False, True])
+def test_whole_layer_dense_against_lists(dev, monkeypatch, with_pose):
+    """InterSO3PoseConv forward + backward at O = 256 with the dense product forced / switched off: y, dF, dW agree to the
+    bars of the bench-shape tests; the no-grad forward takes the dense product too; identity POSES (what the model feeds) count
+    as no rotation."""
+    import synth_clouds
+    B, P, c, o = 2, 512, 32, 256
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    xyz_np, _, _ = synth_clouds.laptop_batch(31, B, P)
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    pose = torch.eye(4, device=dev).repeat(B, P, 1, 1) if with_pose else None
+    gen = torch.Generator(device=dev).manual_seed(13)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    y0, gF0, gW0, log0, _ = _layer_run(dev, monkeypatch, 'off', xyz, pose, feats0, W0, c, o, radius, sigma)
+    y1, gF1, gW1, log1, y1n = _layer_run(dev, monkeypatch, 'force', xyz, pose, feats0, W0, c, o, radius, sigma)
+    assert [r['regime'] for r in log1] == ['dense rows'] and log0[0]['regime'] != 'dense rows'
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(y1, y0) < 2e-5 and rel(gF1, gF0) < 2e-5 and rel(gW1, gW0) < 5e-5
+    assert torch.equal(y1n, y1)
+
+
+def test_clouds_the_dense_product_cannot_take_fall_back(dev, monkeypatch):
+    """Padded (short) lists name a row twice; a pose rotation that is not the identity rotates the offsets: both must stay on
+    the list kernels even with the dense product forced, with unchanged results."""
+    import synth_clouds
+    import vgtk.so3conv.functional as L
+    B, P, c, o = 2, 512, 16, 256
+    xyz_np, _, _ = synth_clouds.laptop_batch(41, B, P)
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(15)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    # (a) a small ball: most lists are short
+    head = L._ListHead(__import__('vgtk.cuda.grouping', fromlist=['x']).ball_query(xyz, xyz, 0.05, NN), P, None, None, dense_probe=(None, None))
+    assert not head.dense_possible()
+    r0 = _layer_run(dev, monkeypatch, 'off', xyz, None, feats0, W0, c, o, 0.05, 0.002)
+    r1 = _layer_run(dev, monkeypatch, 'force', xyz, None, feats0, W0, c, o, 0.05, 0.002)
+    assert r1[3][0]['regime'] != 'dense rows' and all(torch.equal(a, b) for a, b in zip(r0[:3], r1[:3]))
+    # (b) one rotated pose in the batch
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
+    a = 0.3
+    pose[1, 17, :3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0.], [np.sin(a), np.cos(a), 0.], [0., 0., 1.]], device=dev)
+    r0 = _layer_run(dev, monkeypatch, 'off', xyz, pose, feats0, W0, c, o, radius, sigma)
+    r1 = _layer_run(dev, monkeypatch, 'force', xyz, pose, feats0, W0, c, o, radius, sigma)
+    assert r1[3][0]['regime'] != 'dense rows' and all(torch.equal(a_, b_) for a_, b_ in zip(r0[:3], r1[:3]))
