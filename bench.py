@@ -314,10 +314,11 @@ def summarize_by_kernel(records):
     by_kernel = {}
     for name, tag, e0, e1 in records:
         kname = (tag or {}).get('kernel') or name
-        k = by_kernel.setdefault(kname, {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'entries': set()})
+        k = by_kernel.setdefault(kname, {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'executed_f16_flops': 0.0, 'entries': set()})
         k['ms'] += e0.elapsed_time(e1)
         k['launches'] += 1
         k['flops'] += (tag or {}).get('flops', 0.0)
+        k['executed_f16_flops'] += (tag or {}).get('executed_f16_flops', 0.0)
         k['entries'].add(name)
     return by_kernel
 
@@ -346,6 +347,20 @@ def pmc_of_kernel(kname):
 def roofline_object(kname, k, default_cfg):
     ach = k['flops'] / (k['ms'] * 1e-3) / 1e12 if k['ms'] > 0 else 0.0
     pmc = pmc_of_kernel(kname) if default_cfg else None
+    if kname.startswith('kc_gemm_kernel'):
+        # the deepest inter conv re-associated over its referenced rows (csrc/so3_dense.hip): per (cloud, anchor) a dense GEMM
+        # over ALL referenced rows (rows / nsample times the list kernels' flops: every point meets every referenced row, a 0/1
+        # mask keeps its own neighbours) with fp32-accurate products from two fp16 planes per operand (3 fp16 MFMAs per
+        # product).  `achieved` / `frac` = the fp16 flops the kernel EXECUTES on the fp16 matrix pipe; `algorithmic` = the flops
+        # of the operator as SURVEY.md section 8(d) counts them (2 O P A K nsample per cloud), i.e. what the list kernel was priced on
+        ex = k['executed_f16_flops'] / (k['ms'] * 1e-3) / 1e12 if k['ms'] > 0 else 0.0
+        return {'bound': 'mfma', 'pipe': 'fp16 (dense product over the referenced rows; 2 x fp16 split operands: 3 fp16 MFMAs per fp32-equivalent product, fp32 accumulate)',
+                'kernel': kname, 'entries': sorted(k['entries']), 'achieved': ex, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ex / PEAK_BF16_MFMA_TFLOPS,
+                'algorithmic': {'TFLOPs': ach, 'over_fp32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS, 'x3_over_fp16_peak': 3.0 * ach / PEAK_BF16_MFMA_TFLOPS,
+                                'executed_over_algorithmic_x3': (ex / (3.0 * ach)) if ach > 0 else None},
+                'traffic': (pmc['fetch'] + pmc['write']) if pmc else None, 'traffic_detail': pmc, 'launches': k['launches'],
+                'avg_launch_ms': k['ms'] / max(k['launches'], 1)}
     if 'f16x2' in kname:
         # fp32 operands, fp32 accumulation, every product as three fp16 MFMA products of two-plane splits (csrc/gemm_bf16x3.hip,
         # gemm_f16x2_kernel): the roofline is the fp16 matrix pipe (same dense peak as bf16), 3 x the algorithmic flops on it

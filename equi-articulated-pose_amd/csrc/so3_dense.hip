@@ -28,17 +28,20 @@
 //   0            the square expanded: w = clamp([1 - |u|^2/sigma] + [-|x~_p|^2/sigma] + u . [2 x~_p / sigma]): 1 add + 3 fma, but
 //                partial sums up to ~6.5 at the bench radii -> ~7e-7 absolute (bar on the weights: 2e-6, tests/test_gpu_dense.py).
 // The weights are NOT scaled: l = fp16(w - fp16(w)) is a subnormal for w < 0.12 and then carries an absolute error <= 2^-25,
-// below the evaluation error above.  The mask arrives as one 64-bit word per (32-column tile, k-step element) through the
-// SCALAR cache and is applied by v_cndmask with the word as its lane mask: no per-lane mask traffic at all.
+// below the evaluation error above.  The mask is one bit per generated weight -- a dword per lane and k-step, riding in the
+// operand ring -- and enters as the ADDEND of the weight's last fma (1.0 for a list member, else 0.0: the clamp then returns 0).
+// (First version: 64-bit lane masks through the scalar cache + v_cndmask; every use made the wave wait for all its outstanding
+// LDS reads as well -- scalar loads return out of order -- 2.2 of 16.5 ms, profiles/r05_dense_ablation.txt.)
 //
 // Geometry (kc_gemm_kernel): 4 waves, one per SIMD; block tile 256 x 256, wave tile 256 x 64 = 256 accumulator registers;
 // k-step 32 (two MFMA k-blocks).  The stored operand lives in HBM already in FRAGMENT ORDER ([k-block][row tile][plane][lane]
 // 16-byte pieces, written by dense_split_kernel), so a k-step of a block is 32 contiguous KB moved by 32 global->LDS DMA
 // instructions and read back with conflict-free ds_read_b128; the side of the generated operand that runs along k (16 float4
-// per k-block) rides in the same ring; three stages, one barrier per k-step.  Every wave generates the operand of ITS 64
+// per k-block) rides in the same ring; four stages, one barrier per k-step.  Every wave generates the operand of ITS 64
 // columns for all 256 rows: 16 weights per lane and k-block against 48 matrix instructions, ~2.5 vector instructions per
 // matrix instruction, issued in their shadow.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -82,14 +85,17 @@ __device__ __forceinline__ float pow2_scale(float v) {
 // x (scaled) = h + l + e, h = fp16(x), l = fp16(x - h), both to nearest even; two values -> the packed h word and l word.
 // v_fma_mix{lo,hi}_f16 form fp16(-1 * h + x) in one instruction each, reading h's half straight from the packed word.
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &l) {
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
 #ifdef EAP_DENSE_PLAIN_SPLIT
-    const f16x2 hh = __builtin_bit_cast(f16x2, h);
+    const f16x2 hh = __builtin_convertvector((f32x2){x0, x1}, f16x2);
     const f16x2 ll = __builtin_convertvector((f32x2){x0 - (float)hh.x, x1 - (float)hh.y}, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
     l = __builtin_bit_cast(unsigned, ll);
 #else
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+    // (one statement: hipcc pads every asm statement whose result the next instruction reads with a wait state)
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h), "=&v"(l) : "v"(x0), "v"(x1));
 #endif
 }
 
@@ -133,32 +139,30 @@ __global__ __launch_bounds__(256) void dense_member_kernel(int p, int n_sup, int
     if (bad) atomicOr(&flags[b], bad);
 }
 
-// mask[b][tile][step][16]: word 8 t + e, bit l  <->  column n = 32 tile + (l & 31), contraction index kk = 32 step + 16 t + 8 (l >> 5) + e
+// bits[b][wave tile wt][step][lane]: bit 16 t + 8 j + e of the lane's dword  <->  column n = 64 wt + 32 j + (lane & 31), contraction index
+// kk = 32 step + 16 t + 8 (lane >> 5) + e -- the 32 weights the lane generates in a k-step of the product kernel
 //   dir 0 (backward): kk = point, n = (k, r) = (n / rp, n % rp), n < ks rp        dir 1 (forward): kk = (k, r), n = point
-// one wave per (tile, step): 16 ballots
-__global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, int dir, int tiles, int steps,
-                                                         const unsigned *__restrict__ memb, u64 *__restrict__ mask) {
+__global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, int dir, int wtiles, int steps,
+                                                         const unsigned *__restrict__ memb, unsigned *__restrict__ bits) {
+    constexpr int W = MEMB_WORDS;
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= (long long)tiles * steps) return;
-    const int tile = (int)(wv / steps), step = (int)(wv - (long long)tile * steps);
-    constexpr int W = MEMB_WORDS;
-    const int n = 32 * tile + (lane & 31);
+    if (wv >= (long long)wtiles * steps) return;
+    const int wt = (int)(wv / steps), step = (int)(wv - (long long)wt * steps);
     const int nkr = ks * rp;
-    u64 mine = 0;
+    unsigned word = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int kk = 32 * step + 16 * (i >> 3) + 8 * (lane >> 5) + (i & 7);
+    for (int i = 0; i < 32; ++i) {
+        const int tt = i >> 4, j = (i >> 3) & 1, e = i & 7;
+        const int n = 64 * wt + 32 * j + (lane & 31);
+        const int kk = 32 * step + 16 * tt + 8 * (lane >> 5) + e;
         const int pt = dir ? n : kk, kr = dir ? kk : n;
-        bool bit = false;
         if (pt < p && kr < nkr) {
             const int r = kr % rp;
-            bit = (memb[((size_t)b * p + pt) * W + (r >> 5)] >> (r & 31)) & 1u;
+            word |= ((memb[((size_t)b * p + pt) * W + (r >> 5)] >> (r & 31)) & 1u) << i;
         }
-        const u64 word = __ballot(bit);
-        if (lane == i) mine = word;
     }
-    if (lane < 16) mask[(((size_t)b * tiles + tile) * steps + step) * 16 + lane] = mine;
+    bits[(((size_t)b * wtiles + wt) * steps + step) * 64 + lane] = word;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -226,9 +230,10 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int 
 // the stored operand: T[b][m][l][na] (dY [b,o,p,a] or G [b,o,(k,r),a]) -> per (cloud, anchor) the row scales and the two
 // fp16 planes in fragment order
 // ------------------------------------------------------------------------------------------------------------------------
-// scale[(b na + a) m + row] = 2^(14 - e) for max_l |T[b][row][l][a]| in [2^e, 2^(e+1)).  One block per (b, row): thread
+// scale[(b na + a) m + row] = scale2[(b m + row) na + a] = 2^(14 - e) for max_l |T[b][row][l][a]| in [2^e, 2^(e+1)).  One block per (b, row): thread
 // (anchor quad aq, lane group pg) walks the row's float4 pieces aq + nq (pg + G j): consecutive threads, consecutive pieces
-__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, const f32x4 *__restrict__ T, float *__restrict__ scale) {
+__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, const f32x4 *__restrict__ T, float *__restrict__ scale,
+                                                           float *__restrict__ scale2) {
     __shared__ unsigned s[256][4];
     const int nq = na >> 2, G = 256 / nq, b = blockIdx.y, row = blockIdx.x, t = threadIdx.x;
     const int aq = t % nq, pg = t / nq;
@@ -248,34 +253,37 @@ __global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na,
     if (t < na) {
         unsigned v = 0;
         for (int g = 0; g < G; ++g) v = max(v, s[g * nq + (t >> 2)][t & 3]);
-        scale[((size_t)b * na + t) * m + row] = pow2_scale(__uint_as_float(v));
+        const float sc = pow2_scale(__uint_as_float(v));
+        scale[((size_t)b * na + t) * m + row] = sc;            // [b][a][row]: the product's epilogue
+        scale2[((size_t)b * m + row) * na + t] = sc;           // [b][row][a]: the split
     }
 }
 
 // planes[z = b na + a][k-block kb][row tile mt][plane][lane] (16 bytes): lane (i = lane & 31, kg = lane >> 5) holds the 8
 // contraction elements 16 kb + 8 kg .. + 7 of row 32 mt + i -- what a lane of v_mfma_f32_32x32x16_f16 takes as its A operand.
-// One wave per (b, mt, kb); a lane reads its row's 8 x 16-byte pieces per anchor quad (240-byte stride: the lines are
-// shared with the wave's next iterations) and writes whole 1 KB runs.
+// One block per (b, mt, kb): thread (anchor quad aq = t % nq, row group t / nq) takes the 8 elements of (row, kg) for its four
+// anchors -- 8 float4 loads 4 na bytes apart, the nq threads of a row covering each element's 4 na contiguous bytes -- and
+// writes its 8 pieces; the 64 pieces of a 1 KB run come from one block within a few hundred cycles.
 __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, const f32x4 *__restrict__ T,
-                                                          const float *__restrict__ scale, u32x4 *__restrict__ planes) {
-    const int lane = threadIdx.x & 63, b = blockIdx.z, mt = blockIdx.y;
-    const int kb = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (kb >= kb_total) return;
-    const int nq = na >> 2, row = 32 * mt + (lane & 31), l0 = 16 * kb + 8 * (lane >> 5);
+                                                          const float *__restrict__ scale2, u32x4 *__restrict__ planes) {
+    const int b = blockIdx.z, mt = blockIdx.y, kb = blockIdx.x, t = threadIdx.x;
+    const int nq = na >> 2, RG = 256 / nq;                      // rows per pass
+    const int aq = t % nq, rr = t / nq;
+    if (rr >= RG) return;
     const int MT = m >> 5;
-    const f32x4 *src = T + ((size_t)b * m + row) * (size_t)l * nq;
-    for (int aq = 0; aq < nq; ++aq) {
+    for (int it = rr; it < 64; it += RG) {                      // item = (row i, k half kg)
+        const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
+        const f32x4 *src = T + (((size_t)b * m + row) * (size_t)l + l0) * nq + aq;
         f32x4 q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = (l0 + e < l) ? src[(size_t)(l0 + e) * nq + aq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 8; ++e) q[e] = (l0 + e < l) ? src[(size_t)e * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale2 + ((size_t)b * m + row) * na + 4 * aq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int a = 4 * aq + j;
-            const float sc = scale[((size_t)b * na + a) * m + row];
             unsigned h[4], lo[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2(q[2 * e][j] * sc, q[2 * e + 1][j] * sc, h[e], lo[e]);
-            u32x4 *dst = planes + ((((size_t)b * na + a) * kb_total + kb) * MT + mt) * 128 + lane;
+            for (int e = 0; e < 4; ++e) split2(q[2 * e][j] * sc[j], q[2 * e + 1][j] * sc[j], h[e], lo[e]);
+            u32x4 *dst = planes + ((((size_t)b * na + 4 * aq + j) * kb_total + kb) * MT + mt) * 128 + (i + 32 * kg);
             dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
             dst[64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
         }
@@ -304,22 +312,26 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int
 // ------------------------------------------------------------------------------------------------------------------------
 struct KcArgs {
     int MT, N, KS, na, zcount;            // row tiles of the stored operand, columns, k-steps, anchors per cloud, clouds x anchors
-    int tiles_m, blocks_n, mask_tiles;    // row blocks (MT / MI), column blocks (of 4 wave tiles), 32-column tiles in the mask table
+    int tiles_m, blocks_n, mask_tiles;    // row blocks (MT / MI), column blocks (of 4 wave tiles), wave tiles in the mask table
     const u32x4 *A;                       // planes [z][2 KS][MT][2][64]
     const float *scale;                   // [z][32 MT]
     const f32x4 *strT; long long strB, strA;     // k-side table: element kk of (cloud, anchor) at strT[b strB + a strA + kk]
     const f32x4 *colT; long long colB, colA;     // column-side table
-    const u64 *mask;                      // [b][mask_tiles][KS][16]
+    const unsigned *mask;                 // [b][mask_tiles wave tiles][KS][64 lanes] mask bits
     float neg_inv_sigma;                  // FORM 1
     float *C; long long cB, cA, ldm; int rp; long long kstride;     // element (row, n) of (b, a) at C[b cB + a cA + row ldm + (n / rp) kstride + n % rp]
 };
 
-template <int MI, int FORM>
+// DBG (timing ablations, `make ABLATION=1` + EAP_DENSE_DEBUG, WRONG results): 1 = no mask (all lanes kept), 2 = no k-side table
+// reads (constants), 4 = no weight evaluation at all (the B fragments of the prologue for every k-block), 8 = no DMA inside the k-loop,
+// 16 = no fragment reads of the stored operand inside the k-loop
+template <int MI, int FORM, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
+    static_assert(MI == 8, "the DMA piece schedule below assumes 8 KB of the stored operand per wave and k-step");
     constexpr unsigned SUB_A = MI * 2048u;                 // bytes of the stored operand per k-block (16 k) of a block
     constexpr unsigned STR_OFF = 2 * SUB_A;                // the k-side table's slice: 2 x 256 bytes (+ 2 x 256 of duplicate landing space)
-    constexpr unsigned STAGE = 2 * SUB_A + 1024u;
-    constexpr int PIECES = 4 * MI, PPW = PIECES / 4;       // 1 KB DMA pieces per k-step / per wave
+    constexpr unsigned BIT_OFF = STR_OFF + 1024u;          // the mask bits of the step: one dword per lane and wave
+    constexpr unsigned STAGE = BIT_OFF + 1024u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // ---- block -> (z, row block, column block): an XCD owns whole (cloud, anchor) pairs, so the stored operand of a pair is
@@ -351,25 +363,41 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     f32x4 cc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) cc[j] = colz[min(64 * wt + 32 * j + li, g.N - 1)];
-    cu64p mrow[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) mrow[j] = (cu64p)(uintptr_t)(g.mask + ((size_t)b * g.mask_tiles + min(2 * wt + j, g.mask_tiles - 1)) * (size_t)g.KS * 16);
+    const float nis = g.neg_inv_sigma;
 
-    // ---- DMA: piece q of a k-step = k-block q / (2 MI), 1 KB run q % (2 MI) of the block's 2 MI KB; wave w moves pieces w PPW .. ----
-    const unsigned char *Az = reinterpret_cast<const unsigned char *>(g.A) + ((size_t)z * 2 * g.KS * g.MT + (size_t)bm * MI) * 2048u;
-    const size_t kb_bytes = (size_t)g.MT * 2048u;
-    const unsigned char *strz = reinterpret_cast<const unsigned char *>(g.strT + b * g.strB + a * g.strA);
+    // ---- DMA.  Per k-step a wave moves 10 pieces: its 8 KB of the block's 32 KB of the stored operand (contiguous in memory AND in
+    //      the stage: the immediate offset of global_load_lds goes into both addresses, tools/microbench/glds_offset.hip, so four
+    //      pieces share one M0 and one base), the k-side table's slice (2 x 16 float4; waves 0, 1 land k-block `wave`, waves 2, 3 a
+    //      duplicate nobody reads: uniform piece counts, one s_waitcnt immediate for all waves) and its own 256 bytes of mask bits ----
+    const unsigned char *Aw = reinterpret_cast<const unsigned char *>(g.A) + ((size_t)z * 2 * g.KS * g.MT + (size_t)bm * MI) * 2048u
+                              + (size_t)(wave >> 1) * ((size_t)g.MT * 2048u) + (size_t)(wave & 1) * 8192u;      // k-block wave / 2, runs 8 (wave & 1) ..
+    const size_t step_bytes = (size_t)g.MT * 4096u;                                                              // two k-blocks
+    const unsigned char *strw = reinterpret_cast<const unsigned char *>(g.strT + b * g.strB + a * g.strA) + (size_t)(wave & 1) * 256u;
+    const unsigned char *bitw = reinterpret_cast<const unsigned char *>(g.mask) + ((size_t)b * g.mask_tiles + min(wt, g.mask_tiles - 1)) * (size_t)g.KS * 256u;
     const unsigned lds0 = lds_addr(smem);
+    const unsigned ldsA = lds0 + (unsigned)(wave >> 1) * SUB_A + (unsigned)(wave & 1) * 8192u;
     const unsigned voff16 = (unsigned)lane * 16u, voff4 = (unsigned)lane * 4u;
-    auto issue = [&](int step, int stage) __attribute__((always_inline)) {
-        const unsigned dst = lds0 + (unsigned)stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int q = wave * PPW + i, sub = q / (2 * MI), r = q % (2 * MI);
-            glds16s(Az + (size_t)(2 * step + sub) * kb_bytes + (size_t)r * 1024u, voff16, dst + (unsigned)sub * SUB_A + (unsigned)r * 1024u);
+    // (M0 is the compiler's scratch register, nothing of ours lives in it across statements: set in the statement that uses it)
+#define DMA2(src, dst, o0, o1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #o0 "\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #o1 \
+                                            :: "v"(voff16), "s"(src), "s"(dst) : "memory")
+#define DMA1(src, dst, o0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #o0 :: "v"(voff16), "s"(src), "s"(dst) : "memory")
+#define DMA4B(src, dst) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff4), "s"(src), "s"(dst) : "memory")
+    auto dma_slot = [&](int step, unsigned stage_off, int slot) __attribute__((always_inline)) {
+        const unsigned char *src = Aw + (size_t)step * step_bytes;
+        const unsigned dst = ldsA + stage_off;
+        if (slot == 0) DMA2(src, dst, 0, 1024);
+        if (slot == 1) DMA2(src, dst, 2048, 3072);
+        if (slot == 2) DMA1(src + 4096, dst + 4096u, 0);
+        if (slot == 3) DMA2(src + 4096, dst + 4096u, 1024, 2048);
+        if (slot == 4) DMA1(src + 4096, dst + 4096u, 3072);
+        if (slot == 5) {
+            DMA4B(strw + (size_t)step * 512u, lds0 + stage_off + STR_OFF + (unsigned)wave * 256u);
+            DMA4B(bitw + (size_t)step * 256u, lds0 + stage_off + BIT_OFF + (unsigned)wave * 256u);
         }
-        // the k-side table: 2 x 16 float4; waves 0, 1 land k-block `wave`, waves 2, 3 a duplicate nobody reads (uniform piece counts)
-        glds4s(strz + (size_t)(2 * step + (wave & 1)) * 256u, voff4, dst + STR_OFF + (unsigned)wave * 256u);
+    };
+    auto issue = [&](int step, unsigned stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int slot = 0; slot < 6; ++slot) dma_slot(step, stage_off, slot);
     };
 
     f32x16 acc[MI][2];
@@ -386,23 +414,30 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) f[i] = *reinterpret_cast<const u32x4 *>(st + (unsigned)sub * SUB_A + (unsigned)(2 * i + plane) * 1024u + (unsigned)lane * 16u);
     };
-    const float nis = g.neg_inv_sigma;
-    // weights of tile j, elements e0, e0 + 1 of a k-block (k-side entries sv[e]) -> word e0 / 2 of h, l
-    auto gen2 = [&](const f32x4 (&sv)[8], cu64p mk, int j, int e0, BFrag &f) __attribute__((always_inline)) {
+    auto frag_loop = [&](const unsigned char *st, int sub, int plane, u32x4 (&f)[MI]) __attribute__((always_inline)) {
+        if constexpr (DBG & 16) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f[i] = (u32x4){0x3c003c00u + (unsigned)sub, 0x3c003c00u, 0x3c003c00u + (unsigned)plane, 0x3c003c00u};
+        } else frag_a(st, sub, plane, f);
+    };
+    // weights of tile j, elements e0, e0 + 1 of a k-block (k-side entries sv[e]; mask bits 16 tb + 8 j + e of mb) -> word e0 / 2 of h, l.
+    // The mask is the fma's addend: 1.0 for a list member, 0.0 otherwise -- the clamp then returns 0 (the product term is <= 0).
+    auto gen2 = [&](const f32x4 (&sv)[8], unsigned mb, int tb, int j, int e0, BFrag &f, bool prologue = false) __attribute__((always_inline)) {
+        if ((DBG & 4) && !prologue) return;
         float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const f32x4 s = sv[e0 + e];
-            float x;
+            const int keep = (DBG & 1) ? -1 : ((int)(mb << (31 - (16 * tb + 8 * j + e0 + e))) >> 31);
+            const float one = __int_as_float(keep & 0x3f800000);
             if constexpr (FORM == 1) {
                 const float tx = cc[j].x - s.x, ty = cc[j].y - s.y, tz = cc[j].z - s.z;
                 const float d2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-                asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(x) : "v"(d2), "v"(nis));
+                v[e] = __builtin_amdgcn_fmed3f(fmaf(d2, nis, one), 0.f, 1.f);                    // (v_fma_f32 ... clamp)
             } else {
-                const float y = fmaf(cc[j].y, s.y, fmaf(cc[j].x, s.x, cc[j].w + s.w));
-                asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(x) : "v"(cc[j].z), "v"(s.z), "v"(y));
+                const float y = fmaf(cc[j].y, s.y, fmaf(cc[j].x, s.x, (cc[j].w - 1.0f) + s.w));
+                v[e] = __builtin_amdgcn_fmed3f(fmaf(cc[j].z, s.z, y) + one, 0.f, 1.f);
             }
-            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(v[e]) : "v"(x), "s"(mk[e0 + e]));
         }
         unsigned h, l;
         split2(v[0], v[1], h, l);
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     };
     auto load_sv = [&](const f32x4 *str, f32x4 (&sv)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = str[8 * kg + e];
+        for (int e = 0; e < 8; ++e) sv[e] = (DBG & 2) ? (f32x4){0.01f * (float)e, 0.02f, 0.03f * (float)kg, 0.f} : str[8 * kg + e];
     };
     auto mm = [&](const u32x4 &fa, const u32x4 &fb, f32x16 &c) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), c, 0, 0, 0);
@@ -419,80 +454,102 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
 #define SB() __builtin_amdgcn_sched_barrier(0)
     // issue order inside a product: one matrix instruction, then NV vector instructions in its shadow (hipcc on its own puts the
     // weight evaluation in front of the sixteen matrix instructions; one wave per SIMD has nobody else to fill the pipe)
-#define PIPE(NV)                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2 * MI; ++i_) {                       \
+#define PIPE_HALF(NV, ND)                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) {                           \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        if constexpr ((ND) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (ND) > 0 ? (ND) : 1, 0);  \
         __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                       \
     }
-    // One k-block: acc += A(st, sub) x Bc; meanwhile the weights of the NEXT k-block (k-side entries `nstr`, mask words `nm0`,
-    // `nm1`) are generated into Bn in eight portions and the next k-block's first plane fragments are read into `ah`.
-    auto kblock = [&](const unsigned char *st, int sub, const unsigned char *nst, int nsub, const f32x4 *nstr, cu64p nm0, cu64p nm1,
-                      const BFrag &Bc, BFrag &Bn, u32x4 (&ah)[MI]) __attribute__((always_inline)) {
+#define PIPE(NV, ND0, ND1) PIPE_HALF(NV, ND0) PIPE_HALF(NV, ND1)
+    // One k-block u: acc += A(u) x Bc.  In its shadow: the weights of k-block u + 1 are generated into Bn (k-side entries `sv`, read
+    // during the previous k-block; mask bits of `mb`) in eight portions spread over the three products; the second plane of A(u) and
+    // the k-side entries of k-block u + 2 (`nsv`) are read at the head of the first product, the first plane of A(u + 1) between
+    // the second and the third -- no LDS read is waited for less than a product after its issue.
+    auto kblock = [&](const unsigned char *st, int sub, const unsigned char *nst, int nsub, const f32x4 *nnstr, unsigned mb, int tb,
+                      const BFrag &Bc, BFrag &Bn, u32x4 (&ah)[MI], const f32x4 (&sv)[8], f32x4 (&nsv)[8], auto dma) __attribute__((always_inline)) {
         u32x4 al[MI];
-        f32x4 sv[8];
-        frag_a(st, sub, 1, al);
-        load_sv(nstr, sv);
         SB();
+        frag_loop(st, sub, 1, al);
+        load_sv(nnstr, nsv);
+        dma(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.h[0], acc[i][0]); mm(ah[i], Bc.h[1], acc[i][1]); }
-        gen2(sv, nm0, 0, 0, Bn); gen2(sv, nm0, 0, 2, Bn); gen2(sv, nm0, 0, 4, Bn);
-        PIPE(FORM ? 4 : 3)
+        gen2(sv, mb, tb, 0, 0, Bn); gen2(sv, mb, tb, 0, 2, Bn); gen2(sv, mb, tb, 0, 4, Bn);
+        PIPE(FORM ? 4 : 3, 1, 1)             // the 16 LDS reads one per matrix instruction
         SB();
+        dma(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.l[0], acc[i][0]); mm(ah[i], Bc.l[1], acc[i][1]); }
-        gen2(sv, nm0, 0, 6, Bn); gen2(sv, nm1, 1, 0, Bn); gen2(sv, nm1, 1, 2, Bn);
-        PIPE(FORM ? 4 : 3)
+        gen2(sv, mb, tb, 0, 6, Bn); gen2(sv, mb, tb, 1, 0, Bn); gen2(sv, mb, tb, 1, 2, Bn);
+        PIPE(FORM ? 4 : 3, 0, 0)
         SB();
-        frag_a(nst, nsub, 0, ah);
-        SB();
+        frag_loop(nst, nsub, 0, ah);
+        dma(2);
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(al[i], Bc.h[0], acc[i][0]); mm(al[i], Bc.h[1], acc[i][1]); }
-        gen2(sv, nm1, 1, 4, Bn); gen2(sv, nm1, 1, 6, Bn);
-        PIPE(FORM ? 3 : 2)
+        gen2(sv, mb, tb, 1, 4, Bn); gen2(sv, mb, tb, 1, 6, Bn);
+        PIPE(FORM ? 3 : 2, 1, 0)             // the next k-block's 8 fragment reads behind the first 8 matrix instructions
         SB();
     };
 
-    // ---- prologue: stages 0, 1 <- k-steps 0, 1 ----
+    // ---- prologue: stages 0, 1, 2 <- k-steps 0, 1, 2 (past the last step: the last step again, into a stage nobody reads) ----
+    const int last = g.KS - 1;
     issue(0, 0);
-    if (g.KS > 1) issue(1, 1);
+    issue(min(1, last), STAGE);
+    issue(min(2, last), 2 * STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // (a wave whose 64 columns lie past N runs the same instruction stream on clamped columns and an all-zero mask: a branch
     // around the k-blocks would put the 256 accumulators across a control-flow join)
     BFrag B0, B1;
     u32x4 ah[MI];
+    f32x4 sv[8], sw[8];
+    unsigned mbc = *reinterpret_cast<const unsigned *>(smem + BIT_OFF + (unsigned)t * 4u);        // mask bits of step 0
     {
-        f32x4 sv[8];
         load_sv(reinterpret_cast<const f32x4 *>(smem + STR_OFF), sv);
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) { gen2(sv, mrow[0], 0, e, B0); gen2(sv, mrow[1], 1, e, B0); }
+        for (int e = 0; e < 8; e += 2) { gen2(sv, mbc, 0, 0, e, B0, true); gen2(sv, mbc, 0, 1, e, B0, true); }
+        if constexpr (DBG & 4) B1 = B0;
         frag_a(smem, 0, 0, ah);
+        load_sv(reinterpret_cast<const f32x4 *>(smem + STR_OFF) + 16, sv);                       // k-block 1
     }
 
-    // ---- k-loop: the barrier that opens step s certifies stage (s + 1) % 3 (its DMA was issued a whole step ago) and frees
-    //      stage (s + 2) % 3 (read during step s - 1) for the DMA of step s + 2 ----
-    unsigned s0 = 0, s1 = STAGE, s2 = 2 * STAGE;
+    // ---- k-loop, four stages.  The barrier that opens step s certifies stage (s + 1) % 4 -- its pieces were issued during step
+    //      s - 2 and the counted wait in front of the barrier leaves only step s - 1's 10 pieces (k-step s + 2) in flight -- and frees
+    //      stage (s + 3) % 4 (read during step s - 1) for the pieces of k-step s + 3, which are issued one or two at a time at the
+    //      head of the six products of the step ----
+    unsigned s0 = 0, s1 = STAGE, s2 = 2 * STAGE, s3 = 3 * STAGE;
     for (int s = 0; s < g.KS; ++s) {
         if (s > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (s + 2 < g.KS) issue(s + 2, (s + 2) % 3);
-        {
-            const f32x4 *str0 = reinterpret_cast<const f32x4 *>(smem + s0 + STR_OFF);
-            const f32x4 *str1 = reinterpret_cast<const f32x4 *>(smem + s1 + STR_OFF);
-            cu64p m0 = mrow[0] + (size_t)s * 16, m1 = mrow[1] + (size_t)s * 16;
-            // k-block 0 of the step; generates k-block 1 (this stage's second table slice, mask words 8..15)
-            kblock(smem + s0, 0, smem + s0, 1, str0 + 16, m0 + 8, m1 + 8, B0, B1, ah);
-            // k-block 1; generates k-block 0 of step s + 1 (the certified next stage; past the end: stale data nobody uses)
-            kblock(smem + s0, 1, smem + s1, 0, str1, m0 + 16, m1 + 16, B1, B0, ah);
-        }
-        { const unsigned r = s0; s0 = s1; s1 = s2; s2 = r; }
+        const int nxt = min(s + 3, last);
+        const unsigned dst = s3;
+        const unsigned mbn = *reinterpret_cast<const unsigned *>(smem + s1 + BIT_OFF + (unsigned)t * 4u);      // mask bits of step s + 1
+        const f32x4 *str1 = reinterpret_cast<const f32x4 *>(smem + s1 + STR_OFF);
+        // k-block 2s: generates k-block 2s + 1 (sv = its k-side entries, mask bits 16..31 of this step's dword); reads the entries of
+        // k-block 2s + 2 (first slice of the next stage) for the next call
+        kblock(smem + s0, 0, smem + s0, 1, str1, mbc, 1, B0, B1, ah, sv, sw, [&](int slot) __attribute__((always_inline)) {
+            if constexpr (!(DBG & 8)) dma_slot(nxt, dst, slot);
+        });
+        // k-block 2s + 1: generates k-block 2s + 2 (mask bits 0..15 of the NEXT step's dword); reads the entries of k-block 2s + 3
+        // (past the end: stale data nobody uses)
+        kblock(smem + s0, 1, smem + s1, 0, str1 + 16, mbn, 0, B1, B0, ah, sw, sv, [&](int slot) __attribute__((always_inline)) {
+            if constexpr (!(DBG & 8)) dma_slot(nxt, dst, 3 + slot);
+        });
+        mbc = mbn;
+        { const unsigned r = s0; s0 = s1; s1 = s2; s2 = s3; s3 = r; }
     }
 #undef SB
 #undef PIPE
+#undef PIPE_HALF
+#undef DMA1
+#undef DMA2
+#undef DMA4B
 
-    // ---- epilogue: the scales come off (two factors), D[i][j] of a 32 x 32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 kg ----
+    // ---- epilogue: the row scales come off, D[i][j] of a 32 x 32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 kg ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead pieces of the last steps land in the ring: before it is reused
     __syncthreads();
     float *isc = reinterpret_cast<float *>(smem);
     if (t < 32 * MI) isc[t] = 1.0f / g.scale[(size_t)z * (32 * g.MT) + 32 * MI * bm + t];
@@ -515,19 +572,19 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     }
 }
 
-template <int MI, int FORM>
+template <int MI, int FORM, int DBG = 0>
 int kc_launch(const KcArgs &g, hipStream_t s) {
-    constexpr size_t shmem = 3 * (2 * (size_t)MI * 2048u + 1024u);
+    constexpr size_t shmem = 4 * (2 * (size_t)MI * 2048u + 2048u);
     static bool set = false;
     if (!set) {
-        if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_gemm_kernel<MI, FORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_gemm_kernel<MI, FORM, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       (int)shmem), "so3_dense: shared memory attribute"))
             return e;
         set = true;
     }
     const long long blocks = (long long)g.zcount * g.tiles_m * g.blocks_n;
     if (blocks > 0x7fffffffLL) return eap::bad_arg("so3_dense: too many workgroups");
-    hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
+    hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM, DBG>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
     eap::set_kernel(FORM ? "kc_gemm_kernel<8,1>" : "kc_gemm_kernel<8,0>");
     return eap::check_launch("so3_dense product");
 }
@@ -553,8 +610,8 @@ extern "C" int eap_so3_dense_supported(int p, int na, int ks, int rp, int o) {
 
 extern "C" int64_t eap_so3_dense_mask_words(int b, int p, int ks, int rp, int dir) {
     const int n = dir ? p : ks * rp, kd = dir ? ceil_to(ks * rp, KC_BK) : p;
-    const int tiles = 8 * ((n + 255) / 256), steps = kd / KC_BK;
-    return (int64_t)b * tiles * steps * 16 + 16;
+    const int wtiles = 4 * ((n + 255) / 256), steps = kd / KC_BK;
+    return ((int64_t)b * wtiles * steps * 64 + 1) / 2;               // (in 64-bit words: the table holds 32-bit words)
 }
 
 extern "C" int eap_so3_dense_member(int b, int p, int n_sup, int nn, int rp, int rows_ld, const int32_t *idx, const int32_t *rows,
@@ -573,12 +630,9 @@ extern "C" int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const 
     if (b <= 0) return 0;
     if (!eap_so3_dense_supported(p, 4, ks, rp, 256) || b > 65535) return eap::bad_arg("so3_dense_masks: shape not taken");
     const int n = dir ? p : ks * rp, kd = dir ? ceil_to(ks * rp, KC_BK) : p;
-    const int tiles = 8 * ((n + 255) / 256), steps = kd / KC_BK;
-    hipStream_t s = eap::S(stream);
-    // the 16 words past the end: read (never used) by the last k-step's look-ahead
-    if (int e = eap::hip_fail(hipMemsetAsync(mask + (size_t)b * tiles * steps * 16, 0, 16 * sizeof(uint64_t), s), "so3_dense_masks memset")) return e;
-    hipLaunchKernelGGL(dense_mask_kernel, dim3(eap::cdiv((long long)tiles * steps, 4), b), dim3(256), 0, s, p, ks, rp, dir, tiles, steps, memb,
-                       reinterpret_cast<u64 *>(mask));
+    const int wtiles = 4 * ((n + 255) / 256), steps = kd / KC_BK;
+    hipLaunchKernelGGL(dense_mask_kernel, dim3(eap::cdiv((long long)wtiles * steps, 4), b), dim3(256), 0, eap::S(stream), p, ks, rp, dir, wtiles, steps, memb,
+                       reinterpret_cast<unsigned *>(mask));
     return eap::check_launch("so3_dense_masks");
 }
 
@@ -603,9 +657,10 @@ extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, const float 
         return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source");
     hipStream_t s = eap::S(stream);
     const int kb_total = ceil_to(l, KC_BK) / 16;
-    hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, reinterpret_cast<const f32x4 *>(src), scale);
-    hipLaunchKernelGGL(dense_split_kernel, dim3(eap::cdiv(kb_total, 4), m / 32, b), dim3(256), 0, s, m, l, na, kb_total,
-                       reinterpret_cast<const f32x4 *>(src), scale, reinterpret_cast<u32x4 *>(planes));
+    float *scale2 = scale + (size_t)b * na * m;
+    hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, reinterpret_cast<const f32x4 *>(src), scale, scale2);
+    hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total,
+                       reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
     return eap::check_launch("so3_dense_split");
 }
 
@@ -621,7 +676,7 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     g.KS = (dir ? kd_pad : p) / KC_BK;
     g.tiles_m = o / 256;
     g.blocks_n = (g.N + 255) / 256;
-    g.mask_tiles = 8 * g.blocks_n;
+    g.mask_tiles = 4 * g.blocks_n;
     g.A = reinterpret_cast<const u32x4 *>(planes);
     g.scale = scale;
     const f32x4 *ptT = reinterpret_cast<const f32x4 *>(pt), *krT = reinterpret_cast<const f32x4 *>(kr);
@@ -634,9 +689,24 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
         g.colT = ptT; g.colB = p_pad; g.colA = 0;
         g.cB = (long long)na * o * p; g.cA = (long long)o * p; g.ldm = p; g.rp = p; g.kstride = 0;
     }
-    g.mask = reinterpret_cast<const u64 *>(mask);
+    g.mask = reinterpret_cast<const unsigned *>(mask);
     g.C = out;
     g.neg_inv_sigma = -1.0f / sigma;
+#ifdef EAP_ABLATION
+    if (const char *d = getenv("EAP_DENSE_DEBUG")) {
+        switch (atoi(d)) {
+            case 1: return kc_launch<8, 1, 1>(g, eap::S(stream));
+            case 2: return kc_launch<8, 1, 2>(g, eap::S(stream));
+            case 3: return kc_launch<8, 1, 3>(g, eap::S(stream));
+            case 4: return kc_launch<8, 1, 4>(g, eap::S(stream));
+            case 8: return kc_launch<8, 1, 8>(g, eap::S(stream));
+            case 16: return kc_launch<8, 1, 16>(g, eap::S(stream));
+            case 20: return kc_launch<8, 1, 20>(g, eap::S(stream));
+            case 28: return kc_launch<8, 1, 28>(g, eap::S(stream));
+            default: break;
+        }
+    }
+#endif
     return g_dense_form ? kc_launch<8, 1>(g, eap::S(stream)) : kc_launch<8, 0>(g, eap::S(stream));
 }
 

@@ -528,10 +528,10 @@ class DenseGeometry:
 
 
 def so3_dense_split(src):
-    """src [b,m,l,na] -> (scale [b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
+    """src [b,m,l,na] -> (scale [2,b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
     fragment order)."""
     b, m, l, na = src.shape
-    scale = torch.empty(b, na, m, dtype=torch.float32, device=src.device)
+    scale = torch.empty(2, b, na, m, dtype=torch.float32, device=src.device)      # [0]: [b,na,m]; [1]: the same numbers as [b,m,na]
     planes = torch.empty(b * na * m * ((l + 31) // 32 * 32), dtype=torch.int32, device=src.device)       # 4 bytes per element
     call('eap_so3_dense_split_f32', src, b, m, l, na, _ptr(src), _ptr(scale), _ptr(planes))
     return scale, planes
@@ -543,17 +543,20 @@ def so3_dense_bwd(gy, geo):
     scale, planes = so3_dense_split(gy)
     z = torch.empty(b, o, geo.ks, na, geo.rp, dtype=torch.float32, device=gy.device)
     call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr), _ptr(geo.mask(0)),
-         _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp})
+         _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
+                       'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
     return z
 
 
-def so3_dense_fwd(g, geo, p):
-    """g [b,o,ks*rp,na] (= W . F over the referenced rows) -> y [b,o,p,na]."""
+def so3_dense_fwd(g, geo, p, c=0):
+    """g [b,o,ks*rp,na] (= W . F over the referenced rows, F with c channels) -> y [b,o,p,na].  (c only prices the launch for
+    bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)"""
     b, o, kd, na = g.shape
     scale, planes = so3_dense_split(g)
     yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
     call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr), _ptr(geo.mask(1)),
-         _ptr(yt), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp})
+         _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp), 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
+                        'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
     call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y))

@@ -641,7 +641,7 @@ def _dense_forward(feats, W, rows, geo, p):
     W3 = W.view(o, c, ks).permute(0, 2, 1).reshape(o * ks, c).contiguous()
     g = torch.empty(b, o * ks, rp * na, dtype=torch.float32, device=feats.device)
     _hip.gemm(0, 0, o * ks, rp * na, c, W3, c, 0, fc, rp * na, c * rp * na, g, rp * na, o * ks * rp * na, b)
-    return _hip.so3_dense_fwd(g.view(b, o, ks * rp, na), geo, p)
+    return _hip.so3_dense_fwd(g.view(b, o, ks * rp, na), geo, p, c)
 
 
 class _InterConv(torch.autograd.Function):

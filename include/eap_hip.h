@@ -337,10 +337,10 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *                             not representable by a 0/1 mask), 2 = a list names a row outside rows[:, :rp] -- such clouds
  *                             must take the list kernels
  *   eap_so3_dense_mask_words  uint64 words of the mask table of one direction; eap_so3_dense_masks fills it:
- *                             [b][32-column tile][k-step of 32][16] lane masks of the product kernel
+ *                             [b][64-column wave tile][k-step of 32][64 lanes] one bit per weight a lane of the product kernel generates
  *   eap_so3_dense_tables_f32  centre [b,4] (centroid of the support points), pt float4 [b, ceil32(p)] and
  *                             kr float4 [b, na, ceil32(ks rp)]: the two sides of the weight (centred coordinates), evaluated in float64
- *   eap_so3_dense_split_f32   src [b,m,l,na] -> scale [b,na,m] (power of two per row) and the two fp16 planes of the scaled
+ *   eap_so3_dense_split_f32   src [b,m,l,na] -> scale [2][b,na,m] (power of two per row; the second copy as [b,m,na]) and the two fp16 planes of the scaled
  *                             rows in the product kernel's fragment order: 4 b na m ceil32(l) bytes
  *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1)
  *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na] */

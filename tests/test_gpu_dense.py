@@ -85,6 +85,8 @@ def test_split_planes_reconstruct_the_operand(dev):
     x = torch.randn(b, m, l, na, device=dev, generator=gen) * torch.exp(3 * torch.randn(b, m, 1, na, device=dev, generator=gen))
     x[0, 3] = 0.0
     scale, planes = _hip.so3_dense_split(x)
+    assert torch.equal(scale[1].view(b, m, na), scale[0].permute(0, 2, 1))
+    scale = scale[0]
     lp = (l + 31) // 32 * 32
     pl = planes.view(torch.float16).view(b, na, lp // 16, m // 32, 2, 64, 8).float()       # [b,a,kb,mt,plane,lane,e]
     v = pl[:, :, :, :, 0] + pl[:, :, :, :, 1]                                              # [b,a,kb,mt,lane,e]

@@ -27,7 +27,7 @@ head.wait()
 print('rows per cloud', head.n_rows.tolist(), 'rp', rp, 'dense possible', head.dense_possible())
 
 
-def timed(fn, n=5):
+def timed(fn, n=int(os.environ.get('REPS', 5))):
     ts = []
     for _ in range(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,7 +39,7 @@ def timed(fn, n=5):
 gen = torch.Generator(device=dev).manual_seed(1)
 gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
 g = torch.randn(B, o, KS * rp, NA, device=dev, generator=gen)
-for form in (1, 0):
+for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
     _hip.lib.eap_so3_dense_form(form)
     geo = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, rk, sigma, NN)
     t_tab, _ = timed(lambda: _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, rk, sigma, NN))

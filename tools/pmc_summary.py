@@ -8,7 +8,7 @@ for d in sys.argv[1:]:
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         dur = collections.defaultdict(dict)
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].split('(')[0][-70:]
+            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][-70:]
             per[k][r['Counter_Name']] += float(r['Counter_Value'])
             dur[k][r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         for k, v in per.items():
