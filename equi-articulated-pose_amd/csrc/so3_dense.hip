@@ -327,7 +327,8 @@ struct KcArgs {
 // 16 = no fragment reads of the stored operand inside the k-loop
 template <int MI, int FORM, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
-    static_assert(MI == 8, "the DMA piece schedule below assumes 8 KB of the stored operand per wave and k-step");
+    static_assert(MI == 8 || MI == 4, "the DMA piece schedule below: 8 or 4 KB of the stored operand per wave and k-step");
+    constexpr unsigned WB = MI * 1024u;                    // bytes of the stored operand a wave moves per k-step
     constexpr unsigned SUB_A = MI * 2048u;                 // bytes of the stored operand per k-block (16 k) of a block
     constexpr unsigned STR_OFF = 2 * SUB_A;                // the k-side table's slice: 2 x 256 bytes (+ 2 x 256 of duplicate landing space)
     constexpr unsigned BIT_OFF = STR_OFF + 1024u;          // the mask bits of the step: one dword per lane and wave
@@ -367,15 +368,15 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
 
     // ---- DMA.  Per k-step a wave moves 10 pieces: its 8 KB of the block's 32 KB of the stored operand (contiguous in memory AND in
     //      the stage: the immediate offset of global_load_lds goes into both addresses, tools/microbench/glds_offset.hip, so four
-    //      pieces share one M0 and one base), the k-side table's slice (2 x 16 float4; waves 0, 1 land k-block `wave`, waves 2, 3 a
+    //      pieces share one M0 and one base; MI = 4: 4 KB), the k-side table's slice (2 x 16 float4; waves 0, 1 land k-block `wave`, waves 2, 3 a
     //      duplicate nobody reads: uniform piece counts, one s_waitcnt immediate for all waves) and its own 256 bytes of mask bits ----
     const unsigned char *Aw = reinterpret_cast<const unsigned char *>(g.A) + ((size_t)z * 2 * g.KS * g.MT + (size_t)bm * MI) * 2048u
-                              + (size_t)(wave >> 1) * ((size_t)g.MT * 2048u) + (size_t)(wave & 1) * 8192u;      // k-block wave / 2, runs 8 (wave & 1) ..
+                              + (size_t)(wave >> 1) * ((size_t)g.MT * 2048u) + (size_t)(wave & 1) * WB;         // k-block wave / 2, second half of its runs for odd waves
     const size_t step_bytes = (size_t)g.MT * 4096u;                                                              // two k-blocks
     const unsigned char *strw = reinterpret_cast<const unsigned char *>(g.strT + b * g.strB + a * g.strA) + (size_t)(wave & 1) * 256u;
     const unsigned char *bitw = reinterpret_cast<const unsigned char *>(g.mask) + ((size_t)b * g.mask_tiles + min(wt, g.mask_tiles - 1)) * (size_t)g.KS * 256u;
     const unsigned lds0 = lds_addr(smem);
-    const unsigned ldsA = lds0 + (unsigned)(wave >> 1) * SUB_A + (unsigned)(wave & 1) * 8192u;
+    const unsigned ldsA = lds0 + (unsigned)(wave >> 1) * SUB_A + (unsigned)(wave & 1) * WB;
     const unsigned voff16 = (unsigned)lane * 16u, voff4 = (unsigned)lane * 4u;
     // (M0 is the compiler's scratch register, nothing of ours lives in it across statements: set in the statement that uses it)
 #define DMA2(src, dst, o0, o1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #o0 "\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #o1 \
@@ -385,11 +386,17 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     auto dma_slot = [&](int step, unsigned stage_off, int slot) __attribute__((always_inline)) {
         const unsigned char *src = Aw + (size_t)step * step_bytes;
         const unsigned dst = ldsA + stage_off;
-        if (slot == 0) DMA2(src, dst, 0, 1024);
-        if (slot == 1) DMA2(src, dst, 2048, 3072);
-        if (slot == 2) DMA1(src + 4096, dst + 4096u, 0);
-        if (slot == 3) DMA2(src + 4096, dst + 4096u, 1024, 2048);
-        if (slot == 4) DMA1(src + 4096, dst + 4096u, 3072);
+        if constexpr (MI == 8) {
+            if (slot == 0) DMA2(src, dst, 0, 1024);
+            if (slot == 1) DMA2(src, dst, 2048, 3072);
+            if (slot == 2) DMA1(src + 4096, dst + 4096u, 0);
+            if (slot == 3) DMA2(src + 4096, dst + 4096u, 1024, 2048);
+            if (slot == 4) DMA1(src + 4096, dst + 4096u, 3072);
+        } else {
+            if (slot == 0) DMA2(src, dst, 0, 1024);
+            if (slot == 2) DMA1(src, dst, 2048);
+            if (slot == 3) DMA1(src, dst, 3072);
+        }
         if (slot == 5) {
             DMA4B(strw + (size_t)step * 512u, lds0 + stage_off + STR_OFF + (unsigned)wave * 256u);
             DMA4B(bitw + (size_t)step * 256u, lds0 + stage_off + BIT_OFF + (unsigned)wave * 256u);
@@ -468,6 +475,9 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     auto kblock = [&](const unsigned char *st, int sub, const unsigned char *nst, int nsub, const f32x4 *nnstr, unsigned mb, int tb,
                       const BFrag &Bc, BFrag &Bn, u32x4 (&ah)[MI], const f32x4 (&sv)[8], f32x4 (&nsv)[8], auto dma) __attribute__((always_inline)) {
         u32x4 al[MI];
+        // vector instructions per matrix instruction of the three products (MI = 4: half the matrix work per generated weight --
+        // the kernel is bound by the weight evaluation there) and LDS reads behind the first / second MI matrix instructions
+        constexpr int NV1 = (MI == 8 ? 3 : 6) + (FORM ? 1 : 0), NV3 = (MI == 8 ? 2 : 4) + (FORM ? 1 : 0);
         SB();
         frag_loop(st, sub, 1, al);
         load_sv(nnstr, nsv);
@@ -475,20 +485,20 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.h[0], acc[i][0]); mm(ah[i], Bc.h[1], acc[i][1]); }
         gen2(sv, mb, tb, 0, 0, Bn); gen2(sv, mb, tb, 0, 2, Bn); gen2(sv, mb, tb, 0, 4, Bn);
-        PIPE(FORM ? 4 : 3, 1, 1)             // the 16 LDS reads one per matrix instruction
+        PIPE(NV1, (MI == 8 ? 1 : 2), 1)      // the MI + 8 LDS reads behind the matrix instructions
         SB();
         dma(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.l[0], acc[i][0]); mm(ah[i], Bc.l[1], acc[i][1]); }
         gen2(sv, mb, tb, 0, 6, Bn); gen2(sv, mb, tb, 1, 0, Bn); gen2(sv, mb, tb, 1, 2, Bn);
-        PIPE(FORM ? 4 : 3, 0, 0)
+        PIPE(NV1, 0, 0)
         SB();
         frag_loop(nst, nsub, 0, ah);
         dma(2);
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(al[i], Bc.h[0], acc[i][0]); mm(al[i], Bc.h[1], acc[i][1]); }
         gen2(sv, mb, tb, 1, 4, Bn); gen2(sv, mb, tb, 1, 6, Bn);
-        PIPE(FORM ? 3 : 2, 1, 0)             // the next k-block's 8 fragment reads behind the first 8 matrix instructions
+        PIPE(NV3, 1, 0)                      // the next k-block's MI fragment reads behind the first MI matrix instructions
         SB();
     };
 
@@ -515,13 +525,14 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     }
 
     // ---- k-loop, four stages.  The barrier that opens step s certifies stage (s + 1) % 4 -- its pieces were issued during step
-    //      s - 2 and the counted wait in front of the barrier leaves only step s - 1's 10 pieces (k-step s + 2) in flight -- and frees
+    //      s - 2 and the counted wait in front of the barrier leaves only step s - 1's 10 (MI = 4: 6) pieces (k-step s + 2) in flight -- and frees
     //      stage (s + 3) % 4 (read during step s - 1) for the pieces of k-step s + 3, which are issued one or two at a time at the
     //      head of the six products of the step ----
     unsigned s0 = 0, s1 = STAGE, s2 = 2 * STAGE, s3 = 3 * STAGE;
     for (int s = 0; s < g.KS; ++s) {
         if (s > 0) {
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            if constexpr (MI == 8) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         const int nxt = min(s + 3, last);
@@ -585,7 +596,7 @@ int kc_launch(const KcArgs &g, hipStream_t s) {
     const long long blocks = (long long)g.zcount * g.tiles_m * g.blocks_n;
     if (blocks > 0x7fffffffLL) return eap::bad_arg("so3_dense: too many workgroups");
     hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM, DBG>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
-    eap::set_kernel(FORM ? "kc_gemm_kernel<8,1>" : "kc_gemm_kernel<8,0>");
+    eap::set_kernel(MI == 8 ? (FORM ? "kc_gemm_kernel<8,1>" : "kc_gemm_kernel<8,0>") : (FORM ? "kc_gemm_kernel<4,1>" : "kc_gemm_kernel<4,0>"));
     return eap::check_launch("so3_dense product");
 }
 
@@ -605,7 +616,7 @@ extern "C" int eap_so3_dense_form(int form) {
 
 extern "C" int eap_so3_dense_supported(int p, int na, int ks, int rp, int o) {
     return p > 0 && (p % 32) == 0 && na > 0 && (na % 4) == 0 && na <= 64 && ks > 0 && rp > 0 && (rp % 4) == 0 && rp <= 32 * MEMB_WORDS &&
-           (o % 256) == 0;
+           (o % 128) == 0;
 }
 
 extern "C" int64_t eap_so3_dense_mask_words(int b, int p, int ks, int rp, int dir) {
@@ -674,7 +685,8 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     g.MT = o / 32; g.na = na; g.zcount = b * na;
     g.N = dir ? p : ks * rp;
     g.KS = (dir ? kd_pad : p) / KC_BK;
-    g.tiles_m = o / 256;
+    const bool wide = (o % 256) == 0;                     // 256-row blocks; else 128-row blocks (half the matrix work per generated weight)
+    g.tiles_m = wide ? o / 256 : o / 128;
     g.blocks_n = (g.N + 255) / 256;
     g.mask_tiles = 4 * g.blocks_n;
     g.A = reinterpret_cast<const u32x4 *>(planes);
@@ -693,7 +705,7 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     g.C = out;
     g.neg_inv_sigma = -1.0f / sigma;
 #ifdef EAP_ABLATION
-    if (const char *d = getenv("EAP_DENSE_DEBUG")) {
+    if (const char *d = wide ? getenv("EAP_DENSE_DEBUG") : nullptr) {
         switch (atoi(d)) {
             case 1: return kc_launch<8, 1, 1>(g, eap::S(stream));
             case 2: return kc_launch<8, 1, 2>(g, eap::S(stream));
@@ -707,6 +719,7 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
         }
     }
 #endif
+    if (!wide) return g_dense_form ? kc_launch<4, 1>(g, eap::S(stream)) : kc_launch<4, 0>(g, eap::S(stream));
     return g_dense_form ? kc_launch<8, 1>(g, eap::S(stream)) : kc_launch<8, 0>(g, eap::S(stream));
 }
 

@@ -595,11 +595,13 @@ BACKWARD_LOG = None      # a list while someone wants to know the backward regim
 
 
 # The dense product over the referenced rows (csrc/so3_dense.hip): 'auto' takes it when every cloud of the batch can (no pose
-# rotation, no padded lists), the output width fills its 256-row blocks and a cloud references at most DENSE_ROW_FACTOR x
-# nsample rows (it does rows / nsample times the flops of the list kernels on a pipe ~4.5 x as fast); 'off' never; 'force'
-# whenever the shapes are taken (tests).
+# rotation, no padded lists) and a cloud references few enough rows: it does rows / nsample times the flops of the list kernels on
+# a pipe ~4.5 x as fast.  The BACKWARD takes it up to DENSE_ROW_FACTOR x nsample rows at any width it supports (128-row blocks are
+# bound by the weight evaluation: 8.9 against 12.1 ms for the 64 -> 128 layer at 280 rows); the FORWARD only where the output
+# width fills 256-row blocks (at 128 it ties with grouping + contraction: 10.0 against 9.5 ms).  'off' never; 'force' whenever the
+# shapes are taken (tests).
 DENSE_MODE = os.environ.get('EAP_DENSE', 'auto')
-DENSE_ROW_FACTOR = 4.0
+DENSE_ROW_FACTOR = 5.0
 
 
 def _dense_rows(rcap, n):
@@ -607,16 +609,19 @@ def _dense_rows(rcap, n):
 
 
 def _dense_wanted(head, o, p, na, ks, nn, n):
-    """-> rp (rows per cloud of the dense product) or 0.  Blocks on the host for the row count."""
+    """-> (rp, forward too): rows per cloud of the dense product (0: not taken) and whether the forward takes it as well.
+    Blocks on the host for the row count."""
     if DENSE_MODE == 'off' or head is None or head.memb is None:
-        return 0
+        return 0, False
     rcap, _ = head.decide()
     rp = _dense_rows(rcap, n)
     if rp <= 0 or rp % 4 or not head.dense_possible() or not _hip.so3_dense_supported(p, na, ks, rp, o):
-        return 0
-    if DENSE_MODE != 'force' and rp > DENSE_ROW_FACTOR * nn:
-        return 0
-    return rp
+        return 0, False
+    if DENSE_MODE == 'force':
+        return rp, True
+    if rp > DENSE_ROW_FACTOR * nn:
+        return 0, False
+    return rp, o % 256 == 0
 
 
 def _weight_grad_from_z(z, fc, b, c, o, ks, ra):
@@ -680,14 +685,17 @@ class _InterConv(torch.autograd.Function):
         head = None
         if (lists_ok and needs_grad) or probe is not None:
             head = _ListHead(idx, n, nonident, gx, prefill=(not keep) and probe is None, dense_probe=probe)
-        rp = _dense_wanted(head, o, p, na, ks, idx.shape[2], n) if probe is not None else 0
+        rp, dense_fwd = _dense_wanted(head, o, p, na, ks, idx.shape[2], n) if probe is not None else (0, False)
         ctx.dense = None
-        if rp > 0:
+        if rp > 0 and needs_grad:                         # (built by whoever needs it first: the forward below, or the backward)
+            ctx.dense = [None, (geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2])]
+        if rp > 0 and dense_fwd:
             head.wait()
             geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2])
             y = _dense_forward(feats, W, head.rows, geo, p)
             ctx.head = head if needs_grad else None
-            ctx.dense = geo if needs_grad else None
+            if needs_grad:
+                ctx.dense[0] = geo
             ctx.layout, ctx.kept_x = 0, False
             ctx.W_param = weakref.ref(W_param)
             ctx.save_for_backward(W, torch.empty(0), idx, gx, rk, mult if mult is not None else torch.empty(0),
@@ -698,8 +706,8 @@ class _InterConv(torch.autograd.Function):
             return y
         if head is not None and not (lists_ok and needs_grad):
             head = None
-        elif head is not None and probe is not None and not keep:
-            head.fill(idx, gx, n)                          # (the probe postponed it)
+        elif head is not None and probe is not None and not keep and rp == 0:
+            head.fill(idx, gx, n)                          # (the probe postponed it; a dense backward does not need the entries)
         ctx.head = head
         y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
         coset = _coset_tables(mult, ident) if (mult is not None and nonident is not None and layout == 2 and COSET_OPERAND) else None
@@ -752,7 +760,10 @@ class _InterConv(torch.autograd.Function):
         # [O x P*A] x [P*A x C*K] weight-gradient GEMM shrinks by P / (referenced rows).
         head, rcap, any_nonident = ctx.head, 0, True
         if ctx.dense is not None:
-            geo = ctx.dense
+            if ctx.dense[0] is None:                       # list-kernel forward, dense backward
+                head.wait()
+                ctx.dense[0] = _hip.DenseGeometry(*ctx.dense[1])
+            geo = ctx.dense[0]
             if BACKWARD_LOG is not None:
                 BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(geo.rp), 'regime': 'dense rows'})
             z = _hip.so3_dense_bwd(gy, geo)                                          # [b,o,ks,na,rp]: the lists' Z with the anchor axis in front

@@ -331,7 +331,7 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  * on the fp16 matrix cores with two planes per operand and fp32 accumulation (the arithmetic of eap_gemm_f16x2_f32).
  *   eap_so3_dense_form        how the weights are evaluated: 1 (default) from the squared distance, 0 from the expanded square
  *                             (fewer instructions, ~3 x the rounding error); tables and product under the same setting; -> old setting
- *   eap_so3_dense_supported   p % 32 == 0, na % 4 == 0, na <= 64, rp % 4 == 0, rp <= 512, o % 256 == 0
+ *   eap_so3_dense_supported   p % 32 == 0, na % 4 == 0, na <= 64, rp % 4 == 0, rp <= 512, o % 128 == 0 (256-row blocks when o % 256 == 0)
  *   eap_so3_dense_member      slot_of int32 [b,n] (scratch), memb uint32 [b,p,16] (bit r of point p = m[p,r]; rp <= 512),
  *                             flags int32 [b]: 1 = a list names a row twice (padded short lists, grouping_cuda_kernel.cu:L98-107:
  *                             not representable by a 0/1 mask), 2 = a list names a row outside rows[:, :rp] -- such clouds

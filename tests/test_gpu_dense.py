@@ -109,14 +109,15 @@ def test_generated_weights_and_backward_product(dev, P, layer):
     from vgtk import _hip
     s = _setup(dev, 2, P, layer=layer)
     head, geo, rp = _geometry(s, dev)
-    B, o = 2, 256
+    B, o = 2, (256 if layer == 2 else 128)                                     # 256-row and 128-row blocks of the product kernel
     wd = _dense_weights64(s, head.rows, rp)                                   # [B,P,rp,A,K]
     # one-hot: dY[b,o,p,a] = 1 iff p == p0 + o  ->  Z[b,o,k,a,r] = Wd[p0 + o,(k,r),a]
-    for p0 in (0, P - 256):
+    for p0 in (0, P - o):
         gy = torch.zeros(B, o, P, NA, device=dev)
         gy[:, torch.arange(o), p0 + torch.arange(o), :] = 1.0
         z = _hip.so3_dense_bwd(gy, geo)                                       # [B,o,K,A,rp]
         ref = wd[:, p0:p0 + o].permute(0, 1, 4, 3, 2)                         # [B,o,K,A,rp]
+        assert z.shape == ref.shape
         err = float((z.double() - ref).abs().max())
         assert err < 5e-7, (p0, err)                                           # (bar of the list kernels' weights: 2e-6)
         assert float(ref.max()) > 0.5                                          # not vacuous
@@ -157,7 +158,7 @@ def test_forward_product(dev, P, layer):
     from vgtk import _hip
     s = _setup(dev, 2, P, layer=layer)
     head, geo, rp = _geometry(s, dev)
-    B, o = 2, 256
+    B, o = 2, (256 if layer == 2 else 128)
     wd = _dense_weights64(s, head.rows, rp)                                   # [B,P,rp,A,K]
     gen = torch.Generator(device=dev).manual_seed(9)
     g = torch.randn(B, o, KS, rp, NA, device=dev, generator=gen) * torch.exp(2 * torch.randn(B, o, 1, 1, NA, device=dev, generator=gen))
@@ -238,3 +239,21 @@ def test_clouds_the_dense_product_cannot_take_fall_back(dev, monkeypatch):
     r0 = _layer_run(dev, monkeypatch, 'off', xyz, pose, feats0, W0, c, o, radius, sigma)
     r1 = _layer_run(dev, monkeypatch, 'force', xyz, pose, feats0, W0, c, o, radius, sigma)
     assert r1[3][0]['regime'] != 'dense rows' and all(torch.equal(a_, b_) for a_, b_ in zip(r0[:3], r1[:3]))
+
+
+def test_narrow_layer_takes_the_dense_backward_only(dev, monkeypatch):
+    """O = 128 in 'auto' mode: the forward stays on grouping + contraction (bit-equal to DENSE_MODE 'off'), the backward takes the
+    dense product on 128-row blocks."""
+    import synth_clouds
+    B, P, c, o = 2, 512, 32, 128
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(51, B, P)[0]).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(17)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    y0, gF0, gW0, log0, _ = _layer_run(dev, monkeypatch, 'off', xyz, None, feats0, W0, c, o, radius, sigma)
+    y1, gF1, gW1, log1, y1n = _layer_run(dev, monkeypatch, 'auto', xyz, None, feats0, W0, c, o, radius, sigma)
+    assert [r['regime'] for r in log1] == ['dense rows'] and log0[0]['regime'] == 'inverse lists'
+    assert torch.equal(y1, y0) and torch.equal(y1n, y0)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(gF1, gF0) < 2e-5 and rel(gW1, gW0) < 5e-5
