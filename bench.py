@@ -152,12 +152,13 @@ class StandInLoss(torch.autograd.Function):
         return g_f, g_w, g_b, None
 
 
-CPU_BASELINE_THREADS = 16   # torch CPU ops of this path slow down beyond ~8-16 threads (measured on the 256-core GPU host)
+CPU_BASELINE_THREADS = (16, 32, 64, 128)   # torch CPU ops of this path slow down beyond ~16-32 threads (measured on the 256-thread GPU host)
 
 
-def cpu_probe(points, threads, skip, slab=32, runs=3):
-    """One thread count of the CPU baseline, in THIS process: 1 warm-up + `runs` timed runs of the oracle (oracle/so3_ref.py)
-    fwd+bwd of the 3 layers on a slab of `slab` query points of one `points`-point cloud -> dict."""
+def cpu_probe(points, threads, skip, slab=32, runs=3, deadline=60.0):
+    """One thread count of the CPU baseline, in THIS process: 1 warm-up + up to `runs` timed runs (as many as end before
+    `deadline` seconds, at least one) of the oracle (oracle/so3_ref.py) fwd+bwd of the 3 layers on the first `slab` query
+    points of one `points`-point cloud (slab == points: the whole cloud, nothing scaled) -> dict."""
     import synth_clouds
     from oracle import so3_ref
     consts = np.load(os.path.join(PKG, 'vgtk', 'data', 'anchors', 'constants.npz'))
@@ -166,6 +167,8 @@ def cpu_probe(points, threads, skip, slab=32, runs=3):
     xyz, _, pose = synth_clouds.laptop_batch(0, 1, points)
     xyz, pose = torch.from_numpy(xyz), torch.from_numpy(pose)
     torch.set_num_threads(threads)
+    slab = min(slab, points)
+    t_start = time.perf_counter()
 
     def one_run():
         total = 0.0
@@ -183,38 +186,43 @@ def cpu_probe(points, threads, skip, slab=32, runs=3):
             total += time.perf_counter() - t0
         return total
 
-    one_run()                                           # warm-up
-    times = sorted(one_run() for _ in range(runs))
-    return {'threads': threads, 'clouds_per_sec': 1.0 / (times[len(times) // 2] * points / slab), 'runs_s': [round(t, 3) for t in times]}
+    warm = one_run()                                    # warm-up
+    times = []
+    while len(times) < runs and (not times or time.perf_counter() - t_start + times[-1] < deadline):
+        times.append(one_run())
+    times.sort()
+    med = times[len(times) // 2]
+    return {'threads': threads, 'clouds_per_sec': 1.0 / (med * points / slab), 'query_points': slab, 'points': points,
+            'warmup_s': round(warm, 3), 'runs_s': [round(t, 3) for t in times]}
 
 
-def cpu_baseline(points, slab=32):
-    """The CPU oracle beside the GPU number, by BASELINE.md section 2's protocol (1 warm-up + 3 timed runs, median) at 16
-    threads AND at os.cpu_count() threads (both stated; `value` / `cores` = the faster).  Faithful = with the reference's 60x60
-    anchor-permutation search; `short_circuit` = search skipped (identity poses), at the faster thread count.  Every thread
-    count runs in a CHILD process under a hard time limit: torch's CPU ops of this path can take minutes per run with
-    hundreds of threads (256 threads: 54 s for what 16 threads do in 2 s), and the default bench must end within minutes."""
+def cpu_baseline(points, slab=256):
+    """The CPU oracle beside the GPU number, by BASELINE.md section 2's protocol (1 warm-up + 3 timed runs, median), in child
+    processes without a GPU, each under a time budget (a run that would overrun it is not started: fewer than 3 timed runs are
+    reported as such, never a missing entry):
+      1. thread sweep {16, 32, 64, 128} (those the host has) on a 32-point slab of the `points`-point cloud -> the fastest count;
+      2. at that count: a slab of `slab` (256) query points, scaled by points / slab -> `value`;
+      3. at that count: config 1 of BASELINE.json DIRECTLY -- one whole 512-point cloud, nothing scaled -> `config1`;
+      4. at that count: 2. with the reference's 60x60 anchor-permutation search short-circuited (identity poses)."""
     import subprocess
 
-    def probe(threads, skip, limit):
-        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-probe', str(threads), '--points', str(points)] + (['--probe-skip-search'] if skip else [])
+    def probe(threads, skip, pts, slab_, deadline):
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-probe', str(threads), '--points', str(pts), '--probe-slab', str(slab_),
+               '--probe-deadline', str(deadline)] + (['--probe-skip-search'] if skip else [])
         env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-        try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, env=env)
-            lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-            if out.returncode == 0 and lines:
-                return json.loads(lines[-1])
-            return {'threads': threads, 'clouds_per_sec': None, 'note': 'probe failed: ' + out.stderr[-200:]}
-        except subprocess.TimeoutExpired:
-            return {'threads': threads, 'clouds_per_sec': None, 'note': f'1 warm-up + 3 runs did not finish within {limit} s'}
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+        if out.returncode != 0 or not lines:
+            raise RuntimeError('cpu baseline probe failed: ' + out.stderr[-400:])
+        return json.loads(lines[-1])
 
     ncpu = os.cpu_count() or 1
-    faithful = [probe(min(ncpu, CPU_BASELINE_THREADS), False, 150)]
-    if ncpu > CPU_BASELINE_THREADS:
-        faithful.append(probe(ncpu, False, 45))
-    done = [f for f in faithful if f.get('clouds_per_sec')]
-    best = max(done, key=lambda d: d['clouds_per_sec']) if done else {'threads': min(ncpu, CPU_BASELINE_THREADS), 'clouds_per_sec': None}
-    short = probe(best['threads'], True, 120)
+    counts = [t for t in CPU_BASELINE_THREADS if t <= ncpu] or [ncpu]
+    sweep = [probe(t, False, points, 32, 8.0) for t in counts]
+    best = max(sweep, key=lambda d: d['clouds_per_sec'])['threads']
+    main = probe(best, False, points, slab, 45.0)
+    config1 = probe(best, False, 512, 512, 40.0)
+    short = probe(best, True, points, slab, 25.0)
     model = 'unknown'
     try:
         for ln in open('/proc/cpuinfo'):
@@ -223,13 +231,57 @@ def cpu_baseline(points, slab=32):
                 break
     except OSError:
         pass
-    return {'value': best['clouds_per_sec'], 'unit': 'point-clouds/sec', 'cores': best['threads'], 'kind': 'port',
+    return {'value': main['clouds_per_sec'], 'unit': 'point-clouds/sec', 'cores': best, 'kind': 'port',
             'host_logical_cpus': ncpu, 'host_cpu_model': model,
-            'protocol': 'BASELINE.md section 2: 1 warm-up + 3 timed runs, median; torch.set_num_threads at each listed count; each count in a child process with a time limit',
-            'by_threads': faithful,
-            'sample': f'oracle fwd+bwd of the 3 backbone layers on {slab} of {points} query points of 1 cloud, '
-                      f'scaled x{points // slab}; includes the reference\'s 60x60 anchor-permutation search',
-            'value_perm_search_short_circuited': short.get('clouds_per_sec'), 'short_circuit_runs_s': short.get('runs_s')}
+            'protocol': 'BASELINE.md section 2: 1 warm-up + 3 timed runs, median (fewer timed runs where three would overrun the '
+                        'probe\'s time budget: see runs_s); torch.set_num_threads at each listed count; every probe in a child process without a GPU',
+            'thread_sweep': {'sample': f'32 of {points} query points', 'by_threads': sweep, 'fastest': best},
+            'runs_s': main['runs_s'], 'warmup_s': main['warmup_s'],
+            'sample': f'oracle fwd+bwd of the 3 backbone layers on {main["query_points"]} of {points} query points of 1 cloud (every op of the path is '
+                      f'independent across query points; the support is the whole cloud), time x {points}/{main["query_points"]}; includes the '
+                      f'reference\'s 60x60 anchor-permutation search',
+            'config1': {'value': config1['clouds_per_sec'], 'unit': 'point-clouds/sec', 'cores': best, 'runs_s': config1['runs_s'], 'warmup_s': config1['warmup_s'],
+                        'sample': 'BASELINE.json config 1 directly: ONE whole 512-point cloud (512-point radii), fwd+bwd of the 3 backbone layers, nothing scaled'},
+            'value_perm_search_short_circuited': short['clouds_per_sec'], 'short_circuit_runs_s': short['runs_s']}
+
+
+def expected_scaling(world, ms_per_step, n_params):
+    """What the N-rank line should look like, written down BEFORE anyone has run this path on RCCL: per step
+    and rank the compute is the single-GPU step (weak scaling: the same clouds per GPU) plus
+      * the gradient all-reduce (4 n_params bytes, ring over xGMI: 2 (N - 1) / N of the bytes per link at ~40 GB/s effective for
+        a few-MB message + 2 (N - 1) hops of ~10 us), launched from autograd hooks: the deepest layer's bucket (89 % of the
+        bytes) travels under the ~25 ms of the two shallower layers' backward -- only the last, small bucket is exposed;
+      * one all-gather of 5.76 kB per cloud of pose hypotheses (latency-bound, ~(N - 1) x 10 us by the default ring);
+      * 6 SyncBatchNorm moment exchanges (3 forward, 3 backward, <= 8 kB each): blocking, ~(N - 1) x 10 us each by the ring;
+      * the max over ranks of box-to-box speed differences (+-3 % between boxes measured this round) and barrier skew.
+    -> estimate of the exposed communication per step and the efficiency band the first SCALE record should fall in."""
+    if world <= 1:
+        return None
+    hop_us = 10.0
+    last_bucket_bytes = 4.0 * 64 * 24                           # the first layer's weights (+ the stand-in head): what cannot overlap
+    allreduce_exposed = 2 * (world - 1) * hop_us * 1e-3 + 2.0 * (world - 1) / world * last_bucket_bytes / 40e9 * 1e3
+    allgather = (world - 1) * hop_us * 1e-3
+    syncbn = 6 * (world - 1) * hop_us * 1e-3
+    exposed = allreduce_exposed + allgather + syncbn
+    return {'exposed_comm_ms_per_step_estimate': exposed,
+            'gradient_allreduce_bytes': 4.0 * n_params, 'pose_allgather_bytes_per_rank': 5760.0 * 16,
+            'efficiency_from_comm_alone': ms_per_step / (ms_per_step + exposed),
+            'expected_efficiency_band': [0.94, 0.995],
+            'note': 'weak scaling, no data-path collective; the band is the comm estimate widened by the +-3 % box-to-box spread (the line is the MAX '
+                    'over ranks) -- an efficiency below 0.94 means an exchange is NOT overlapped / is slower than a latency-bound ring and should be '
+                    'looked at first: SyncBatchNorm moments (blocking), then the hook-launched buckets'}
+
+
+def distributed_report(world, backend, dev):
+    """rank, device and the communication-library settings of every rank, gathered on rank 0 (the first RCCL run must be readable)."""
+    info = {'rank': int(os.environ.get('RANK', 0)), 'local_rank': int(os.environ.get('LOCAL_RANK', 0)), 'device': str(dev),
+            'device_name': torch.cuda.get_device_name(dev), 'pid': os.getpid(),
+            'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith(('NCCL_', 'RCCL_', 'HSA_', 'HIP_VISIBLE', 'ROCR_VISIBLE', 'TORCH_NCCL', 'MASTER_'))}}
+    if world == 1:
+        return [info]
+    out = [None] * world
+    dist.all_gather_object(out, info)
+    return out
 
 
 def zpconv_roofline(dev, points, clouds=8, channels=64):
@@ -638,11 +690,13 @@ def main(argv=None):
     ap.add_argument('--plain', action='store_true', help='warm-up + timed steps only (no attribution loop, no A/B leg, no extras): what the counter passes of tools/gpu/profile_round.sh run')
     ap.add_argument('--cpu-baseline-probe', type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline(): one thread count, no GPU
     ap.add_argument('--probe-skip-search', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--probe-slab', type=int, default=32, help=argparse.SUPPRESS)
+    ap.add_argument('--probe-deadline', type=float, default=60.0, help=argparse.SUPPRESS)
     ap.add_argument('--check-launch', action='store_true', help='start the ranks, run the two exchanges on small tensors, print what was started (no GPU needed)')
     args = ap.parse_args(argv)
 
     if args.cpu_baseline_probe > 0:
-        print(json.dumps(cpu_probe(args.points, args.cpu_baseline_probe, args.probe_skip_search)))
+        print(json.dumps(cpu_probe(args.points, args.cpu_baseline_probe, args.probe_skip_search, slab=args.probe_slab, deadline=args.probe_deadline)))
         return
     if args.gpus > 1 and 'RANK' not in os.environ:
         # no launcher around us: start the N ranks ourselves (the driver's N = 1 command form with --gpus N)
@@ -714,6 +768,7 @@ def main(argv=None):
             dt = t.item()
         return dt
 
+    ranks_report = distributed_report(world, backend, dev)          # (collective: every rank)
     for _ in range(args.warmup):
         step()
     # the headline loop: EXACTLY --steps steps, no per-launch events
@@ -806,6 +861,10 @@ def main(argv=None):
             line['fp32_mfma_contraction'] = ab
         if ab3 is not None:
             line['bf16x3_contraction'] = ab3
+        if world > 1:
+            line['ranks'] = ranks_report
+            line['backend'] = backend + (' (RCCL)' if backend == 'nccl' else '')
+            line['expected_scaling'] = expected_scaling(world, line['ms_per_step'], sum(p.numel() for p in conv_params))
         if world > 1 and backend != 'nccl':
             line['functional_check_only'] = (f'{world} ranks over {backend} on {n_dev} device(s): the N > 1 code path runs, '
                                              f'this is NOT a scaling measurement')

@@ -116,6 +116,17 @@ int zpconv_first_rows(int b, int np, int per_point, int nn, const int32_t *idx, 
 // csrc/abi.hip: a side stream per device (fork: it waits for `s` so far; join: `s` waits for it)
 int side_fork(hipStream_t s, hipStream_t *side);
 int side_join(hipStream_t s);
+// Joins on EVERY exit path after a fork: an early error return must not leave the side stream reading buffers the caller frees
+// once the entry has failed.  (One side stream and one fork / join event pair per device, shared by every caller: entries that
+// fork are meant to be called from ONE host thread per device -- the autograd thread of a process that owns the GPU, as the
+// reference's extensions are; two host threads forking on the same device would share the events.)
+struct SideJoin {
+    hipStream_t s;
+    bool armed = true;
+    explicit SideJoin(hipStream_t stream) : s(stream) {}
+    ~SideJoin() { if (armed) side_join(s); }
+    int join() { armed = false; return side_join(s); }
+};
 int inter_zpconv_bwd_flagged(int b, int np, int nq, int na, int ks, int ann, int c, const int32_t *idx, const float *w,
                              const float *grad, float *gfeats, const int32_t *only_flagged, hipStream_t s);
 // csrc/so3_inter_mfma.hip with the clouds already served by group_lists_fwd skipped

@@ -370,6 +370,7 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     hipStream_t side;
     e = eap::side_fork(s, &side);
     if (e) return e;
+    eap::SideJoin joiner(s);              // (also on the error returns below)
     e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, nullptr, nullptr, flag, side);
     if (e) return e;
     e = eap_inv_lists_rows(b, np, nq, ann, idx0, counts, rows, off, cnt, n_rows, stream);
@@ -403,7 +404,7 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
         e = eap::check_launch("inter_zpconv_backward (on-chip rows) reduce");
         if (e) return e;
     }
-    e = eap::side_join(s);
+    e = joiner.join();
     if (e) return e;
     hipLaunchKernelGGL(zp_hot_status_kernel, dim3(eap::cdiv(b, 256)), dim3(256), 0, s, b, flag, status);
     return eap::check_launch("inter_zpconv_backward (on-chip rows) status");

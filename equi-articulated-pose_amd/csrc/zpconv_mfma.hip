@@ -445,6 +445,7 @@ extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks
     hipStream_t side;
     e = eap::side_fork(s, &side);
     if (e) return e;
+    eap::SideJoin joiner(s);              // (also on the error returns below)
     e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, nullptr, nullptr, flag, side);
     if (e) return e;
 #ifdef EAP_EXPERIMENTS   // `make EXPERIMENTS=1`: the 32-neighbour re-cut of tools/experiments/kernels/zpconv_mfma2.hip behind eap_inter_zpconv_fwd_kernel(2)
@@ -454,7 +455,7 @@ extern "C" int eap_inter_zpconv_fwd_ws_f32(int b, int np, int nq, int na, int ks
 #endif
     e = eap::inter_zpconv_mfma_fwd(b, np, nq, na, ks, ann, c, idx0, w, src, nobody, dst, s);
     if (e) return e;
-    e = eap::side_join(s);
+    e = joiner.join();
     if (e) return e;
     return eap::inter_zpconv_rows_fwd(b, np, nq, na, ks, ann, c, idx, w, src, dst, flag, s);
 }

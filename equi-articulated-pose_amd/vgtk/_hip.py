@@ -107,14 +107,25 @@ def _dma_ok(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB):
 
 
 # Contractions whose A operand is shared by the batch (the inter conv's forward contraction on the transposed
-# intermediate, the pointwise contraction so3_contract, the implicit intra conv) on the bf16 matrix cores with 3 x bf16
-# split operands: fp32 in, fp32 accumulate, products as accurate as fp32's (csrc/gemm_bf16x3.hip).  False: the fp32-MFMA
-# kernels everywhere.
+# intermediate, the pointwise contraction so3_contract, the implicit intra conv) on the 16-bit matrix cores with split
+# operands, fp32 in, fp32 accumulate (csrc/gemm_bf16x3.hip).  False: the fp32-MFMA kernels everywhere.
 SPLIT_BF16_CONTRACTION = True
 # Planes per operand on those kernels: 3 = three bf16 planes, six products (exact splits); 2 = two fp16 planes after a
 # power-of-two scale per tensor, three products (include/eap_hip.h, eap_gemm_f16x2_f32: representation error <= 2^-23 per
 # element, bounded against fp64 by the fp32-MFMA kernel's error in tests/test_gpu_split_planes.py).
-SPLIT_PLANES = int(os.environ.get('EAP_SPLIT_PLANES', '2'))      # (the environment switch is for A/B runs)
+# Accuracy bar of the default (2): every product carries a representation error <= 2^-21 |a||b| (the l l' term is dropped: NOT
+# bit-for-bit an fp32 product), and an operand row scaled from a BOUND on its magnitude that is L times too large adds an absolute
+# 2^-39 L max|row| per element; against float64 the result stays within 1.25 x (max) / 1.1 x (rms) of the fp32-MFMA kernel's
+# error on the same operands, with bounds up to 2^20 too large (README.md "Numerics", tests/test_gpu_split_planes.py).  3 planes
+# are exact splits (dropped terms <= 2^-23 |a||b|) and need no magnitudes.
+def _split_planes_from_env():
+    v = os.environ.get('EAP_SPLIT_PLANES', '2')
+    if v not in ('2', '3'):
+        raise ImportError(f'EAP_SPLIT_PLANES={v!r}: 2 (two fp16 planes, three products) or 3 (three bf16 planes, six products)')
+    return int(v)
+
+
+SPLIT_PLANES = _split_planes_from_env()      # (the environment switch is for A/B runs)
 
 
 SPLIT_PLANES_SCAN_ROWS = 384     # see _planes2 (tests set it to 0 to reach the two-plane kernel at every shape)
@@ -174,8 +185,9 @@ def _planes2(transB, M, N, K, A, lda, batch, B, ldb, strideB, b_bound):
 
 
 def gemm(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, b_blocked=False, b_bound=None):
-    """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored.  b_bound = (device word, factor): a
-    known bound on the columns of B, see _planes2 (saves the two-plane kernel its pass over B)."""
+    """b_blocked: B is stored blocked by 4 (include/eap_hip.h); `ldb` is then ignored.  b_bound = (words int32 [batch, N // grp] holding
+    non-negative float bit patterns, grp = consecutive columns per word, factor): words * factor bounds the magnitudes of B's columns,
+    see _planes2 (saves the two-plane kernel its pass over B)."""
     tag = {'flops': 2.0 * M * N * K * batch, 'shape': ('gemm', int(transA), int(transB), M, N, K, batch)}
     if SPLIT_BF16_CONTRACTION and not b_blocked and not transA and transB and (strideA == 0 or batch == 1) and \
             lib.eap_gemm_bf16x3_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(strideB)):

@@ -161,8 +161,8 @@ class GradientReducer:
         def hook(p):
             bucket = self.buckets[bucket_index]
             if bucket['work'] is not None:
-                raise RuntimeError('GradientReducer: a gradient arrived for a bucket whose all-reduce is in flight -- call finish() '
-                                   'after every backward (gradient accumulation over several backward passes: finish() after the last)')
+                raise RuntimeError('GradientReducer: a gradient arrived for a bucket whose all-reduce is in flight -- finish() must follow '
+                                   'EVERY backward (accumulating several backward passes into one reduction is not supported)')
             o = bucket['offsets'][slot]
             bucket['flat'][o:o + p.numel()].copy_(p.grad.reshape(-1))      # p.grad is the accumulated gradient: a second visit overwrites
             bucket['flat'][bucket['n'] + slot].fill_(1.0)                  # device-side fill: no host -> device copy inside the backward
@@ -171,14 +171,28 @@ class GradientReducer:
         return hook
 
     def finish(self):
-        """Launch what the hooks could not (in bucket order), wait for every bucket and write the reduced gradients back."""
-        world = dist.get_world_size(self.group) if self.buckets else 1
+        """Launch what the hooks could not (in bucket order), wait for every bucket and write the reduced gradients back.
+
+        After finish(), p.grad of every parameter that fired on ANY rank since the previous finish() is the average over the ranks
+        of what the hooks saw (a rank where it did not fire contributes zeros and has whatever p.grad it still held REPLACED --
+        the replicas end identical); call it after EVERY backward, with zero_grad() between steps as usual.  Accumulating over
+        several backward passes before one finish() is not supported (the hook raises as soon as a launched bucket is reached
+        again)."""
+        if not self.buckets:
+            return
+        world = dist.get_world_size(self.group)
         for bucket in self.buckets[self._next:]:
             self._launch(bucket)
         self._next = len(self.buckets)
         for bucket in self.buckets:
             bucket['work'].wait()
-            touched = bucket['flat'][bucket['n']:].tolist()
+        # which parameters fired anywhere: ONE device -> host read for all buckets (a read per bucket stalls the host once per
+        # bucket and step on every rank)
+        touched_all = torch.cat([bucket['flat'][bucket['n']:].float() for bucket in self.buckets]).tolist()
+        k = 0
+        for bucket in self.buckets:
+            touched = touched_all[k:k + len(bucket['params'])]
+            k += len(bucket['params'])
             if self.average:
                 bucket['flat'][:bucket['n']] /= world
             for i, (p, o) in enumerate(zip(bucket['params'], bucket['offsets'])):

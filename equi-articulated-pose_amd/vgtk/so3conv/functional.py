@@ -781,6 +781,7 @@ class _InterConv(torch.autograd.Function):
         if head is not None:
             rcap, any_nonident = head.decide()
             if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
+                head.entries = None                        # (prefilled on last step's hint, not needed after all: 20 bytes per entry)
                 head = None
         if BACKWARD_LOG is not None:      # diagnostics for bench.py / tests: which regime each layer's backward took
             BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(rcap),

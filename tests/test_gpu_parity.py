@@ -1025,3 +1025,43 @@ def test_native_zpconv_backward_with_rows_on_chip(dev):
     got = Z.inter_zpconv_backward(idx, w, g, P)
     ref = native.inter_zpconv_backward(idx.cpu().numpy(), w.cpu().numpy(), g.cpu().numpy(), P)
     assert rel_err(got.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.gpu
+def test_inter_zpconv_backward_remembers_the_verdict_per_index(dev):
+    """vgtk.cuda.zpconv.inter_zpconv_backward (zpconv_cuda.cpp:L58-75) with the SAME index tensor again: which clouds the on-chip
+    kernel leaves to the product pipeline depends on the index alone and is remembered (round-4 advisor finding: a batch of padded
+    lists paid the prelude and a host read on every call).  Clouds 1, 2 and 4 of 5 name a row twice (the reference's padding):
+    they go to the product pipeline as the runs [1, 2] and [4]; results equal the oracle's on the first and on the remembered
+    call, and after an in-place change of the index the verdict is taken again."""
+    import vgtk.cuda.zpconv as Z
+    rng = np.random.default_rng(23)
+    b, p, q, a, k, ann, c = 5, 16, 40, 60, 24, 16, 32
+    idx = np.stack([np.stack([rng.permutation(q)[:ann] for _ in range(p)]) for _ in range(b)])         # distinct rows per list
+    for cloud in (1, 2, 4):
+        idx[cloud, :, ann // 2:] = idx[cloud, :, :1]                                                 # short lists padded with their first hit
+    idx = np.broadcast_to(idx[:, :, None, None, :], (b, p, a, k, ann)).astype(np.int32).copy()
+    w = rng.random((b, p, a, k, ann)).astype(np.float32)
+    g = rng.standard_normal((b, c, k, p, a)).astype(np.float32)
+    ref = native.inter_zpconv_backward(idx, w, g, q)
+    d_idx, d_w, d_g = T(idx).to(dev), T(w).to(dev), T(g).to(dev)
+    Z._HOT_VERDICTS.clear()
+    first = Z.inter_zpconv_backward(d_idx, d_w, d_g, q)
+    assert rel_err(first.cpu().numpy(), ref) < 1e-5
+    assert len(Z._HOT_VERDICTS) == 1 and list(Z._HOT_VERDICTS.values())[0][1] == (1, 2, 4)
+    reads = []
+    orig = torch.Tensor.tolist
+    torch.Tensor.tolist = lambda self: (reads.append(1), orig(self))[1]
+    try:
+        again = Z.inter_zpconv_backward(d_idx, d_w, d_g, q)
+    finally:
+        torch.Tensor.tolist = orig
+    assert torch.equal(again, first) and not reads                                                   # no host read on the remembered call
+    # all clouds padded: the second call does not even launch the on-chip kernel's prelude
+    idx2 = idx.copy()
+    idx2[:, :, :, :, ann // 2:] = idx2[:, :, :, :, :1]
+    d_idx.copy_(T(idx2).to(dev))                                                                     # in place: the version counter moves
+    ref2 = native.inter_zpconv_backward(idx2, w, g, q)
+    for _ in range(2):
+        assert rel_err(Z.inter_zpconv_backward(d_idx, d_w, d_g, q).cpu().numpy(), ref2) < 1e-5
+    assert any(v[1] == (0, 1, 2, 3, 4) for v in Z._HOT_VERDICTS.values())

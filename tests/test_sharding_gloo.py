@@ -199,6 +199,17 @@ def _divergent_worker(rank, world, port, out_dir):
     loss({0, 1}, set()).backward()
     reducer.finish()
     s2 = {n: (None if p.grad is None else p.grad.clone()) for n, p in zip('nabcd', params)}
+    # step 3 WITHOUT zero_grad, c on rank 0 only: rank 1 still holds step 2's average in c.grad and does not fire -- it contributes
+    # zeros and its stale tensor is REPLACED, so both ranks end with the same (documented) value: avg over ranks of what the hooks
+    # saw = (rank 0's accumulated c.grad + 0) / 2
+    c_before = c.grad.clone()
+    reads = []
+    orig_tolist = torch.Tensor.tolist
+    torch.Tensor.tolist = lambda self: (reads.append(1), orig_tolist(self))[1]
+    loss({0}, set()).backward()
+    reducer.finish()
+    torch.Tensor.tolist = orig_tolist
+    s3_c, s3_expect = c.grad.clone(), 0.5 * (c_before + 3 * torch.arange(1.0, 6.0))     # rank 0: stale + new (torch accumulates), rank 1: 0
     # a second backward while a bucket is in flight raises
     for p in params:
         p.grad = None
@@ -209,7 +220,7 @@ def _divergent_worker(rank, world, port, out_dir):
     except RuntimeError:
         raised = True
     reducer.finish()
-    out = {'raised': raised, 'never_none': s1['n'] is None and s2['n'] is None}
+    out = {'raised': raised, 'never_none': s1['n'] is None and s2['n'] is None, 's3_c': s3_c.numpy(), 's3_expect': s3_expect.numpy(), 'host_reads': len(reads)}
     for tag, s in (('s1', s1), ('s2', s2)):
         for n in 'abcd':
             out[f'{tag}_{n}'] = s[n].numpy()
@@ -235,6 +246,8 @@ def test_gradient_reducer_with_rank_dependent_graphs(tmp_path):
         np.testing.assert_allclose(r[i]['s2_c'], 1.5 * 3 * w)
         np.testing.assert_allclose(r[i]['s2_b'], 0 * w)                 # zeroed by zero_grad, untouched by the reduction
         np.testing.assert_allclose(r[i]['s2_a'], 1.5 * w)
+        np.testing.assert_allclose(r[i]['s3_c'], r[0]['s3_expect'])     # identical on both ranks
+        assert int(r[i]['host_reads']) == 1                              # one stacked read per finish(), not one per bucket (5 here)
 
 
 def test_bench_starts_its_own_ranks():
