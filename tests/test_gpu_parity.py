@@ -1036,7 +1036,7 @@ def test_inter_zpconv_backward_remembers_the_verdict_per_index(dev):
     call, and after an in-place change of the index the verdict is taken again."""
     import vgtk.cuda.zpconv as Z
     rng = np.random.default_rng(23)
-    b, p, q, a, k, ann, c = 5, 16, 40, 60, 24, 16, 32
+    b, p, q, a, k, ann, c = 5, 8, 80, 60, 24, 64, 32                                                 # (the on-chip kernel takes 64 neighbours, 24 kernel points)
     idx = np.stack([np.stack([rng.permutation(q)[:ann] for _ in range(p)]) for _ in range(b)])         # distinct rows per list
     for cloud in (1, 2, 4):
         idx[cloud, :, ann // 2:] = idx[cloud, :, :1]                                                 # short lists padded with their first hit
