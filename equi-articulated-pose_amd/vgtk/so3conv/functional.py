@@ -679,8 +679,10 @@ class _InterConv(torch.autograd.Function):
         # whether the batch can take it is known on the host once the lists' first half has run -- one host wait per layer,
         # only for layers whose width fills the dense kernel's blocks
         probe = None
-        if (DENSE_MODE != 'off' and geometry is not None and lists_ok and epilogue is None
-                and _hip.so3_dense_supported(p, na, ks, 4, o) and n <= _hip.DENSE_MAX_ROWS * 64):
+        # (a folded inference epilogue does not stop it: the dense forward leaves `epilogue.applied` False and the caller runs the
+        # norm as a pass of its own -- cheaper than giving up the dense product for the 128 -> 512 layer)
+        if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0)
+                and _hip.so3_dense_supported(p, na, ks, 4, o)):
             probe = (geometry[2], geometry[3])
         head = None
         if (lists_ok and needs_grad) or probe is not None:
