@@ -199,30 +199,39 @@ def cpu_probe(points, threads, skip, slab=32, runs=3, deadline=60.0):
 def cpu_baseline(points, slab=256):
     """The CPU oracle beside the GPU number, by BASELINE.md section 2's protocol (1 warm-up + 3 timed runs, median), in child
     processes without a GPU, each under a time budget (a run that would overrun it is not started: fewer than 3 timed runs are
-    reported as such, never a missing entry):
+    reported as such, never a missing entry); steps 2-4 run side by side when the host has 6 x the thread count to spare:
       1. thread sweep {16, 32, 64, 128} (those the host has) on a 32-point slab of the `points`-point cloud -> the fastest count;
       2. at that count: a slab of `slab` (256) query points, scaled by points / slab -> `value`;
       3. at that count: config 1 of BASELINE.json DIRECTLY -- one whole 512-point cloud, nothing scaled -> `config1`;
       4. at that count: 2. with the reference's 60x60 anchor-permutation search short-circuited (identity poses)."""
     import subprocess
 
-    def probe(threads, skip, pts, slab_, deadline):
+    def start(threads, skip, pts, slab_, deadline):
         cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-probe', str(threads), '--points', str(pts), '--probe-slab', str(slab_),
                '--probe-deadline', str(deadline)] + (['--probe-skip-search'] if skip else [])
         env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-        out = subprocess.run(cmd, capture_output=True, text=True, env=env)
-        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-        if out.returncode != 0 or not lines:
-            raise RuntimeError('cpu baseline probe failed: ' + out.stderr[-400:])
+        return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+
+    def finish(proc):
+        out, err = proc.communicate()
+        lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+        if proc.returncode != 0 or not lines:
+            raise RuntimeError('cpu baseline probe failed: ' + err[-400:])
         return json.loads(lines[-1])
 
     ncpu = os.cpu_count() or 1
     counts = [t for t in CPU_BASELINE_THREADS if t <= ncpu] or [ncpu]
-    sweep = [probe(t, False, points, 32, 8.0) for t in counts]
+    sweep = [finish(start(t, False, points, 32, 8.0)) for t in counts]            # one after the other
     best = max(sweep, key=lambda d: d['clouds_per_sec'])['threads']
-    main = probe(best, False, points, slab, 45.0)
-    config1 = probe(best, False, 512, 512, 40.0)
-    short = probe(best, True, points, slab, 25.0)
+    # the three protocol runs side by side when the host has the threads for it (3 x `best` of its logical CPUs), else in turn
+    jobs = [(best, False, points, slab, 90.0), (best, False, 512, 512, 90.0), (best, True, points, slab, 60.0)]
+    if 3 * best <= ncpu // 2:
+        procs = [start(*j) for j in jobs]
+        main, config1, short = [finish(pr) for pr in procs]
+        side_by_side = True
+    else:
+        main, config1, short = [finish(start(*j)) for j in jobs]
+        side_by_side = False
     model = 'unknown'
     try:
         for ln in open('/proc/cpuinfo'):
@@ -236,6 +245,7 @@ def cpu_baseline(points, slab=256):
             'protocol': 'BASELINE.md section 2: 1 warm-up + 3 timed runs, median (fewer timed runs where three would overrun the '
                         'probe\'s time budget: see runs_s); torch.set_num_threads at each listed count; every probe in a child process without a GPU',
             'thread_sweep': {'sample': f'32 of {points} query points', 'by_threads': sweep, 'fastest': best},
+            'probes_side_by_side': side_by_side,
             'runs_s': main['runs_s'], 'warmup_s': main['warmup_s'],
             'sample': f'oracle fwd+bwd of the 3 backbone layers on {main["query_points"]} of {points} query points of 1 cloud (every op of the path is '
                       f'independent across query points; the support is the whole cloud), time x {points}/{main["query_points"]}; includes the '
@@ -868,6 +878,19 @@ def main(argv=None):
         if world > 1 and backend != 'nccl':
             line['functional_check_only'] = (f'{world} ranks over {backend} on {n_dev} device(s): the N > 1 code path runs, '
                                              f'this is NOT a scaling measurement')
+        cpu_job = None
+        if world == 1 and not args.no_cpu_baseline:
+            # child processes on the host cores, BESIDE the side legs below (never beside the headline loop above): a few minutes of CPU
+            # work that would otherwise be added to the run
+            import threading
+            cpu_job = {}
+            def _cpu():
+                try:
+                    cpu_job['result'] = cpu_baseline(args.points)
+                except Exception as e:          # noqa: BLE001  (reported in the line, the GPU numbers stand)
+                    cpu_job['error'] = repr(e)
+            cpu_job['thread'] = threading.Thread(target=_cpu, daemon=True)
+            cpu_job['thread'].start()
         if world == 1 and default_cfg and not args.no_other_configs:
             del model, opt, xyz, pose
             torch.cuda.empty_cache()
@@ -878,10 +901,13 @@ def main(argv=None):
         if world == 1 and not args.fwd_only:
             line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
             progress('native zpconv done')
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.points)
+        if cpu_job is not None:
+            cpu_job['thread'].join()
+            if 'error' in cpu_job:
+                raise RuntimeError('cpu baseline: ' + cpu_job['error'])
+            line['cpu_baseline'] = cpu_job['result']
             progress('cpu baseline done')
-            line['speedup_vs_cpu_baseline'] = (line['value'] / line['cpu_baseline']['value']) if line['cpu_baseline']['value'] else None
+            line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -232,16 +232,19 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int 
 // ------------------------------------------------------------------------------------------------------------------------
 // scale[(b na + a) m + row] = scale2[(b m + row) na + a] = 2^(14 - e) for max_l |T[b][row][l][a]| in [2^e, 2^(e+1)).  One block per (b, row): thread
 // (anchor quad aq, lane group pg) walks the row's float4 pieces aq + nq (pg + G j): consecutive threads, consecutive pieces
-__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, const f32x4 *__restrict__ T, float *__restrict__ scale,
-                                                           float *__restrict__ scale2) {
+// (a row's l elements may come in l / seg segments of seg elements, seg_pitch4 float4 apart: the rows of G as the small GEMM
+// leaves them, [o][k][pitch >= rp na])
+__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, int seg, long long seg_pitch4, const f32x4 *__restrict__ T,
+                                                           float *__restrict__ scale, float *__restrict__ scale2) {
     __shared__ unsigned s[256][4];
     const int nq = na >> 2, G = 256 / nq, b = blockIdx.y, row = blockIdx.x, t = threadIdx.x;
     const int aq = t % nq, pg = t / nq;
     unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     if (pg < G) {
-        const f32x4 *src = T + ((size_t)b * m + row) * (size_t)l * nq;
+        const f32x4 *src = T + ((size_t)b * m + row) * (size_t)(l / seg) * seg_pitch4;
         for (int i = pg; i < l; i += G) {
-            const f32x4 q = src[(size_t)i * nq + aq];
+            const int sg = i / seg;
+            const f32x4 q = src[(size_t)sg * seg_pitch4 + (size_t)(i - sg * seg) * nq + aq];
             v0 = max(v0, __float_as_uint(q.x) & 0x7fffffffu);
             v1 = max(v1, __float_as_uint(q.y) & 0x7fffffffu);
             v2 = max(v2, __float_as_uint(q.z) & 0x7fffffffu);
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na,
 // One block per (b, mt, kb): thread (anchor quad aq = t % nq, row group t / nq) takes the 8 elements of (row, kg) for its four
 // anchors -- 8 float4 loads 4 na bytes apart, the nq threads of a row covering each element's 4 na contiguous bytes -- and
 // writes its 8 pieces; the 64 pieces of a 1 KB run come from one block within a few hundred cycles.
-__global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, const f32x4 *__restrict__ T,
+__global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, int seg, long long seg_pitch4, const f32x4 *__restrict__ T,
                                                           const float *__restrict__ scale2, u32x4 *__restrict__ planes) {
     const int b = blockIdx.z, mt = blockIdx.y, kb = blockIdx.x, t = threadIdx.x;
     const int nq = na >> 2, RG = 256 / nq;                      // rows per pass
@@ -273,10 +276,14 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
     const int MT = m >> 5;
     for (int it = rr; it < 64; it += RG) {                      // item = (row i, k half kg)
         const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
-        const f32x4 *src = T + (((size_t)b * m + row) * (size_t)l + l0) * nq + aq;
+        const f32x4 *src = T + ((size_t)b * m + row) * (size_t)(l / seg) * seg_pitch4 + aq;
+        int sg = l0 / seg, sr = l0 - sg * seg;                    // segment and position of element l0 + e
         f32x4 q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = (l0 + e < l) ? src[(size_t)e * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 8; ++e) {
+            q[e] = (l0 + e < l) ? src[(size_t)sg * seg_pitch4 + (size_t)sr * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (++sr == seg) { sr = 0; ++sg; }
+        }
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale2 + ((size_t)b * m + row) * na + 4 * aq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -662,21 +669,27 @@ extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks,
     return eap::check_launch("so3_dense_tables");
 }
 
-extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, const float *src, float *scale, void *planes, eap_stream_t stream) {
+// seg / seg_pitch: a row's l elements in l / seg segments of seg elements whose starts are seg_pitch floats apart (seg <= 0: one
+// segment: src is plain [b,m,l,na])
+extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, const float *src, float *scale, void *planes,
+                                       eap_stream_t stream) {
     if (b <= 0) return 0;
-    if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || (reinterpret_cast<uintptr_t>(src) & 15))
-        return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source");
+    if (seg <= 0) { seg = l; seg_pitch = (int64_t)l * na; }
+    if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || (reinterpret_cast<uintptr_t>(src) & 15) || l % seg != 0 ||
+        (seg_pitch & 3) != 0 || seg_pitch < (int64_t)seg * na)
+        return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source, whole segments of a 16-byte aligned pitch");
     hipStream_t s = eap::S(stream);
     const int kb_total = ceil_to(l, KC_BK) / 16;
     float *scale2 = scale + (size_t)b * na * m;
-    hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, reinterpret_cast<const f32x4 *>(src), scale, scale2);
-    hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total,
+    hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), reinterpret_cast<const f32x4 *>(src), scale, scale2);
+    hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total, seg, (long long)(seg_pitch / 4),
                        reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
     return eap::check_launch("so3_dense_split");
 }
 
 // dir 0: Z[b][o][k][a][r] = sum_p dY Wd (planes of dY [b,o,p,a]);  dir 1: Yt[b][a][o][p] = sum_(k,r) G Wd (planes of G [b,o,(k,r),a])
-extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, float sigma, const void *planes, const float *scale,
+// ldz (dir 0): floats between consecutive (o, k) rows of Z, >= na rp (the columns past na rp are not written)
+extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const void *planes, const float *scale,
                                          const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (!eap_so3_dense_supported(p, na, ks, rp, o)) return eap::bad_arg("so3_dense_product: shape not taken (eap_so3_dense_supported)");
@@ -695,7 +708,8 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     if (dir == 0) {
         g.strT = ptT; g.strB = p_pad; g.strA = 0;
         g.colT = krT; g.colB = (long long)na * kd_pad; g.colA = kd_pad;
-        g.cB = (long long)o * ks * na * rp; g.cA = rp; g.ldm = (long long)ks * na * rp; g.rp = rp; g.kstride = (long long)na * rp;
+        if (ldz < (int64_t)na * rp) return eap::bad_arg("so3_dense_product: ldz < na rp");
+        g.cB = (long long)o * ks * ldz; g.cA = rp; g.ldm = (long long)ks * ldz; g.rp = rp; g.kstride = ldz;
     } else {
         g.strT = krT; g.strB = (long long)na * kd_pad; g.strA = kd_pad;
         g.colT = ptT; g.colB = p_pad; g.colA = 0;

@@ -539,36 +539,48 @@ class DenseGeometry:
         return m
 
 
-def so3_dense_split(src):
+def so3_dense_split(src, seg=0, seg_pitch=0, shape=None):
     """src [b,m,l,na] -> (scale [2,b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
-    fragment order)."""
-    b, m, l, na = src.shape
+    fragment order).  seg > 0 (with shape = (b, m, l, na)): a row's l elements lie in l / seg segments of seg elements whose
+    starts are seg_pitch floats apart (the rows of a GEMM output with padded columns)."""
+    b, m, l, na = src.shape if shape is None else shape
     scale = torch.empty(2, b, na, m, dtype=torch.float32, device=src.device)      # [0]: [b,na,m]; [1]: the same numbers as [b,m,na]
     planes = torch.empty(b * na * m * ((l + 31) // 32 * 32), dtype=torch.int32, device=src.device)       # 4 bytes per element
-    call('eap_so3_dense_split_f32', src, b, m, l, na, _ptr(src), _ptr(scale), _ptr(planes))
+    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), _ptr(src), _ptr(scale), _ptr(planes))
     return scale, planes
 
 
-def so3_dense_bwd(gy, geo):
-    """gy [b,o,p,na] -> Z [b,o,ks,na,rp] (the inverse-list kernel's Z with the anchor axis in front of the row axis)."""
+def dense_pitch(n):
+    """Row pitch for a matrix with n columns that the split contraction kernels take as an operand (whole 128-column tiles)."""
+    return (n + 127) // 128 * 128
+
+
+def so3_dense_bwd(gy, geo, ldz=None):
+    """gy [b,o,p,na] -> Z [b,o,ks,ldz] whose rows hold [na,rp] (the inverse-list kernel's Z with the anchor axis in front of the row
+    axis); ldz >= na*rp (default: equal) pads the rows for the GEMMs that follow -- the padding is NOT written."""
     b, o, p, na = gy.shape
+    ldz = na * geo.rp if ldz is None else int(ldz)
     scale, planes = so3_dense_split(gy)
-    z = torch.empty(b, o, geo.ks, na, geo.rp, dtype=torch.float32, device=gy.device)
-    call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr), _ptr(geo.mask(0)),
-         _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
-                       'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
+    z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
+    call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
+         _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
+                                        'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
     return z
 
 
-def so3_dense_fwd(g, geo, p, c=0):
-    """g [b,o,ks*rp,na] (= W . F over the referenced rows, F with c channels) -> y [b,o,p,na].  (c only prices the launch for
-    bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)"""
-    b, o, kd, na = g.shape
-    scale, planes = so3_dense_split(g)
+def so3_dense_fwd(g, geo, p, c=0, ldg=None):
+    """g [b,o,ks,ldg] (rows hold [rp,na]: W . F over the referenced rows, F with c channels; ldg >= rp*na, default equal) -> y [b,o,p,na].
+    (c only prices the launch for bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)"""
+    b, o = g.shape[:2]
+    na = geo.na
+    if ldg is None:
+        scale, planes = so3_dense_split(g.view(b, o, geo.ks * geo.rp, na))
+    else:
+        scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=int(ldg), shape=(b, o, geo.ks * geo.rp, na))
     yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
-    call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr), _ptr(geo.mask(1)),
-         _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp), 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
-                        'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
+    call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
+         _ptr(geo.mask(1)), _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp),
+                                         'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp, 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
     call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y))

@@ -624,29 +624,38 @@ def _dense_wanted(head, o, p, na, ks, nn, n):
     return rp, o % 256 == 0
 
 
-def _weight_grad_from_z(z, fc, b, c, o, ks, ra):
-    """dW[o,(c,k)] = sum_{b,(r,a)} Z[b,o,k,(r,a)] Fc[b,c,(r,a)] for Z [b, o*ks, ra] and the referenced feature rows Fc [b, c, ra]
-    (any order of the (row, anchor) axis, the same in both)."""
-    if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, o * ks):
+def _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz=None):
+    """dW[o,(c,k)] = sum_{b,(r,a)} Z[b,o,k,(r,a)] Fc[b,c,(r,a)] for Z [b, o*ks, ra] (row pitch ldz >= ra) and the referenced feature
+    rows Fc [b, c, ra] (any order of the (row, anchor) axis, the same in both)."""
+    ldz = ra if ldz is None else ldz
+    if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ldz, o * ks * ldz, o * ks):
         # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
         # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe
         dt = torch.empty(c, o * ks, dtype=torch.float32, device=z.device)
-        _hip.gemm_reduce(0, 1, c, o * ks, ra, fc, ra, c * ra, z, ra, o * ks * ra, dt, o * ks, b)
+        _hip.gemm_reduce(0, 1, c, o * ks, ra, fc, ra, c * ra, z, ldz, o * ks * ldz, dt, o * ks, b)
         return dt.view(c, o, ks).permute(1, 0, 2).reshape(o, c * ks).contiguous()
     d = torch.empty(o * ks, c, dtype=torch.float32, device=z.device)    # sum_b Z_b Fc_b^T
-    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ra, o * ks * ra, fc, ra, c * ra, d, c, b)
+    _hip.gemm_reduce(0, 1, o * ks, c, ra, z, ldz, o * ks * ldz, fc, ra, c * ra, d, c, b)
     return d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
 
 
 def _dense_forward(feats, W, rows, geo, p):
-    """y [b,o,p,a] = sum_(k,r) G[o,(k,r),a] Wd[p,(k,r),a] with G = W F over the referenced rows (csrc/so3_dense.hip)."""
+    """y [b,o,p,a] = sum_(k,r) G[o,(k,r),a] Wd[p,(k,r),a] with G = W F over the referenced rows (csrc/so3_dense.hip).  The small
+    GEMM that makes G runs on the split-operand kernels where its shapes allow: its columns (row, anchor) padded to whole
+    128-column tiles (the padding of F is zero, G's padded columns are skipped by the split that follows)."""
     b, c, n, na = feats.shape
     o, ks, rp = W.shape[0], geo.ks, geo.rp
-    fc = _hip.rows_gather(feats, rows, rp)                                        # [b,c,rp,na]; empty slots: zeros
+    ra = rp * na
     W3 = W.view(o, c, ks).permute(0, 2, 1).reshape(o * ks, c).contiguous()
-    g = torch.empty(b, o * ks, rp * na, dtype=torch.float32, device=feats.device)
-    _hip.gemm(0, 0, o * ks, rp * na, c, W3, c, 0, fc, rp * na, c * rp * na, g, rp * na, o * ks * rp * na, b)
-    return _hip.so3_dense_fwd(g.view(b, o, ks * rp, na), geo, p, c)
+    ld = _hip.dense_pitch(ra) if (c % 16 == 0 and c >= 16 and (o * ks) % 128 == 0) else ra
+    if ld == ra:
+        fc = _hip.rows_gather(feats, rows, rp).view(b, c, ra)                     # [b,c,(r,a)]; empty slots: zeros
+    else:
+        fc = torch.zeros(b, c, ld, dtype=torch.float32, device=feats.device)
+        fc[:, :, :ra] = _hip.rows_gather(feats, rows, rp).view(b, c, ra)
+    g = torch.empty(b, o * ks, ld, dtype=torch.float32, device=feats.device)
+    _hip.gemm(0, 0, o * ks, ld, c, W3, c, 0, fc, ld, c * ld, g, ld, o * ks * ld, b)
+    return _hip.so3_dense_fwd(g.view(b, o, ks, ld), geo, p, c, ldg=None if ld == ra else ld)
 
 
 class _InterConv(torch.autograd.Function):
@@ -768,17 +777,20 @@ class _InterConv(torch.autograd.Function):
             geo = ctx.dense[0]
             if BACKWARD_LOG is not None:
                 BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(geo.rp), 'regime': 'dense rows'})
-            z = _hip.so3_dense_bwd(gy, geo)                                          # [b,o,ks,na,rp]: the lists' Z with the anchor axis in front
             rp = geo.rp
             ra = na * rp
+            # Z's rows padded to whole 128-column tiles where that puts the feature-gradient GEMM on the split-operand kernels
+            # (the padding is never written: garbage columns of gFc nobody reads; the weight gradient contracts over ra columns)
+            ldz = _hip.dense_pitch(ra) if (c % 128 == 0 and (o * ks) % 16 == 0 and ctx.needs_input_grad[0]) else ra
+            z = _hip.so3_dense_bwd(gy, geo, ldz)                                     # [b,o,ks,ldz] rows = [na,rp]: the lists' Z, anchor axis in front
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
-                gFc = torch.empty(b, c, ra, dtype=torch.float32, device=gy.device)
-                _hip.gemm(0, 0, c, ra, o * ks, W2, o * ks, 0, z, ra, o * ks * ra, gFc, ra, c * ra, b)
-                gF = _hip.rows_scatter(gFc.view(b, c, na, rp).transpose(2, 3).contiguous(), head.rows, n)
+                gFc = torch.empty(b, c, ldz, dtype=torch.float32, device=gy.device)
+                _hip.gemm(0, 0, c, ldz, o * ks, W2, o * ks, 0, z, ldz, o * ks * ldz, gFc, ldz, c * ldz, b)
+                gF = _hip.rows_scatter(gFc[:, :, :ra].reshape(b, c, na, rp).transpose(2, 3).contiguous(), head.rows, n)
             if ctx.needs_input_grad[1]:
                 fc = _hip.rows_gather(feats, head.rows, rp).transpose(2, 3).contiguous().view(b, c, ra)      # [b,c,(a,r)]
-                gW = _weight_grad_from_z(z, fc, b, c, o, ks, ra)
+                gW = _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz)
             return gF, gW, None, None, None, None, None, None, None, None, None, None, None
         if head is not None:
             rcap, any_nonident = head.decide()

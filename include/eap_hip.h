@@ -342,7 +342,10 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *                             kr float4 [b, na, ceil32(ks rp)]: the two sides of the weight (centred coordinates), evaluated in float64
  *   eap_so3_dense_split_f32   src [b,m,l,na] -> scale [2][b,na,m] (power of two per row; the second copy as [b,m,na]) and the two fp16 planes of the scaled
  *                             rows in the product kernel's fragment order: 4 b na m ceil32(l) bytes
- *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1)
+ *                             (seg > 0: a row's l elements come in segments of seg elements seg_pitch floats apart -- G as a GEMM with
+ *                             padded columns leaves it)
+ *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1); dir 0 writes
+ *                             Z with ldz >= na rp floats between its (o, k) rows (padding for the GEMMs that follow, not written)
  *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na] */
 int eap_so3_dense_supported(int p, int na, int ks, int rp, int o);
 int eap_so3_dense_form(int form);
@@ -353,8 +356,9 @@ int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const uint32_t *m
 int eap_so3_dense_tables_f32(int b, int p, int n, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
                              const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
                              eap_stream_t stream);
-int eap_so3_dense_split_f32(int b, int m, int l, int na, const float *src, float *scale, void *planes, eap_stream_t stream);
-int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, float sigma, const void *planes, const float *scale,
+int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, const float *src, float *scale, void *planes,
+                            eap_stream_t stream);
+int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const void *planes, const float *scale,
                               const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream);
 int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, eap_stream_t stream);
 

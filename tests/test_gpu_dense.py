@@ -115,7 +115,7 @@ def test_generated_weights_and_backward_product(dev, P, layer):
     for p0 in (0, P - o):
         gy = torch.zeros(B, o, P, NA, device=dev)
         gy[:, torch.arange(o), p0 + torch.arange(o), :] = 1.0
-        z = _hip.so3_dense_bwd(gy, geo)                                       # [B,o,K,A,rp]
+        z = _hip.so3_dense_bwd(gy, geo).view(B, o, KS, NA, rp)               # [B,o,K,A,rp]
         ref = wd[:, p0:p0 + o].permute(0, 1, 4, 3, 2)                         # [B,o,K,A,rp]
         assert z.shape == ref.shape
         err = float((z.double() - ref).abs().max())
@@ -123,14 +123,14 @@ def test_generated_weights_and_backward_product(dev, P, layer):
         assert float(ref.max()) > 0.5                                          # not vacuous
     gen = torch.Generator(device=dev).manual_seed(5)
     gy = torch.randn(B, o, P, NA, device=dev, generator=gen) * torch.exp(2 * torch.randn(B, o, 1, NA, device=dev, generator=gen))
-    z = _hip.so3_dense_bwd(gy, geo)
+    z = _hip.so3_dense_bwd(gy, geo).view(B, o, KS, NA, rp)
     ref = torch.einsum('bopa,bprak->bokar', gy.double(), wd)
     # bound: the products (1e-6 of sum |dY| w) + the weights' own evaluation error (5e-7 absolute, 4 x below the bar above) on
     # every list member
     mag = torch.einsum('bopa,bprak->bokar', gy.double().abs(), wd)
     magm = torch.einsum('bopa,bpr->boar', gy.double().abs(), _member(s, head.rows, rp))[:, :, None]
     assert float(((z.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
-    z2 = _hip.so3_dense_bwd(gy, geo)
+    z2 = _hip.so3_dense_bwd(gy, geo).view(B, o, KS, NA, rp)
     assert torch.equal(z, z2)                                                  # bit-reproducible
 
 
@@ -147,9 +147,17 @@ def test_backward_product_matches_the_list_kernel(dev):
     gy = torch.randn(2, 256, 512, NA, device=dev, generator=gen)
     z_list = _hip.so3_inter_group_inv(gy, head.rows[:, :rp].contiguous(), head.off[:, :rp].contiguous(), head.cnt[:, :rp].contiguous(),
                                       ent_p, ent_gx, s['rk'], None, s['sigma'], NN)                  # [b,o,ks,rp,na]
-    z = _hip.so3_dense_bwd(gy, geo)
+    z = _hip.so3_dense_bwd(gy, geo).view(2, 256, KS, NA, rp)
     scale = float(z_list.abs().max())
     assert float((z.transpose(3, 4) - z_list).abs().max()) < 1e-5 * scale
+    # rows padded to a pitch: the same numbers, the padding untouched
+    ld = NA * rp + 40
+    zp = torch.full((2, 256, KS, ld), 7.0, device=dev)
+    from vgtk._hip import _ptr, _I64, _F32
+    sc, pl = _hip.so3_dense_split(gy)
+    _hip.call('eap_so3_dense_product_f32', gy, 0, 2, 256, 512, NA, KS, rp, _I64(ld), _F32(geo.sigma), _ptr(pl), _ptr(sc), _ptr(geo.pt), _ptr(geo.kr),
+              _ptr(geo.mask(0)), _ptr(zp))
+    assert torch.equal(zp[..., :NA * rp].reshape(2, 256, KS, NA, rp), z) and float((zp[..., NA * rp:] - 7.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1)])
@@ -162,13 +170,18 @@ def test_forward_product(dev, P, layer):
     wd = _dense_weights64(s, head.rows, rp)                                   # [B,P,rp,A,K]
     gen = torch.Generator(device=dev).manual_seed(9)
     g = torch.randn(B, o, KS, rp, NA, device=dev, generator=gen) * torch.exp(2 * torch.randn(B, o, 1, 1, NA, device=dev, generator=gen))
-    y = _hip.so3_dense_fwd(g.view(B, o, KS * rp, NA), geo, P)
+    y = _hip.so3_dense_fwd(g.view(B, o, KS, rp * NA), geo, P)
     assert y.shape == (B, o, P, NA)
+    # the same operand with padded rows [o, k, pitch] (what the small GEMM in front leaves): bit-equal
+    ld = rp * NA + 56
+    gp = torch.full((B, o, KS, ld), float('nan'), device=dev)
+    gp[..., :rp * NA] = g.view(B, o, KS, rp * NA)
+    assert torch.equal(_hip.so3_dense_fwd(gp, geo, P, ldg=ld), y)
     ref = torch.einsum('bokra,bprak->bopa', g.double(), wd)
     mag = torch.einsum('bokra,bprak->bopa', g.double().abs(), wd)
     magm = torch.einsum('bokra,bpr->bopa', g.double().abs(), _member(s, head.rows, rp))
     assert float(((y.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
-    assert torch.equal(y, _hip.so3_dense_fwd(g.view(B, o, KS * rp, NA), geo, P))
+    assert torch.equal(y, _hip.so3_dense_fwd(g.view(B, o, KS, rp * NA), geo, P))
 
 
 def _layer_run(dev, monkeypatch, mode, xyz, pose, feats0, W0, c, o, radius, sigma):

@@ -18,7 +18,7 @@ for kind in ('randn', 'rowscale', 'const', 'quant'):
         gy = torch.ones_like(gy) * 0.7371
     if kind == 'quant':
         gy = gy.half().float()       # l plane zero (up to scale: power of two)
-    z = _hip.so3_dense_bwd(gy, geo)
+    z = _hip.so3_dense_bwd(gy, geo).view(B, o, 24, NA, rp)
     ref = torch.einsum('bopa,bprak->bokar', gy.double(), wd)
     mag = torch.einsum('bopa,bprak->bokar', gy.double().abs(), wd)
     e = ((z.double() - ref).abs() / mag.clamp(min=1e-30))

@@ -46,7 +46,7 @@ for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
     geo.mask(0); geo.mask(1)
     t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(gy))
     z = torch.empty(B, o, KS, NA, rp, device=dev)
-    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', gy, 0, B, o, P, NA, KS, rp, _hip._F32(sigma), _hip._ptr(planes), _hip._ptr(scale),
+    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', gy, 0, B, o, P, NA, KS, rp, _hip._I64(NA * rp), _hip._F32(sigma), _hip._ptr(planes), _hip._ptr(scale),
                                         _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(0)), _hip._ptr(z)))
     fl = 6.0 * B * o * P * NA * KS * rp
     print(f'form {form} backward: tables {t_tab:.2f} ms, split {t_split:.2f} ms, product {t_prod:.2f} ms = {fl / t_prod / 1e9:.0f} TFLOP/s fp16 '
@@ -54,7 +54,7 @@ for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
     del planes, scale, z
     t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(g))
     yt = torch.empty(B, NA, o, P, device=dev)
-    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', g, 1, B, o, P, NA, KS, rp, _hip._F32(sigma), _hip._ptr(planes), _hip._ptr(scale),
+    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', g, 1, B, o, P, NA, KS, rp, _hip._I64(0), _hip._F32(sigma), _hip._ptr(planes), _hip._ptr(scale),
                                         _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(1)), _hip._ptr(yt)))
     y = torch.empty(B, o, P, NA, device=dev)
     t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_f32', g, B, o, P, NA, _hip._ptr(yt), _hip._ptr(y)))
