@@ -57,6 +57,17 @@ typedef const __attribute__((address_space(4))) unsigned long long *cu64p;      
 
 constexpr int KC_BK = 32;                 // contraction elements per k-step (two MFMA k-blocks of 16)
 
+// The DENSE INDEX d of a (kernel point k, row slot r) pair: d = (r / 16) 16 ks + 16 k + r % 16 -- groups of 16 row slots outermost,
+// then the kernel point, then the 16 slots.  Rows are sorted longest list first and every cloud has its own count R <= rp, so a
+// cloud uses the PREFIX d < ceil16(R) ks of the index range: the product kernel ends its column blocks (backward) / its k-steps
+// (forward) there instead of multiplying by the empty slots of the batch-wide rp (16 % of the work at the bench clouds:
+// 86..136 rows per cloud).  16 consecutive d = 16 rows of one kernel point; rp % 16 == 0.
+__host__ __device__ __forceinline__ void dense_kr(int d, int ks, int &k, int &r) {
+    const int g = d / (16 * ks), rem = d - g * 16 * ks;
+    k = rem >> 4;
+    r = 16 * g + (rem & 15);
+}
+
 __device__ inline unsigned lds_addr(const void *ptr) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)ptr;
 }
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256) void dense_member_kernel(int p, int n_sup, int
 
 // bits[b][wave tile wt][step][lane]: bit 16 t + 8 j + e of the lane's dword  <->  column n = 64 wt + 32 j + (lane & 31), contraction index
 // kk = 32 step + 16 t + 8 (lane >> 5) + e -- the 32 weights the lane generates in a k-step of the product kernel
-//   dir 0 (backward): kk = point, n = (k, r) = (n / rp, n % rp), n < ks rp        dir 1 (forward): kk = (k, r), n = point
+//   dir 0 (backward): kk = point, n = dense index of (k, r), n < ks rp        dir 1 (forward): kk = dense index of (k, r), n = point
 __global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, int dir, int wtiles, int steps,
                                                          const unsigned *__restrict__ memb, unsigned *__restrict__ bits) {
     constexpr int W = MEMB_WORDS;
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, 
         const int kk = 32 * step + 16 * tt + 8 * (lane >> 5) + e;
         const int pt = dir ? n : kk, kr = dir ? kk : n;
         if (pt < p && kr < nkr) {
-            const int r = kr % rp;
+            int k_, r;
+            dense_kr(kr, ks, k_, r);
             word |= ((memb[((size_t)b * p + pt) * W + (r >> 5)] >> (r & 31)) & 1u) << i;
         }
     }
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256) void dense_points_kernel(int p, int p_pad, int
     pt[(size_t)b * p_pad + i] = v;
 }
 
-// kr[b][a][k rp + r], u = x~_row(r) - rk[a][k]: FORM 1 (u, 0); FORM 0 (u, 1 - |u|^2/sigma); entries past ks rp and empty
+// kr[b][a][dense index of (k, r)], u = x~_row(r) - rk[a][k]: FORM 1 (u, 0); FORM 0 (u, 1 - |u|^2/sigma); entries past ks rp and empty
 // slots: far away (FORM 1) / zeros (FORM 0) -- weight 0 either way, and their mask bits are 0
 __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int ks, int rp, int kd_pad, int rows_ld, int form, float inv_sigma,
                                                          const float *__restrict__ s_xyz, const float *__restrict__ centre,
@@ -212,7 +224,8 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int 
     if (i >= kd_pad) return;
     f32x4 v = form ? (f32x4){1e4f, 1e4f, 1e4f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (i < ks * rp) {
-        const int k = i / rp, r = i - k * rp;
+        int k, r;
+        dense_kr(i, ks, k, r);
         const int row = rows[(size_t)b * rows_ld + r];
         if ((unsigned)row < (unsigned)n_sup) {
             const double is = (double)inv_sigma;
@@ -267,17 +280,22 @@ __global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na,
 // One block per (b, mt, kb): thread (anchor quad aq = t % nq, row group t / nq) takes the 8 elements of (row, kg) for its four
 // anchors -- 8 float4 loads 4 na bytes apart, the nq threads of a row covering each element's 4 na contiguous bytes -- and
 // writes its 8 pieces; the 64 pieces of a 1 KB run come from one block within a few hundred cycles.
-__global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, int seg, long long seg_pitch4, const f32x4 *__restrict__ T,
+// mapped (the forward's G, seg = rp, l = ks rp): element l of a row is the pair (k, r) with DENSE INDEX l, found at segment k,
+// position r; k-blocks past the cloud's own prefix (n_rows) are not written -- the product never reads them.
+__global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, int seg, long long seg_pitch4, int mapped,
+                                                          const int32_t *__restrict__ n_rows, const f32x4 *__restrict__ T,
                                                           const float *__restrict__ scale2, u32x4 *__restrict__ planes) {
     const int b = blockIdx.z, mt = blockIdx.y, kb = blockIdx.x, t = threadIdx.x;
     const int nq = na >> 2, RG = 256 / nq;                      // rows per pass
     const int aq = t % nq, rr = t / nq;
     if (rr >= RG) return;
-    const int MT = m >> 5;
+    const int MT = m >> 5, nseg = l / seg;
+    if (mapped && n_rows != nullptr && 16 * kb >= ((min(n_rows[b], seg) + 15) & ~15) * nseg) return;
     for (int it = rr; it < 64; it += RG) {                      // item = (row i, k half kg)
         const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
         const f32x4 *src = T + ((size_t)b * m + row) * (size_t)(l / seg) * seg_pitch4 + aq;
         int sg = l0 / seg, sr = l0 - sg * seg;                    // segment and position of element l0 + e
+        if (mapped) dense_kr(l0, nseg, sg, sr);                   // (8 consecutive dense indices: one kernel point, 8 consecutive slots)
         f32x4 q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -314,6 +332,20 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int
     }
 }
 
+// Z[b][o][k][a][r] = 0 for the row slots r >= ceil16(n_rows[b]) the trimmed backward product does not write (the GEMMs that follow
+// contract over them against zero feature rows: 0 x garbage must not be NaN)
+__global__ __launch_bounds__(256) void dense_zero_tail_kernel(int rows_ok, int na, int rp, long long ldz, const int32_t *__restrict__ n_rows,
+                                                              float *__restrict__ z) {
+    const int b = blockIdx.y, row = blockIdx.x;                           // one block per (o, k) row of a cloud
+    const int r0 = (min(n_rows[b], rp) + 15) & ~15, tail = rp - r0;
+    if (tail <= 0) return;
+    float *dst = z + ((long long)b * rows_ok + row) * ldz;
+    for (int e = threadIdx.x; e < na * tail; e += 256) {
+        const int a = e / tail;
+        dst[(long long)a * rp + r0 + (e - a * tail)] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // the product
 // ------------------------------------------------------------------------------------------------------------------------
@@ -326,6 +358,8 @@ struct KcArgs {
     const f32x4 *colT; long long colB, colA;     // column-side table
     const unsigned *mask;                 // [b][mask_tiles wave tiles][KS][64 lanes] mask bits
     float neg_inv_sigma;                  // FORM 1
+    const int32_t *n_rows; int ks, trim;  // referenced rows per cloud; trim 1: the columns are dense indices cut at the cloud's prefix (backward), 3: not cut,
+                                          // 2: the k axis is cut at the cloud's prefix (forward), 0: not cut
     float *C; long long cB, cA, ldm; int rp; long long kstride;     // element (row, n) of (b, a) at C[b cB + a cA + row ldm + (n / rp) kstride + n % rp]
 };
 
@@ -360,17 +394,22 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     }
     const int bm = local % g.tiles_m, bn = local / g.tiles_m;
     const int b = z / g.na, a = z - b * g.na;
+    // this cloud's prefix of the dense index range (see dense_kr): whole 16-row groups of its own referenced rows
+    const int used = (g.trim == 1 || g.trim == 2) ? ((min(g.n_rows[b], g.rp) + 15) & ~15) * g.ks : 0;      // (trim 3 / 0: dense indices, every slot)
+    const int N = g.trim == 1 ? min(g.N, used) : g.N;
+    const int KS = g.trim == 2 ? max(min(g.KS, used / KC_BK), 1) : g.KS;
+    if (256 * bn >= N) return;                             // (block-uniform, before any barrier)
 
     const int t = threadIdx.x, lane = t & 63, li = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wt = bn * 4 + wave;                          // this wave's 64 columns
-    const bool active = 64 * wt < g.N;                     // (wave-uniform)
+    const bool active = 64 * wt < N;                       // (wave-uniform)
 
     // ---- per-lane column constants ----
     const f32x4 *colz = g.colT + b * g.colB + a * g.colA;
     f32x4 cc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) cc[j] = colz[min(64 * wt + 32 * j + li, g.N - 1)];
+    for (int j = 0; j < 2; ++j) cc[j] = colz[min(64 * wt + 32 * j + li, N - 1)];
     const float nis = g.neg_inv_sigma;
 
     // ---- DMA.  Per k-step a wave moves 10 pieces: its 8 KB of the block's 32 KB of the stored operand (contiguous in memory AND in
@@ -510,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     };
 
     // ---- prologue: stages 0, 1, 2 <- k-steps 0, 1, 2 (past the last step: the last step again, into a stage nobody reads) ----
-    const int last = g.KS - 1;
+    const int last = KS - 1;
     issue(0, 0);
     issue(min(1, last), STAGE);
     issue(min(2, last), 2 * STAGE);
@@ -536,7 +575,7 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     //      stage (s + 3) % 4 (read during step s - 1) for the pieces of k-step s + 3, which are issued one or two at a time at the
     //      head of the six products of the step ----
     unsigned s0 = 0, s1 = STAGE, s2 = 2 * STAGE, s3 = 3 * STAGE;
-    for (int s = 0; s < g.KS; ++s) {
+    for (int s = 0; s < KS; ++s) {
         if (s > 0) {
             if constexpr (MI == 8) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -577,9 +616,10 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = 64 * wt + 32 * j + li;
-        if (n >= g.N) continue;
-        const int k = n / g.rp;
-        const long long coff = (long long)k * g.kstride + (n - k * g.rp);
+        if (n >= N) continue;
+        int k = n / g.rp, r = n - k * g.rp;                  // (untrimmed: plain columns, rp = N)
+        if (g.trim & 1) dense_kr(n, g.ks, k, r);
+        const long long coff = (long long)k * g.kstride + r;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -622,7 +662,7 @@ extern "C" int eap_so3_dense_form(int form) {
 }
 
 extern "C" int eap_so3_dense_supported(int p, int na, int ks, int rp, int o) {
-    return p > 0 && (p % 32) == 0 && na > 0 && (na % 4) == 0 && na <= 64 && ks > 0 && rp > 0 && (rp % 4) == 0 && rp <= 32 * MEMB_WORDS &&
+    return p > 0 && (p % 32) == 0 && na > 0 && (na % 4) == 0 && na <= 64 && ks > 0 && (ks % 2) == 0 && rp > 0 && (rp % 16) == 0 && rp <= 32 * MEMB_WORDS &&
            (o % 128) == 0;
 }
 
@@ -670,27 +710,30 @@ extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks,
 }
 
 // seg / seg_pitch: a row's l elements in l / seg segments of seg elements whose starts are seg_pitch floats apart (seg <= 0: one
-// segment: src is plain [b,m,l,na])
-extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, const float *src, float *scale, void *planes,
-                                       eap_stream_t stream) {
+// segment: src is plain [b,m,l,na]).  mapped (the forward's G: seg = rp, l = ks rp): element l of the OUTPUT is the pair (k, r)
+// whose dense index is l (eap_so3_dense_product_f32), read from segment k, position r; with n_rows [b] the k-blocks past a
+// cloud's own prefix are left unwritten.
+extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const float *src,
+                                       float *scale, void *planes, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (seg <= 0) { seg = l; seg_pitch = (int64_t)l * na; }
     if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || (reinterpret_cast<uintptr_t>(src) & 15) || l % seg != 0 ||
-        (seg_pitch & 3) != 0 || seg_pitch < (int64_t)seg * na)
-        return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source, whole segments of a 16-byte aligned pitch");
+        (seg_pitch & 3) != 0 || seg_pitch < (int64_t)seg * na || (mapped && ((seg % 16) != 0 || ((l / seg) % 2) != 0)))
+        return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source, whole segments of a 16-byte aligned pitch (mapped: seg % 16, an even number of segments)");
     hipStream_t s = eap::S(stream);
     const int kb_total = ceil_to(l, KC_BK) / 16;
     float *scale2 = scale + (size_t)b * na * m;
     hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), reinterpret_cast<const f32x4 *>(src), scale, scale2);
-    hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total, seg, (long long)(seg_pitch / 4),
-                       reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
+    hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total, seg, (long long)(seg_pitch / 4), mapped ? 1 : 0,
+                       n_rows, reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
     return eap::check_launch("so3_dense_split");
 }
 
-// dir 0: Z[b][o][k][a][r] = sum_p dY Wd (planes of dY [b,o,p,a]);  dir 1: Yt[b][a][o][p] = sum_(k,r) G Wd (planes of G [b,o,(k,r),a])
 // ldz (dir 0): floats between consecutive (o, k) rows of Z, >= na rp (the columns past na rp are not written)
-extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const void *planes, const float *scale,
-                                         const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream) {
+// n_rows [b] (may be null: no trimming): referenced rows per cloud -- a cloud's products end at ceil16(n_rows[b]) row slots (dir 0: the
+// slots past it are ZEROED in Z, not computed)
+extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
+                                         const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (!eap_so3_dense_supported(p, na, ks, rp, o)) return eap::bad_arg("so3_dense_product: shape not taken (eap_so3_dense_supported)");
     const int p_pad = ceil_to(p, KC_BK), kd_pad = ceil_to(ks * rp, KC_BK);
@@ -718,6 +761,12 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     g.mask = reinterpret_cast<const unsigned *>(mask);
     g.C = out;
     g.neg_inv_sigma = -1.0f / sigma;
+    g.n_rows = n_rows; g.ks = ks; g.trim = dir ? 2 : 1;       // (columns / k axis are dense indices either way; without n_rows every slot counts)
+    if (n_rows == nullptr) g.trim = dir ? 0 : 3;
+    if (dir == 0 && n_rows != nullptr) {
+        hipLaunchKernelGGL(dense_zero_tail_kernel, dim3(o * ks, b), dim3(256), 0, eap::S(stream), o * ks, na, rp, (long long)ldz, n_rows, out);
+        if (int e = eap::check_launch("so3_dense zero tail")) return e;
+    }
 #ifdef EAP_ABLATION
     if (const char *d = wide ? getenv("EAP_DENSE_DEBUG") : nullptr) {
         switch (atoi(d)) {

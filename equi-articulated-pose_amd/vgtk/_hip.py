@@ -515,12 +515,13 @@ class DenseGeometry:
     rotations: the lane masks of both directions (built on demand from the membership bits) and the two float4 tables of the
     expanded weight, for the first rp referenced rows of every cloud."""
 
-    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn):
+    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn, n_rows=None):
         b, p = memb.shape[:2]
         n = s_xyz.shape[2]
         na, ks, _ = rk.shape
         dev = memb.device
         self.b, self.p, self.na, self.ks, self.rp, self.nn, self.memb, self.sigma = b, p, na, ks, int(rp), int(nn), memb, float(sigma)
+        self.n_rows = n_rows                      # int32 [b] or None: the products stop at every cloud's own rows (include/eap_hip.h)
         p_pad, kd_pad = (p + 31) // 32 * 32, (ks * self.rp + 31) // 32 * 32
         self.centre = torch.empty(b, 4, dtype=torch.float32, device=dev)
         self.pt = torch.empty(b, p_pad, 4, dtype=torch.float32, device=dev)
@@ -539,14 +540,15 @@ class DenseGeometry:
         return m
 
 
-def so3_dense_split(src, seg=0, seg_pitch=0, shape=None):
+def so3_dense_split(src, seg=0, seg_pitch=0, shape=None, mapped=False, n_rows=None):
     """src [b,m,l,na] -> (scale [2,b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
     fragment order).  seg > 0 (with shape = (b, m, l, na)): a row's l elements lie in l / seg segments of seg elements whose
-    starts are seg_pitch floats apart (the rows of a GEMM output with padded columns)."""
+    starts are seg_pitch floats apart (the rows of a GEMM output with padded columns).  mapped: the output's element l is the
+    (k, r) pair with dense index l (the forward's operand), n_rows trims every cloud to its own rows."""
     b, m, l, na = src.shape if shape is None else shape
     scale = torch.empty(2, b, na, m, dtype=torch.float32, device=src.device)      # [0]: [b,na,m]; [1]: the same numbers as [b,m,na]
     planes = torch.empty(b * na * m * ((l + 31) // 32 * 32), dtype=torch.int32, device=src.device)       # 4 bytes per element
-    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), _ptr(src), _ptr(scale), _ptr(planes))
+    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), int(bool(mapped)), _ptr(n_rows), _ptr(src), _ptr(scale), _ptr(planes))
     return scale, planes
 
 
@@ -562,7 +564,7 @@ def so3_dense_bwd(gy, geo, ldz=None):
     ldz = na * geo.rp if ldz is None else int(ldz)
     scale, planes = so3_dense_split(gy)
     z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
-    call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
+    call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
          _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
                                         'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
     return z
@@ -573,12 +575,10 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None):
     (c only prices the launch for bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)"""
     b, o = g.shape[:2]
     na = geo.na
-    if ldg is None:
-        scale, planes = so3_dense_split(g.view(b, o, geo.ks * geo.rp, na))
-    else:
-        scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=int(ldg), shape=(b, o, geo.ks * geo.rp, na))
+    ldg = geo.rp * na if ldg is None else int(ldg)
+    scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg, shape=(b, o, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
     yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
-    call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
+    call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
          _ptr(geo.mask(1)), _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp),
                                          'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp, 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes

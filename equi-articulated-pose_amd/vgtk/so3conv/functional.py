@@ -605,7 +605,8 @@ DENSE_ROW_FACTOR = 5.0
 
 
 def _dense_rows(rcap, n):
-    return min((rcap + 3) & ~3, n)
+    """row slots of the dense product: whole groups of 16 (csrc/so3_dense.hip, dense index)"""
+    return (rcap + 15) & ~15
 
 
 def _dense_wanted(head, o, p, na, ks, nn, n):
@@ -615,7 +616,7 @@ def _dense_wanted(head, o, p, na, ks, nn, n):
         return 0, False
     rcap, _ = head.decide()
     rp = _dense_rows(rcap, n)
-    if rp <= 0 or rp % 4 or not head.dense_possible() or not _hip.so3_dense_supported(p, na, ks, rp, o):
+    if rp <= 0 or rp > n or not head.dense_possible() or not _hip.so3_dense_supported(p, na, ks, rp, o):
         return 0, False
     if DENSE_MODE == 'force':
         return rp, True
@@ -691,7 +692,7 @@ class _InterConv(torch.autograd.Function):
         # (a folded inference epilogue does not stop it: the dense forward leaves `epilogue.applied` False and the caller runs the
         # norm as a pass of its own -- cheaper than giving up the dense product for the 128 -> 512 layer)
         if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0)
-                and _hip.so3_dense_supported(p, na, ks, 4, o)):
+                and _hip.so3_dense_supported(p, na, ks, 16, o)):
             probe = (geometry[2], geometry[3])
         head = None
         if (lists_ok and needs_grad) or probe is not None:
@@ -699,10 +700,10 @@ class _InterConv(torch.autograd.Function):
         rp, dense_fwd = _dense_wanted(head, o, p, na, ks, idx.shape[2], n) if probe is not None else (0, False)
         ctx.dense = None
         if rp > 0 and needs_grad:                         # (built by whoever needs it first: the forward below, or the backward)
-            ctx.dense = [None, (geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2])]
+            ctx.dense = [None, (geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)]
         if rp > 0 and dense_fwd:
             head.wait()
-            geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2])
+            geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)
             y = _dense_forward(feats, W, head.rows, geo, p)
             ctx.head = head if needs_grad else None
             if needs_grad:

@@ -328,10 +328,12 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *     Wd[p,(k,r),a] = m[p,r] relu(1 - |x_row(r) - x_p - rk[a,k]|^2 / sigma)
  *     dir 0 (backward)  Z [b,o,k,a,r]   = sum_p      dY[b,o,p,a]     Wd[p,(k,r),a]
  *     dir 1 (forward)   Yt[b,a,o,p]     = sum_(k,r)  G [b,o,(k,r),a] Wd[p,(k,r),a]      (G = W F over the referenced rows)
- * on the fp16 matrix cores with two planes per operand and fp32 accumulation (the arithmetic of eap_gemm_f16x2_f32).
+ * on the fp16 matrix cores with two planes per operand and fp32 accumulation (the arithmetic of eap_gemm_f16x2_f32).  Inside, the
+ * (k, r) axis runs in the DENSE INDEX order d = (r / 16) 16 ks + 16 k + r % 16; a cloud with n_rows[b] < rp referenced rows uses a
+ * prefix of it, and with n_rows given the products stop there (dir 0 zeroes the slots past ceil16(n_rows[b]) in Z).
  *   eap_so3_dense_form        how the weights are evaluated: 1 (default) from the squared distance, 0 from the expanded square
  *                             (fewer instructions, ~3 x the rounding error); tables and product under the same setting; -> old setting
- *   eap_so3_dense_supported   p % 32 == 0, na % 4 == 0, na <= 64, rp % 4 == 0, rp <= 512, o % 128 == 0 (256-row blocks when o % 256 == 0)
+ *   eap_so3_dense_supported   p % 32 == 0, na % 4 == 0, na <= 64, ks % 2 == 0, rp % 16 == 0, rp <= 512, o % 128 == 0 (256-row blocks when o % 256 == 0)
  *   eap_so3_dense_member      slot_of int32 [b,n] (scratch), memb uint32 [b,p,16] (bit r of point p = m[p,r]; rp <= 512),
  *                             flags int32 [b]: 1 = a list names a row twice (padded short lists, grouping_cuda_kernel.cu:L98-107:
  *                             not representable by a 0/1 mask), 2 = a list names a row outside rows[:, :rp] -- such clouds
@@ -356,9 +358,10 @@ int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const uint32_t *m
 int eap_so3_dense_tables_f32(int b, int p, int n, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
                              const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
                              eap_stream_t stream);
-int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, const float *src, float *scale, void *planes,
-                            eap_stream_t stream);
-int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const void *planes, const float *scale,
+int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const float *src,
+                            float *scale, void *planes, eap_stream_t stream);
+int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows, const void *planes,
+                              const float *scale,
                               const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream);
 int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, eap_stream_t stream);
 

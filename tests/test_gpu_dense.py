@@ -49,7 +49,7 @@ def _geometry(s, dev):
     assert head.dense_possible()
     rp = L._dense_rows(rcap, n)
     head.wait()
-    geo = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, s['rk'], s['sigma'], NN)
+    geo = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, s['rk'], s['sigma'], NN, head.n_rows)
     return head, geo, rp
 
 
@@ -155,7 +155,7 @@ def test_backward_product_matches_the_list_kernel(dev):
     zp = torch.full((2, 256, KS, ld), 7.0, device=dev)
     from vgtk._hip import _ptr, _I64, _F32
     sc, pl = _hip.so3_dense_split(gy)
-    _hip.call('eap_so3_dense_product_f32', gy, 0, 2, 256, 512, NA, KS, rp, _I64(ld), _F32(geo.sigma), _ptr(pl), _ptr(sc), _ptr(geo.pt), _ptr(geo.kr),
+    _hip.call('eap_so3_dense_product_f32', gy, 0, 2, 256, 512, NA, KS, rp, _I64(ld), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(pl), _ptr(sc), _ptr(geo.pt), _ptr(geo.kr),
               _ptr(geo.mask(0)), _ptr(zp))
     assert torch.equal(zp[..., :NA * rp].reshape(2, 256, KS, NA, rp), z) and float((zp[..., NA * rp:] - 7.0).abs().max()) == 0.0
 

@@ -37,8 +37,9 @@ def timed(fn, n=int(os.environ.get('REPS', 5))):
 
 
 gen = torch.Generator(device=dev).manual_seed(1)
+TRIM = os.environ.get('TRIM', '1') != '0'
 gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
-g = torch.randn(B, o, KS * rp, NA, device=dev, generator=gen)
+g = torch.randn(B, o, KS, rp * NA, device=dev, generator=gen)
 for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
     _hip.lib.eap_so3_dense_form(form)
     geo = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, rk, sigma, NN)
@@ -46,15 +47,15 @@ for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
     geo.mask(0); geo.mask(1)
     t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(gy))
     z = torch.empty(B, o, KS, NA, rp, device=dev)
-    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', gy, 0, B, o, P, NA, KS, rp, _hip._I64(NA * rp), _hip._F32(sigma), _hip._ptr(planes), _hip._ptr(scale),
+    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', gy, 0, B, o, P, NA, KS, rp, _hip._I64(NA * rp), _hip._F32(sigma), _hip._ptr(head.n_rows if TRIM else None), _hip._ptr(planes), _hip._ptr(scale),
                                         _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(0)), _hip._ptr(z)))
     fl = 6.0 * B * o * P * NA * KS * rp
     print(f'form {form} backward: tables {t_tab:.2f} ms, split {t_split:.2f} ms, product {t_prod:.2f} ms = {fl / t_prod / 1e9:.0f} TFLOP/s fp16 '
           f'({fl / 3 / t_prod / 1e9:.0f} fp32-equivalent), algorithmic {2.0 * B * o * P * NA * KS * NN / t_prod / 1e9:.0f} TFLOP/s')
     del planes, scale, z
-    t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(g))
+    t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(g, seg=rp, seg_pitch=rp * NA, shape=(B, o, KS * rp, NA), mapped=True, n_rows=head.n_rows if TRIM else None))
     yt = torch.empty(B, NA, o, P, device=dev)
-    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', g, 1, B, o, P, NA, KS, rp, _hip._I64(0), _hip._F32(sigma), _hip._ptr(planes), _hip._ptr(scale),
+    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', g, 1, B, o, P, NA, KS, rp, _hip._I64(0), _hip._F32(sigma), _hip._ptr(head.n_rows if TRIM else None), _hip._ptr(planes), _hip._ptr(scale),
                                         _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(1)), _hip._ptr(yt)))
     y = torch.empty(B, o, P, NA, device=dev)
     t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_f32', g, B, o, P, NA, _hip._ptr(yt), _hip._ptr(y)))
