@@ -255,13 +255,20 @@ __global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na,
     unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     if (pg < G) {
         const f32x4 *src = T + ((size_t)b * m + row) * (size_t)(l / seg) * seg_pitch4;
-        for (int i = pg; i < l; i += G) {
-            const int sg = i / seg;
-            const f32x4 q = src[(size_t)sg * seg_pitch4 + (size_t)(i - sg * seg) * nq + aq];
-            v0 = max(v0, __float_as_uint(q.x) & 0x7fffffffu);
-            v1 = max(v1, __float_as_uint(q.y) & 0x7fffffffu);
-            v2 = max(v2, __float_as_uint(q.z) & 0x7fffffffu);
-            v3 = max(v3, __float_as_uint(q.w) & 0x7fffffffu);
+        for (int i0 = pg; i0 < l; i0 += 8 * G) {                   // eight independent 16-byte loads in flight per thread
+            f32x4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * G, l - 1), sg = i / seg;      // (past the end: the last element again -- a maximum does not mind)
+                q[u] = src[(size_t)sg * seg_pitch4 + (size_t)(i - sg * seg) * nq + aq];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v0 = max(v0, __float_as_uint(q[u].x) & 0x7fffffffu);
+                v1 = max(v1, __float_as_uint(q[u].y) & 0x7fffffffu);
+                v2 = max(v2, __float_as_uint(q[u].z) & 0x7fffffffu);
+                v3 = max(v3, __float_as_uint(q[u].w) & 0x7fffffffu);
+            }
         }
     }
     s[t][0] = v0; s[t][1] = v1; s[t][2] = v2; s[t][3] = v3;
@@ -291,26 +298,37 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
     if (rr >= RG) return;
     const int MT = m >> 5, nseg = l / seg;
     if (mapped && n_rows != nullptr && 16 * kb >= ((min(n_rows[b], seg) + 15) & ~15) * nseg) return;
-    for (int it = rr; it < 64; it += RG) {                      // item = (row i, k half kg)
-        const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
-        const f32x4 *src = T + ((size_t)b * m + row) * (size_t)(l / seg) * seg_pitch4 + aq;
-        int sg = l0 / seg, sr = l0 - sg * seg;                    // segment and position of element l0 + e
-        if (mapped) dense_kr(l0, nseg, sg, sr);                   // (8 consecutive dense indices: one kernel point, 8 consecutive slots)
-        f32x4 q[8];
+    // item = (row i, k half kg); two items per round: sixteen independent 16-byte loads in flight per thread
+    for (int it0 = rr; it0 < 64; it0 += 2 * RG) {
+        f32x4 q[2][8];
+        int rowv[2], lanef[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            q[e] = (l0 + e < l) ? src[(size_t)sg * seg_pitch4 + (size_t)sr * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (++sr == seg) { sr = 0; ++sg; }
+        for (int u = 0; u < 2; ++u) {
+            const int it = min(it0 + u * RG, 63);
+            const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
+            rowv[u] = row; lanef[u] = i + 32 * kg;
+            const f32x4 *src = T + ((size_t)b * m + row) * (size_t)nseg * seg_pitch4 + aq;
+            int sg = l0 / seg, sr = l0 - sg * seg;                // segment and position of element l0 + e
+            if (mapped) dense_kr(l0, nseg, sg, sr);               // (8 consecutive dense indices: one kernel point, 8 consecutive slots)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                q[u][e] = (l0 + e < l) ? src[(size_t)sg * seg_pitch4 + (size_t)sr * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (++sr == seg) { sr = 0; ++sg; }
+            }
         }
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale2 + ((size_t)b * m + row) * na + 4 * aq);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned h[4], lo[4];
+        for (int u = 0; u < 2; ++u) {
+            if (it0 + u * RG >= 64) break;
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale2 + ((size_t)b * m + rowv[u]) * na + 4 * aq);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2(q[2 * e][j] * sc[j], q[2 * e + 1][j] * sc[j], h[e], lo[e]);
-            u32x4 *dst = planes + ((((size_t)b * na + 4 * aq + j) * kb_total + kb) * MT + mt) * 128 + (i + 32 * kg);
-            dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
-            dst[64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+            for (int j = 0; j < 4; ++j) {
+                unsigned h[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(q[u][2 * e][j] * sc[j], q[u][2 * e + 1][j] * sc[j], h[e], lo[e]);
+                u32x4 *dst = planes + ((((size_t)b * na + 4 * aq + j) * kb_total + kb) * MT + mt) * 128 + lanef[u];
+                dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
+                dst[64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+            }
         }
     }
 }
