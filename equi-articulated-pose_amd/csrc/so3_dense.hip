@@ -661,7 +661,7 @@ int kc_launch(const KcArgs &g, hipStream_t s) {
     const long long blocks = (long long)g.zcount * g.tiles_m * g.blocks_n;
     if (blocks > 0x7fffffffLL) return eap::bad_arg("so3_dense: too many workgroups");
     hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM, DBG>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
-    eap::set_kernel(MI == 8 ? (FORM ? "kc_gemm_kernel<8,1>" : "kc_gemm_kernel<8,0>") : (FORM ? "kc_gemm_kernel<4,1>" : "kc_gemm_kernel<4,0>"));
+    eap::set_kernel(MI == 8 ? (FORM ? "kc_gemm_kernel<8, 1>" : "kc_gemm_kernel<8, 0>") : (FORM ? "kc_gemm_kernel<4, 1>" : "kc_gemm_kernel<4, 0>"));
     return eap::check_launch("so3_dense product");
 }
 

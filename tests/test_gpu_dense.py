@@ -270,3 +270,48 @@ def test_narrow_layer_takes_the_dense_backward_only(dev, monkeypatch):
     assert torch.equal(y1, y0) and torch.equal(y1n, y0)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     assert rel(gF1, gF0) < 2e-5 and rel(gW1, gW0) < 5e-5
+
+
+def test_odd_batch_and_strided_centres(dev, monkeypatch):
+    """(a) 3 clouds = 180 (cloud, anchor) products: not a multiple of the 8 XCDs -- the tail of the workgroup map; (b) a strided
+    layer (so3conv/functional.py:L931-1013: half as many centres as support points, lazily sampled): the dense product with
+    query points != support points.  Both against the list kernels."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    # (a)
+    B, P, c, o = 3, 512, 16, 256
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(61, B, P)[0]).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(19)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    r0 = _layer_run(dev, monkeypatch, 'off', xyz, None, feats0, W0, c, o, radius, sigma)
+    r1 = _layer_run(dev, monkeypatch, 'force', xyz, None, feats0, W0, c, o, radius, sigma)
+    assert r1[3][0]['regime'] == 'dense rows'
+    assert rel(r1[0], r0[0]) < 2e-5 and rel(r1[1], r0[1]) < 2e-5 and rel(r1[2], r0[2]) < 5e-5
+    # (b)
+    B, P = 2, 1024
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(71, B, P)[0]).to(dev)
+    pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    outs = {}
+    for mode in ('off', 'force'):
+        monkeypatch.setattr(L, 'DENSE_MODE', mode)
+        torch.manual_seed(2913)
+        conv = sptk.InterSO3PoseConv(c, o, 1, 2, radius, sigma, NN, kanchor=NA, permute_modes=1, lazy_sample=True).to(dev)
+        with torch.no_grad():
+            conv.basic_conv.W.copy_(W0)
+        feats = feats0.clone().requires_grad_(True)
+        L.BACKWARD_LOG = []
+        y = conv(zptk.SphericalPointCloudPose(xyz, feats, None, pose))[3].feats
+        assert y.shape == (B, o, P // 2, NA)
+        gy = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(23))
+        gF, gW = torch.autograd.grad(y, [feats, conv.basic_conv.W], gy)
+        log, L.BACKWARD_LOG = L.BACKWARD_LOG, None
+        outs[mode] = (y.detach(), gF, gW, log[0]['regime'])
+    assert outs['force'][3] == 'dense rows' and outs['off'][3] != 'dense rows'
+    for i, bar in enumerate((2e-5, 2e-5, 5e-5)):
+        assert rel(outs['force'][i], outs['off'][i]) < bar, i

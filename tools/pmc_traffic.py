@@ -7,7 +7,7 @@ Written to out_dir/<tag>_pmc_traffic.json (copy into profiles/ to have bench.py 
 import collections, csv, glob, json, os, re, sys
 
 out_dir, run, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-WANT = ('so3_group_lists', 'gemm_bf16x3_kernel', 'gemm_f16x2_kernel', 'gemm_dma_f32_kernel', 'gemm_f32_kernel', 'zpconv_', 'zp_hot', 'bn_act_', 'so3_inter_group', 'chamfer', 'anchor_attn')
+WANT = ('kc_gemm_kernel', 'dense_', 'so3_group_lists', 'gemm_bf16x3_kernel', 'gemm_f16x2_kernel', 'gemm_dma_f32_kernel', 'gemm_f32_kernel', 'zpconv_', 'zp_hot', 'bn_act_', 'so3_inter_group', 'chamfer', 'anchor_attn')
 
 
 def key_of(name):
@@ -23,7 +23,7 @@ def key_of(name):
         elif ch == '(' and depth == 0:
             break
         out += ch
-    if out.startswith('gemm_dma_f32_kernel'):
+    if out.startswith('gemm_dma_f32_kernel') or out.startswith('kc_gemm_kernel'):
         out = re.sub(r',\s*0>$', '>', out)      # trailing default template argument of the GEMM (ablation switch)
     m = re.match(r'(gemm_bf16x3_kernel|gemm_f16x2_kernel)<(\d+), (\d+), \d+, (\d+)(?:, (?:true|false))?>$', out)
     if m:                                       # <MI, WN, ablation switch, B layout, pre-split weights> -> the name eap_last_kernel() reports
