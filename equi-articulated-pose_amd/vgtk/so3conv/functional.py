@@ -1072,6 +1072,123 @@ def inter_so3conv_fused_art_mode(xyz, pose, feats, W, seg_labels, n_neighbor, an
     return (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 
 
+# ------------------------------------------------------------------------------------------------
+# the `use_2d` variant (functional.py:L1718-2130, modules.py:L249-255; scripts/train/eyeglasses.sh): an anchor axis of
+# (na, 4) -- every anchor times four residual rotations about the y axis
+# ------------------------------------------------------------------------------------------------
+_RES_2D = {}
+SLOW_2D_CHUNK = 64      # query points per slab of the general (really permuted) 2-D path
+FORCE_GENERAL_2D = False    # test knob: the general path even when no residual index is permuted
+
+
+def _res_rot_2d(device):
+    r = _RES_2D.get(str(device))
+    if r is None:
+        r = _RES_2D[str(device)] = RES_ROT_2D.to(device)
+    return r
+
+
+def residual_rotation_index(pose, ball_idx, chunk=512):
+    """rotated_anchor_idx int64 [b,p,nn,4] of the 2-D variant (functional.py:L1934-1938): per entry and residual rotation z the
+    index j maximising tr(R_rel^T RES_z RES_j^T), R_rel = R_p R_n^T -- the reference's expression, evaluated on the device a slab
+    of points at a time."""
+    res = _res_rot_2d(pose.device)
+    rot = pose[:, :, :3, :3].contiguous()
+    b, p = rot.shape[:2]
+    out = []
+    for s0 in range(0, p, chunk):
+        idx = ball_idx[:, s0:s0 + chunk].long()
+        grouped = batched_index_select_other(rot, idx, dim=1)                                       # [b,pc,nn,3,3]
+        rel = torch.matmul(rot[:, s0:s0 + chunk].unsqueeze(2), grouped.transpose(3, 4).contiguous())
+        ra = torch.matmul(rel.transpose(-1, -2).contiguous().unsqueeze(3), res)                      # [b,pc,nn,4,3,3]
+        d = torch.matmul(ra.unsqueeze(4), res.unsqueeze(0).transpose(2, 3).contiguous())            # [b,pc,nn,4,4,3,3]
+        out.append(torch.argmax(d[..., 0, 0] + d[..., 1, 1] + d[..., 2, 2], dim=-1))
+    return torch.cat(out, dim=1)
+
+
+def _conv_2d(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute, contract=True):
+    """Stride-1 branch of inter_so3poseconv_grouping_strided_2D (+ the contraction when `contract`).  feats [b,c,p,na*4].
+
+    With the residual index unpermuted -- permute_modes == 0, or every entry's relative rotation closest to the identity among
+    the four residual rotations (identity poses: what the shipped model feeds) -- output anchor (a, z) reads feature anchor (a, z)
+    only, with the weights of rotation A_a RES_z: FOUR ordinary convolutions on the fused kernels, one per residual rotation,
+    over the anchor sets {A_a RES_z}_a (the poses still rotate the offsets).  Otherwise the reference's expression in device
+    tensor ops, a slab of SLOW_2D_CHUNK query points at a time (correct, not accelerated: the permuted 2-D case has no kernel)."""
+    if feats.dtype != torch.float32 or xyz.dtype != torch.float32:
+        raise RuntimeError('so3conv: float32 only')
+    _hip.check_input(xyz)
+    if not feats.is_cuda:
+        raise RuntimeError('so3conv: feats must be a device tensor')
+    b, c, p, na4 = feats.shape
+    na = anchors.shape[0]
+    if na4 != 4 * na:
+        raise RuntimeError(f'use_2d: feats must carry {na} x 4 anchors, got {na4}')
+    res = _res_rot_2d(feats.device)
+    tot = torch.matmul(anchors.unsqueeze(1), res.unsqueeze(0)).contiguous()                          # [na,4,3,3] = A_a RES_z (L1921)
+    ball_idx = cuda_nn.ball_query(xyz, xyz, radius, n_neighbor)
+    shift = None
+    if permute and pose is not None:
+        shift = residual_rotation_index(pose, ball_idx)
+        if not FORCE_GENERAL_2D and bool((shift == torch.arange(4, device=shift.device)).all()):
+            shift = None
+    f5 = feats.contiguous().view(b, c, p, na, 4)
+    if shift is None:
+        outs = []
+        for z in range(4):
+            fz = f5[..., z].contiguous()
+            az = tot[:, z].contiguous()
+            if contract:
+                outs.append(inter_so3conv_fused(xyz, pose, fz, W, n_neighbor, az, kernels, radius, sigma, False)[2])
+            else:
+                outs.append(_inter_group(xyz, pose, fz, n_neighbor, az, kernels, radius, sigma, False)[2])
+        y = torch.stack(outs, dim=-1)
+        y = y.view(*y.shape[:-2], na4)
+        rk = rotated_kernels(tot.view(na4, 3, 3), kernels)
+        gx, _ = _hip.so3_prep(xyz, xyz, ball_idx, None if pose is None else pose.contiguous(), None if pose is None else pose.contiguous(),
+                              anchors.contiguous(), 0)
+        return ball_idx, InterWeights(gx, rk, sigma), y
+    # the general case: really permuted residual indices
+    rk = rotated_kernels(tot.view(na4, 3, 3), kernels)                                               # [na*4,ks,3]
+    rot = pose.contiguous()
+    gx, _ = _hip.so3_prep(xyz, xyz, ball_idx, rot, rot, anchors.contiguous(), 0)                      # rotated offsets (L1859-1862)
+    ks = kernels.shape[0]
+    fs = torch.cat([f5, torch.zeros(b, c, 1, na, 4, dtype=feats.dtype, device=feats.device)], dim=2)  # shadow row (L1944)
+    trans = fs.permute(0, 2, 3, 4, 1)                                                                # [b,p+1,na,4,c]
+    outs = []
+    for s0 in range(0, p, SLOW_2D_CHUNK):
+        s1 = min(p, s0 + SLOW_2D_CHUNK)
+        w = _hip.so3_inter_weights(gx[:, s0:s1].contiguous(), rk, float(sigma)).view(b, s1 - s0, na, 4, ks, -1)     # [b,pc,na,4,ks,nn]
+        idx = ball_idx[:, s0:s1].long()
+        g = batched_index_select_other(trans, idx, dim=1)                                            # [b,pc,nn,na,4,c]
+        sel = shift[:, s0:s1, :, None, :, None].expand(-1, -1, -1, na, -1, c)
+        g = torch.gather(g, 4, sel)                                                                  # feature residual index per (entry, z) (L1954-1957)
+        x = torch.einsum('bpnazc,bpazkn->bckpaz', g, w).reshape(b, c, ks, s1 - s0, na4)              # (L2124)
+        outs.append(so3_contract(W, x.reshape(b, c * ks, (s1 - s0) * na4).contiguous()).view(b, W.shape[0], s1 - s0, na4) if contract else x)
+    return ball_idx, InterWeights(gx, rk, sigma), torch.cat(outs, dim=2 if contract else 3)
+
+
+def inter_so3conv_fused_2d(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute):
+    """What InterSO3PoseConv(use_2d=True).forward runs for stride 1 -> (InterWeights, y [b,o,p,na*4])."""
+    if W.dtype != torch.float32 or not W.is_cuda:
+        raise RuntimeError('so3conv: W must be a float32 device tensor')
+    _, w, y = _conv_2d(xyz, pose, feats, W, n_neighbor, anchors, kernels, radius, sigma, permute, contract=True)
+    return (w.materialize() if MATERIALIZE_INTER_W else w), y
+
+
+def inter_so3poseconv_grouping_strided_2D(xyz, pose, feats, stride, n_neighbor, anchors, kernels, radius, sigma, inter_idx=None,
+                                          inter_w=None, lazy_sample=True, radius_expansion=1.0, pooling=None, permute_modes=0):
+    """Grouping of the `use_2d` variant (functional.py:L1718-2130), stride-1 branch (L1812-2128: the neighbourhood is recomputed,
+    inter_idx handed back unchanged).  -> inter_idx, inter_w, new_xyz, new_feats [b,c,ks,p,na*4], sample_idx, sampled_pose.
+    The strided branch of the reference (L1754-1810) applies the 60-anchor expressions to the 240-anchor features and cannot run
+    as written; the shipped configuration forces stride 1 (...pn_38_multi_stage.py:L2191)."""
+    if pooling is not None and stride > 1 and feats.shape[1] > 1:
+        raise ValueError('xyz_pooling is not None?!!')                 # functional.py:L1737
+    if inter_idx is None and stride > 1:
+        raise NotImplementedError('use_2d with stride > 1: the reference\'s strided branch (functional.py:L1754-1810) does not match its 240-anchor features')
+    _, w, new_feats = _conv_2d(xyz, pose, feats, None, n_neighbor, anchors, kernels, radius, sigma, permute_modes != 0, contract=False)
+    return inter_idx, (w.materialize() if MATERIALIZE_INTER_W else w), xyz, new_feats, None, pose
+
+
 def inter_so3conv_grouping(xyz, feats, stride, n_neighbor, anchors, kernels, radius, sigma,
                            inter_idx=None, inter_w=None, lazy_sample=True, radius_expansion=1.0,
                            pooling=None):

@@ -109,8 +109,6 @@ class InterSO3PoseConv(InterSO3Conv):
     def __init__(self, dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor,
                  lazy_sample=True, pooling=None, kanchor=60, permute_modes=0, use_2d=False,
                  use_art_mode=False):
-        if use_2d:
-            raise NotImplementedError('the use_2d grouping variant (240 = 60 x 4 anchors) is outside the accelerated path')
         super().__init__(dim_in, dim_out, kernel_size, stride, radius, sigma, n_neighbor, lazy_sample=lazy_sample, pooling=pooling,
                          kanchor=kanchor)
         self.permute_modes, self.use_2d, self.use_art_mode = permute_modes, use_2d, use_art_mode
@@ -118,6 +116,15 @@ class InterSO3PoseConv(InterSO3Conv):
     def forward(self, x, inter_idx=None, inter_w=None, seg=None, epilogue=None):
         if self.pooling is not None and self.stride > 1 and x.feats.shape[1] > 1:
             raise ValueError('xyz_pooling is not None?!!')             # functional.py:L913
+        if self.use_2d:
+            # anchor axis (60, 4) = anchors x residual rotations about y (functional.py:L1718-2130; scripts/train/eyeglasses.sh):
+            # four ordinary convolutions on the fused kernels while the residual index is unpermuted (identity poses), the
+            # reference's expression in device tensor ops otherwise
+            if inter_idx is None and self.stride > 1:
+                raise NotImplementedError('use_2d with stride > 1 (the reference forces stride 1 for this configuration)')
+            w, feats = L.inter_so3conv_fused_2d(x.xyz, x.pose, x.feats, self.basic_conv.W, self.n_neighbor, self.anchors, self.kernels,
+                                                self.radius, self.sigma, self.permute_modes != 0)
+            return inter_idx, w, None, SphericalPointCloudPose(x.xyz, feats, self.anchors, x.pose)
         if self.use_art_mode and not (inter_idx is None and self.stride > 1):
             # articulation-state mode, stride-1 branch (functional.py:L1420-1520): x.xyz is [b, n_states, 3, p], `seg` picks
             # every point's state; the strided branch of that mode is the regular one (L1326-1331)

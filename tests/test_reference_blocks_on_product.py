@@ -71,6 +71,10 @@ def test_reference_propagation_and_2d_blocks_build(blocks):
     assert isinstance(prop.prop, sptk.KernelPropagation) and prop.prop.kernels.shape == (24, 60, 3)
     blk = M.IntraSO3PoseConv2DBlock(8, 8, activation='leaky_relu')
     assert isinstance(blk.conv, sptk.IntraSO3Conv2D)
+    # the `use_2d` configuration (scripts/train/eyeglasses.sh --use-2d=1): the reference's separable blocks build on the product
+    # with the 2-D inter conv (so3conv/modules.py:L249-255) and the 2-D intra block inside
+    net = M.BasicSO3PoseConvBlock(_params(512, 'separable_block', 60, {'use_2d': True, 'permute_modes': 1}))
+    assert net.blocks[1].inter_conv.conv.use_2d and isinstance(net.blocks[1].intra_conv.conv, sptk.IntraSO3Conv2D)
 
 
 @pytest.mark.gpu
