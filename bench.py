@@ -199,7 +199,7 @@ def cpu_probe(points, threads, skip, slab=32, runs=3, deadline=60.0):
 def cpu_baseline(points, slab=256):
     """The CPU oracle beside the GPU number, by BASELINE.md section 2's protocol (1 warm-up + 3 timed runs, median), in child
     processes without a GPU, each under a time budget (a run that would overrun it is not started: fewer than 3 timed runs are
-    reported as such, never a missing entry); steps 2-4 run side by side when the host has 6 x the thread count to spare:
+    reported as such, never a missing entry):
       1. thread sweep {16, 32, 64, 128} (those the host has) on a 32-point slab of the `points`-point cloud -> the fastest count;
       2. at that count: a slab of `slab` (256) query points, scaled by points / slab -> `value`;
       3. at that count: config 1 of BASELINE.json DIRECTLY -- one whole 512-point cloud, nothing scaled -> `config1`;
@@ -223,15 +223,12 @@ def cpu_baseline(points, slab=256):
     counts = [t for t in CPU_BASELINE_THREADS if t <= ncpu] or [ncpu]
     sweep = [finish(start(t, False, points, 32, 8.0)) for t in counts]            # one after the other
     best = max(sweep, key=lambda d: d['clouds_per_sec'])['threads']
-    # the three protocol runs side by side when the host has the threads for it (3 x `best` of its logical CPUs), else in turn
-    jobs = [(best, False, points, slab, 90.0), (best, False, 512, 512, 90.0), (best, True, points, slab, 60.0)]
-    if 3 * best <= ncpu // 2:
-        procs = [start(*j) for j in jobs]
-        main, config1, short = [finish(pr) for pr in procs]
-        side_by_side = True
-    else:
-        main, config1, short = [finish(start(*j)) for j in jobs]
-        side_by_side = False
+    # the three protocol runs, one after the other (side by side they slow each other down by 1.8 x on the 256-thread host:
+    # memory bandwidth, profiles/r05_h_bench.json) -- the whole baseline runs beside the GPU side legs of the bench instead
+    main = finish(start(best, False, points, slab, 75.0))
+    config1 = finish(start(best, False, 512, 512, 80.0))
+    short = finish(start(best, True, points, slab, 30.0))
+    side_by_side = False
     model = 'unknown'
     try:
         for ln in open('/proc/cpuinfo'):

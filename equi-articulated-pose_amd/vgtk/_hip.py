@@ -557,6 +557,16 @@ def dense_pitch(n):
     return (n + 127) // 128 * 128
 
 
+def _dense_executed_flops(geo, o, p):
+    """fp16 flops the product kernel executes for this geometry: 6 O P A K x (every cloud's own rows rounded to 16).  The per-cloud
+    row counts live on the device; they are read (a host wait) only while bench.py attributes launch times, else the batch-wide rp
+    is used (an upper bound nobody reads)."""
+    rows = geo.rp * geo.b
+    if KERNEL_TIMES is not None and geo.n_rows is not None:
+        rows = sum(min((int(r) + 15) & ~15, geo.rp) for r in geo.n_rows.tolist())
+    return 6.0 * o * p * geo.na * geo.ks * rows
+
+
 def so3_dense_bwd(gy, geo, ldz=None):
     """gy [b,o,p,na] -> Z [b,o,ks,ldz] whose rows hold [na,rp] (the inverse-list kernel's Z with the anchor axis in front of the row
     axis); ldz >= na*rp (default: equal) pads the rows for the GEMMs that follow -- the padding is NOT written."""
@@ -565,7 +575,7 @@ def so3_dense_bwd(gy, geo, ldz=None):
     scale, planes = so3_dense_split(gy)
     z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
     call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
-         _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp,
+         _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': _dense_executed_flops(geo, o, p),
                                         'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
     return z
 
@@ -580,7 +590,7 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None):
     yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
     call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
          _ptr(geo.mask(1)), _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp),
-                                         'executed_f16_flops': 6.0 * b * o * p * na * geo.ks * geo.rp, 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
+                                         'executed_f16_flops': _dense_executed_flops(geo, o, p), 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
     call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y))
