@@ -166,6 +166,14 @@ def cpu_probe(points, threads, skip, slab=32, runs=3, deadline=60.0):
     anchors = torch.from_numpy(np.ascontiguousarray(L.get_anchors()))
     xyz, _, pose = synth_clouds.laptop_batch(0, 1, points)
     xyz, pose = torch.from_numpy(xyz), torch.from_numpy(pose)
+    # away from the cores the bench process launches its GPU work from (the probes run beside the bench's side legs): the upper
+    # half of the host's logical CPUs when the thread count fits there
+    ncpu = os.cpu_count() or 1
+    if hasattr(os, 'sched_setaffinity') and 4 * threads <= ncpu:      # (never fewer than two logical CPUs per thread: 128 threads pinned
+        try:                                                             #  to 128 logical CPUs took 456 s for what 16 threads do in 1.4 s)
+            os.sched_setaffinity(0, set(range(ncpu - 2 * threads, ncpu)))
+        except OSError:
+            pass
     torch.set_num_threads(threads)
     slab = min(slab, points)
     t_start = time.perf_counter()
@@ -212,8 +220,16 @@ def cpu_baseline(points, slab=256):
         env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
         return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
 
-    def finish(proc):
-        out, err = proc.communicate()
+    def finish(proc, limit=None, what=None):
+        t0 = time.perf_counter()
+        try:
+            out, err = proc.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.communicate()
+            dt = time.perf_counter() - t0
+            # (a thread count at which not even the warm-up run ends within the limit: reported as the bound that follows from it)
+            return dict(what, clouds_per_sec=0.0, clouds_per_sec_upper_bound=1.0 / (dt * points / 32), note=f'stopped after {dt:.0f} s inside its warm-up run')
         lines = [ln for ln in out.splitlines() if ln.startswith('{')]
         if proc.returncode != 0 or not lines:
             raise RuntimeError('cpu baseline probe failed: ' + err[-400:])
@@ -221,7 +237,7 @@ def cpu_baseline(points, slab=256):
 
     ncpu = os.cpu_count() or 1
     counts = [t for t in CPU_BASELINE_THREADS if t <= ncpu] or [ncpu]
-    sweep = [finish(start(t, False, points, 32, 8.0)) for t in counts]            # one after the other
+    sweep = [finish(start(t, False, points, 32, 8.0), limit=30.0, what={'threads': t, 'query_points': 32, 'points': points}) for t in counts]     # one after the other
     best = max(sweep, key=lambda d: d['clouds_per_sec'])['threads']
     # the three protocol runs, one after the other (side by side they slow each other down by 1.8 x on the 256-thread host:
     # memory bandwidth, profiles/r05_h_bench.json) -- the whole baseline runs beside the GPU side legs of the bench instead
@@ -875,6 +891,11 @@ def main(argv=None):
         if world > 1 and backend != 'nccl':
             line['functional_check_only'] = (f'{world} ranks over {backend} on {n_dev} device(s): the N > 1 code path runs, '
                                              f'this is NOT a scaling measurement')
+        if world == 1 and default_cfg and not args.no_other_configs:
+            del model, opt, xyz, pose
+            torch.cuda.empty_cache()
+            line['config3_step'] = config3_step(dev)       # (before the CPU probes start: its many small launches feel busy host cores)
+            progress('config-3 composite done')
         cpu_job = None
         if world == 1 and not args.no_cpu_baseline:
             # child processes on the host cores, BESIDE the side legs below (never beside the headline loop above): a few minutes of CPU
@@ -889,12 +910,8 @@ def main(argv=None):
             cpu_job['thread'] = threading.Thread(target=_cpu, daemon=True)
             cpu_job['thread'].start()
         if world == 1 and default_cfg and not args.no_other_configs:
-            del model, opt, xyz, pose
-            torch.cuda.empty_cache()
             line['other_configs'] = other_configs(dev)
             progress('other configurations done')
-            line['config3_step'] = config3_step(dev)
-            progress('config-3 composite done')
         if world == 1 and not args.fwd_only:
             line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
             progress('native zpconv done')
