@@ -186,6 +186,58 @@ __global__ __launch_bounds__(TB) void bn_act_bwd_apply_kernel(int c, long n, flo
     }
 }
 
+// The same pass for a row that is [points][na] (na a multiple of 4), which ALSO leaves the largest magnitude of gx per (cloud,
+// channel, anchor) in rowmax [b, c, na] (bit patterns of non-negative floats, zero-initialised by the caller; unsigned maximum =
+// float maximum: order-independent, so the atomics make nothing run-dependent).  The consumer -- the stored-operand split of the
+// dense backward product, csrc/so3_dense.hip -- otherwise reads the whole gradient once more just for these numbers.  Thread t of
+// the nq * (256 / nq) active ones walks the float4 pieces t, t + T, t + 2T, ... of its segment: T is a multiple of nq = na / 4,
+// so a thread meets ONE anchor quad and keeps its four maxima in registers.
+constexpr int RM_PIECES = 16;           // pieces per thread and block
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_rowmax_kernel(int c, long n4, int nq, float slope, const float4 *__restrict__ gy,
+                                                                      const float4 *__restrict__ x, const float *__restrict__ scale,
+                                                                      const float *__restrict__ shift, const float *__restrict__ mean,
+                                                                      const float *__restrict__ invstd, const float *__restrict__ k2,
+                                                                      const float *__restrict__ k3, float4 *__restrict__ gx,
+                                                                      unsigned *__restrict__ rowmax) {
+    __shared__ unsigned s_max[256][4];
+    const int ci = blockIdx.y, bi = blockIdx.z, t = threadIdx.x;
+    const int T = nq * (256 / nq);
+    const float sc = scale[ci], sh = shift[ci], mu = mean[ci], is = invstd[ci], c2 = k2[ci], c3 = k3[ci];
+    const size_t r0 = ((size_t)bi * c + ci) * (size_t)n4;
+    const long base = (long)blockIdx.x * RM_PIECES * T;
+    auto one = [&](float g, float xv) {
+        const float pre = fmaf(xv, sc, sh);
+        const float gg = pre > 0.f ? g : g * slope;
+        return fmaf(gg, sc, -c2) - ((xv - mu) * is) * c3;
+    };
+    unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    if (t < T) {
+        float4 g[RM_PIECES], a[RM_PIECES];
+#pragma unroll
+        for (int v = 0; v < RM_PIECES; ++v) {
+            const long i = base + (long)v * T + t;
+            if (i < n4) { g[v] = gy[r0 + i]; a[v] = x[r0 + i]; }
+        }
+#pragma unroll
+        for (int v = 0; v < RM_PIECES; ++v) {
+            const long i = base + (long)v * T + t;
+            if (i < n4) {
+                const float4 o = make_float4(one(g[v].x, a[v].x), one(g[v].y, a[v].y), one(g[v].z, a[v].z), one(g[v].w, a[v].w));
+                gx[r0 + i] = o;
+                m0 = max(m0, __float_as_uint(o.x) & 0x7fffffffu); m1 = max(m1, __float_as_uint(o.y) & 0x7fffffffu);
+                m2 = max(m2, __float_as_uint(o.z) & 0x7fffffffu); m3 = max(m3, __float_as_uint(o.w) & 0x7fffffffu);
+            }
+        }
+    }
+    s_max[t][0] = m0; s_max[t][1] = m1; s_max[t][2] = m2; s_max[t][3] = m3;
+    __syncthreads();
+    if (t < 4 * nq) {                                           // anchor t = 4 (t >> 2) + (t & 3): the threads of quad t >> 2 are t >> 2, + nq, ...
+        unsigned v = 0;
+        for (int u = t >> 2; u < T; u += nq) v = max(v, s_max[u][t & 3]);
+        if (v) atomicMax(rowmax + ((size_t)bi * c + ci) * (4 * nq) + t, v);
+    }
+}
+
 inline int nseg_of(long n) { return (int)((n + SEG - 1) / SEG); }
 inline bool ok_dims(int b, int c, long n) { return b > 0 && c > 0 && n > 0 && c <= 65535 && b <= 65535; }
 
@@ -238,6 +290,24 @@ extern "C" int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, co
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(nseg_of(n), c, b), dim3(TB), 0, eap::S(stream), c, (long)n, slope, gy, x,
                        scale, shift, mean, invstd, k2, k3, gx, (const float *)nullptr, 1);
     return eap::check_launch("bn_act_bwd_apply");
+}
+
+extern "C" int eap_bn_act_bwd_apply_rowmax_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *x,
+                                               const float *scale, const float *shift, const float *mean,
+                                               const float *invstd, const float *k2, const float *k3, float *gx, uint32_t *rowmax,
+                                               eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || na <= 0 || (na & 3) != 0 || na > 256 || n % na != 0 ||
+        ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gx)) & 15) != 0)
+        return eap::bad_arg("bn_act_bwd_apply_rowmax: rows of [points][na], na a multiple of 4 up to 256, 16-byte aligned tensors");
+    hipStream_t s = eap::S(stream);
+    if (int e = eap::hip_fail(hipMemsetAsync(rowmax, 0, sizeof(uint32_t) * (size_t)b * c * na, s), "bn_act_bwd_apply_rowmax memset")) return e;
+    const int nq = na / 4, T = nq * (256 / nq);
+    const long n4 = (long)(n / 4);
+    hipLaunchKernelGGL(bn_act_bwd_apply_rowmax_kernel, dim3((unsigned)((n4 + (long)RM_PIECES * T - 1) / ((long)RM_PIECES * T)), c, b), dim3(256), 0, s,
+                       c, n4, nq, slope, reinterpret_cast<const float4 *>(gy), reinterpret_cast<const float4 *>(x), scale, shift, mean, invstd, k2, k3,
+                       reinterpret_cast<float4 *>(gx), rowmax);
+    return eap::check_launch("bn_act_bwd_apply_rowmax");
 }
 
 // ---- per-cloud statistics over a point subset (the pose heads' batched per-cloud calls) ---------------------------

@@ -282,6 +282,21 @@ __global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na,
     }
 }
 
+// the same two scale arrays from row maxima somebody else already has (rowmax [b][m][na], float bit patterns: the BatchNorm
+// backward that produced the gradient leaves them, eap_bn_act_bwd_apply_rowmax_f32)
+__global__ __launch_bounds__(256) void dense_scale_kernel(long long total, int m, int na, const unsigned *__restrict__ rowmax,
+                                                          float *__restrict__ scale, float *__restrict__ scale2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // (b, row, a)
+    if (i >= total) return;
+    const int a = (int)(i % na);
+    const long long br = i / na;
+    const int row = (int)(br % m);
+    const long long b = br / m;
+    const float sc = pow2_scale(__uint_as_float(rowmax[i]));
+    scale[(b * na + a) * m + row] = sc;
+    scale2[i] = sc;
+}
+
 // planes[z = b na + a][k-block kb][row tile mt][plane][lane] (16 bytes): lane (i = lane & 31, kg = lane >> 5) holds the 8
 // contraction elements 16 kb + 8 kg .. + 7 of row 32 mt + i -- what a lane of v_mfma_f32_32x32x16_f16 takes as its A operand.
 // One block per (b, mt, kb): thread (anchor quad aq = t % nq, row group t / nq) takes the 8 elements of (row, kg) for its four
@@ -731,8 +746,9 @@ extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks,
 // segment: src is plain [b,m,l,na]).  mapped (the forward's G: seg = rp, l = ks rp): element l of the OUTPUT is the pair (k, r)
 // whose dense index is l (eap_so3_dense_product_f32), read from segment k, position r; with n_rows [b] the k-blocks past a
 // cloud's own prefix are left unwritten.
-extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const float *src,
-                                       float *scale, void *planes, eap_stream_t stream) {
+// rowmax (may be null): max |src| per (cloud, row, anchor) as float bit patterns, [b][m][na] -- saves the pass that finds them
+extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const uint32_t *rowmax,
+                                       const float *src, float *scale, void *planes, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (seg <= 0) { seg = l; seg_pitch = (int64_t)l * na; }
     if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || (reinterpret_cast<uintptr_t>(src) & 15) || l % seg != 0 ||
@@ -741,7 +757,10 @@ extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int
     hipStream_t s = eap::S(stream);
     const int kb_total = ceil_to(l, KC_BK) / 16;
     float *scale2 = scale + (size_t)b * na * m;
-    hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), reinterpret_cast<const f32x4 *>(src), scale, scale2);
+    if (rowmax != nullptr)
+        hipLaunchKernelGGL(dense_scale_kernel, dim3(eap::cdiv((long long)b * m * na, 256)), dim3(256), 0, s, (long long)b * m * na, m, na, rowmax, scale, scale2);
+    else
+        hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), reinterpret_cast<const f32x4 *>(src), scale, scale2);
     hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total, seg, (long long)(seg_pitch / 4), mapped ? 1 : 0,
                        n_rows, reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
     return eap::check_launch("so3_dense_split");

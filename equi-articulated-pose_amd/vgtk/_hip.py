@@ -540,15 +540,16 @@ class DenseGeometry:
         return m
 
 
-def so3_dense_split(src, seg=0, seg_pitch=0, shape=None, mapped=False, n_rows=None):
+def so3_dense_split(src, seg=0, seg_pitch=0, shape=None, mapped=False, n_rows=None, rowmax=None):
     """src [b,m,l,na] -> (scale [2,b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
     fragment order).  seg > 0 (with shape = (b, m, l, na)): a row's l elements lie in l / seg segments of seg elements whose
     starts are seg_pitch floats apart (the rows of a GEMM output with padded columns).  mapped: the output's element l is the
-    (k, r) pair with dense index l (the forward's operand), n_rows trims every cloud to its own rows."""
+    (k, r) pair with dense index l (the forward's operand), n_rows trims every cloud to its own rows.  rowmax int32 [b,m,na]: the
+    rows' largest magnitudes (float bit patterns) when the producer already has them -- no pass over src for them."""
     b, m, l, na = src.shape if shape is None else shape
     scale = torch.empty(2, b, na, m, dtype=torch.float32, device=src.device)      # [0]: [b,na,m]; [1]: the same numbers as [b,m,na]
     planes = torch.empty(b * na * m * ((l + 31) // 32 * 32), dtype=torch.int32, device=src.device)       # 4 bytes per element
-    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), int(bool(mapped)), _ptr(n_rows), _ptr(src), _ptr(scale), _ptr(planes))
+    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), int(bool(mapped)), _ptr(n_rows), _ptr(rowmax), _ptr(src), _ptr(scale), _ptr(planes))
     return scale, planes
 
 
@@ -572,7 +573,7 @@ def so3_dense_bwd(gy, geo, ldz=None):
     axis); ldz >= na*rp (default: equal) pads the rows for the GEMMs that follow -- the padding is NOT written."""
     b, o, p, na = gy.shape
     ldz = na * geo.rp if ldz is None else int(ldz)
-    scale, planes = so3_dense_split(gy)
+    scale, planes = so3_dense_split(gy, rowmax=take_rowmax_hint(gy))
     z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
     call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
          _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': _dense_executed_flops(geo, o, p),
@@ -626,8 +627,40 @@ def bn_act_bwd_reduce(gy, x, b, c, n, scale, shift, mean, invstd, slope):
     return pg.sum(1, dtype=torch.float64), pgx.sum(1, dtype=torch.float64)
 
 
+# Row maxima of a gradient tensor, handed from the kernel that WROTE it (the BatchNorm backward) to the one that splits it into
+# fp16 planes (the dense backward product's stored operand): one entry, keyed on the tensor OBJECT (a weak reference: autograd
+# hands the same tensor to the next node when nothing is accumulated into it) and its version counter.  Anything else -- another
+# tensor, a tensor modified in between, no entry -- and the split finds the maxima itself.
+_ROWMAX_HINT = [None]
+USE_ROWMAX_HINT = True        # False: the split always finds its maxima itself (A/B runs, tests)
+ROWMAX_HINTS_TAKEN = 0        # how often a hint was accepted (tests)
+
+
+def leave_rowmax_hint(t, rowmax):
+    import weakref
+    _ROWMAX_HINT[0] = (weakref.ref(t), t._version, tuple(t.shape), rowmax)
+
+
+def take_rowmax_hint(t):
+    global ROWMAX_HINTS_TAKEN
+    h, _ROWMAX_HINT[0] = _ROWMAX_HINT[0], None
+    if not USE_ROWMAX_HINT or h is None or h[0]() is not t or h[1] != t._version or h[2] != tuple(t.shape):
+        return None
+    ROWMAX_HINTS_TAKEN += 1
+    return h[3]
+
+
 def bn_act_bwd_apply(gy, x, b, c, n, scale, shift, mean, invstd, k2, k3, slope):
     gx = torch.empty_like(x)
+    if x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[3] <= 64 and n == x.shape[2] * x.shape[3] and c % 128 == 0 and gx.data_ptr() % 16 == 0 \
+            and gy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+        # [b, c, points, anchors] at a width the dense backward product takes: the same pass also leaves the row maxima its
+        # stored-operand split needs (csrc/bn_act.hip bn_act_bwd_apply_rowmax_kernel)
+        rowmax = torch.empty(b, c, x.shape[3], dtype=torch.int32, device=x.device)
+        call('eap_bn_act_bwd_apply_rowmax_f32', x, b, c, _I64(n), int(x.shape[3]), _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
+             _ptr(mean), _ptr(invstd), _ptr(k2), _ptr(k3), _ptr(gx), _ptr(rowmax))
+        leave_rowmax_hint(gx, rowmax)
+        return gx
     call('eap_bn_act_bwd_apply_f32', x, b, c, _I64(n), _F32(slope), _ptr(gy), _ptr(x), _ptr(scale), _ptr(shift),
          _ptr(mean), _ptr(invstd), _ptr(k2), _ptr(k3), _ptr(gx))
     return gx

@@ -344,7 +344,8 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *                             kr float4 [b, na, ceil32(ks rp)]: the two sides of the weight (centred coordinates), evaluated in float64
  *   eap_so3_dense_split_f32   src [b,m,l,na] -> scale [2][b,na,m] (power of two per row; the second copy as [b,m,na]) and the two fp16 planes of the scaled
  *                             rows in the product kernel's fragment order: 4 b na m ceil32(l) bytes
- *                             (seg > 0: a row's l elements come in segments of seg elements seg_pitch floats apart -- G as a GEMM with
+ *                             (rowmax uint32 [b,m,na], may be null: the rows' largest magnitudes as float bit patterns when the producer
+ *                             of src already has them, eap_bn_act_bwd_apply_rowmax_f32; seg > 0: a row's l elements come in segments of seg elements seg_pitch floats apart -- G as a GEMM with
  *                             padded columns leaves it)
  *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1); dir 0 writes
  *                             Z with ldz >= na rp floats between its (o, k) rows (padding for the GEMMs that follow, not written)
@@ -358,8 +359,8 @@ int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const uint32_t *m
 int eap_so3_dense_tables_f32(int b, int p, int n, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
                              const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
                              eap_stream_t stream);
-int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const float *src,
-                            float *scale, void *planes, eap_stream_t stream);
+int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const uint32_t *rowmax,
+                            const float *src, float *scale, void *planes, eap_stream_t stream);
 int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows, const void *planes,
                               const float *scale,
                               const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream);
@@ -562,6 +563,11 @@ int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, const float *
                              const float *scale, const float *shift, const float *mean,
                              const float *invstd, const float *k2, const float *k3, float *gx,
                              eap_stream_t stream);
+/* eap_bn_act_bwd_apply_f32 for rows of [points][na] that ALSO leaves max |gx| per (cloud, channel, anchor) in rowmax uint32 [b,c,na]
+ * (float bit patterns): what eap_so3_dense_split_f32 takes instead of its own pass over the gradient. */
+int eap_bn_act_bwd_apply_rowmax_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *x,
+                                    const float *scale, const float *shift, const float *mean, const float *invstd,
+                                    const float *k2, const float *k3, float *gx, uint32_t *rowmax, eap_stream_t stream);
 
 /* Per-cloud statistics over a point subset: the pose heads run their unary stacks once per cloud on the cloud's member
  * points (`for i_bz in range(bz): ...` SPConvNets/models/..pn_38_multi_stage.py:L706-830, the head's BatchNorm2d layers

@@ -315,3 +315,47 @@ def test_odd_batch_and_strided_centres(dev, monkeypatch):
     assert outs['force'][3] == 'dense rows' and outs['off'][3] != 'dense rows'
     for i, bar in enumerate((2e-5, 2e-5, 5e-5)):
         assert rel(outs['force'][i], outs['off'][i]) < bar, i
+
+
+def test_row_maxima_travel_from_the_batchnorm_backward_to_the_split(dev, monkeypatch):
+    """conv -> BatchNormLeakyReLU -> loss: the BatchNorm backward writes the conv's output gradient AND its largest magnitude per
+    (cloud, channel, anchor) (eap_bn_act_bwd_apply_rowmax_f32); the dense backward's split takes them instead of a pass of its
+    own.  Same scales, so bit-equal gradients with and without the hand-off; the maxima equal torch's."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    from vgtk.so3conv.blocks import BatchNormLeakyReLU
+    B, P, c, o = 2, 512, 16, 256
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(95, B, P)[0]).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(29)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    probe = torch.randn(B, o, P, NA, device=dev, generator=gen)
+    monkeypatch.setattr(L, 'DENSE_MODE', 'force')
+    res = []
+    for use in (True, False):
+        monkeypatch.setattr(_hip, 'USE_ROWMAX_HINT', use)
+        torch.manual_seed(2913)
+        conv = sptk.InterSO3PoseConv(c, o, 1, 1, radius, sigma, NN, kanchor=NA, permute_modes=1).to(dev)
+        norm = BatchNormLeakyReLU(o).to(dev)
+        feats = feats0.clone().requires_grad_(True)
+        taken = _hip.ROWMAX_HINTS_TAKEN
+        y = norm(conv(zptk.SphericalPointCloudPose(xyz, feats, None, None))[3].feats)
+        (y * probe).sum().backward()
+        assert _hip.ROWMAX_HINTS_TAKEN == taken + (1 if use else 0)
+        res.append((feats.grad.clone(), conv.basic_conv.W.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # the kernel's maxima against torch's, and its gradient against the plain apply entry
+    x = torch.randn(B, 128, 64, NA, device=dev, generator=gen)
+    gy = torch.randn(B, 128, 64, NA, device=dev, generator=gen)
+    scale, shift, mean, invstd, k2, k3 = (torch.rand(128, device=dev, generator=gen) + 0.5 for _ in range(6))
+    gx = _hip.bn_act_bwd_apply(gy, x, B, 128, 64 * NA, scale, shift, mean, invstd, k2, k3, 0.01)
+    hint = _hip._ROWMAX_HINT[0]
+    assert hint is not None and hint[0]() is gx
+    assert torch.equal(hint[3].view(torch.float32), gx.abs().amax(dim=2))
+    plain = torch.empty_like(x)
+    _hip.call('eap_bn_act_bwd_apply_f32', x, B, 128, _hip._I64(64 * NA), _hip._F32(0.01), _hip._ptr(gy), _hip._ptr(x), _hip._ptr(scale), _hip._ptr(shift),
+              _hip._ptr(mean), _hip._ptr(invstd), _hip._ptr(k2), _hip._ptr(k3), _hip._ptr(plain))
+    assert torch.equal(plain, gx)
