@@ -348,20 +348,42 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
     }
 }
 
-// Yt[b][a][o][p] -> Y[b][o][p][a]: block (p chunk of 64, o, b) through a [na][65] LDS tile
-__global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int p, int na, const float *__restrict__ yt, float *__restrict__ y) {
+// Yt[b][a][o][p] -> Y[b][o][p][a]: block (p chunk of 64, o, b) through a [na][65] LDS tile.  psum / psq (may be null): the block's
+// sum and sum of squares of (y - pivot), pivot = Y[0][o][0][0] -- the partial moments the BatchNorm that follows would otherwise
+// read the whole tensor for (csrc/bn_act.hip bn_stats_kernel: the same pivot, summed in float64 by the caller), at
+// [o][b * chunks + chunk].
+__global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int p, int na, const float *__restrict__ yt, float *__restrict__ y,
+                                                                float *__restrict__ psum, float *__restrict__ psq) {
     extern __shared__ float tile[];
+    __shared__ float red[2][256];
     const int b = blockIdx.z, o = blockIdx.y, p0 = blockIdx.x * 64, t = threadIdx.x;
     const int np = min(64, p - p0);
+    const float pivot = psum ? yt[(size_t)o * p] : 0.f;                    // Yt[0][0][o][0]
+    float s = 0.f, q = 0.f;
     for (int i = t; i < na * 64; i += 256) {
         const int a = i >> 6, pp = i & 63;
-        if (pp < np) tile[a * 65 + pp] = yt[(((size_t)b * na + a) * o_total + o) * p + p0 + pp];
+        if (pp < np) {
+            const float v = yt[(((size_t)b * na + a) * o_total + o) * p + p0 + pp];
+            tile[a * 65 + pp] = v;
+            const float d = v - pivot;
+            s += d; q = fmaf(d, d, q);
+        }
     }
+    red[0][t] = s; red[1][t] = q;
     __syncthreads();
     float *dst = y + (((size_t)b * o_total + o) * p + p0) * na;
     for (int i = t; i < np * na; i += 256) {
         const int pp = i / na, a = i - pp * na;
         dst[i] = tile[a * 65 + pp];
+    }
+    if (psum == nullptr) return;
+    for (int h = 128; h > 0; h >>= 1) {                                    // (fixed order: bit-reproducible)
+        if (t < h) { red[0][t] += red[0][t + h]; red[1][t] += red[1][t + h]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const size_t at = ((size_t)o * gridDim.z + b) * gridDim.x + blockIdx.x;
+        psum[at] = red[0][0]; psq[at] = red[1][0];
     }
 }
 
@@ -823,9 +845,11 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     return g_dense_form ? kc_launch<8, 1>(g, eap::S(stream)) : kc_launch<8, 0>(g, eap::S(stream));
 }
 
-extern "C" int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, eap_stream_t stream) {
+// psum, psq (may be null): float [o][b * ceil(p / 64)] partial sums of (y - y[0,o,0,0]) and of its square per 64-point chunk
+extern "C" int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, float *psum, float *psq, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (o > 65535 || b > 65535) return eap::bad_arg("so3_dense_untranspose: o, b <= 65535");
-    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, yt, y);
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, yt, y,
+                       psum, psum ? psq : nullptr);
     return eap::check_launch("so3_dense_untranspose");
 }

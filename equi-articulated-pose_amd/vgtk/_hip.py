@@ -594,7 +594,12 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None):
                                          'executed_f16_flops': _dense_executed_flops(geo, o, p), 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
-    call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y))
+    # the re-ordering pass also leaves the channel moments a BatchNorm right behind this layer starts with (its own pass otherwise)
+    chunks = (p + 63) // 64
+    ps = torch.empty(o, b * chunks, dtype=torch.float32, device=g.device)
+    pq = torch.empty_like(ps)
+    call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y), _ptr(ps), _ptr(pq))
+    leave_stats_hint(y, (ps, pq))
     return y
 
 
@@ -604,8 +609,31 @@ def _partials(x, b, c, n):
             torch.empty(c, b * nseg, dtype=torch.float32, device=x.device))
 
 
+# Channel moments of a tensor, handed from the kernel that WROTE it (the dense forward's re-ordering pass) to the BatchNorm behind
+# it: one entry, keyed like the row-maximum hint below (tensor object + version + shape)
+_STATS_HINT = [None]
+STATS_HINTS_TAKEN = 0
+
+
+def leave_stats_hint(t, partials):
+    import weakref
+    _STATS_HINT[0] = (weakref.ref(t), t._version, tuple(t.shape), partials)
+
+
+def take_stats_hint(t):
+    global STATS_HINTS_TAKEN
+    h, _STATS_HINT[0] = _STATS_HINT[0], None
+    if not USE_ROWMAX_HINT or h is None or h[0]() is not t or h[1] != t._version or h[2] != tuple(t.shape):
+        return None
+    STATS_HINTS_TAKEN += 1
+    return h[3]
+
+
 def bn_stats(x, b, c, n):
     """-> (sum, sumsq) of x - pivot per channel, float64 [c] (pivot = x[0, c, 0])."""
+    hint = take_stats_hint(x)
+    if hint is not None and hint[0].shape[0] == c:
+        return hint[0].sum(1, dtype=torch.float64), hint[1].sum(1, dtype=torch.float64)
     ps, pq = _partials(x, b, c, n)
     call('eap_bn_stats_f32', x, b, c, _I64(n), _ptr(x), _ptr(ps), _ptr(pq))
     return ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64)

@@ -349,7 +349,8 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *                             padded columns leaves it)
  *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1); dir 0 writes
  *                             Z with ldz >= na rp floats between its (o, k) rows (padding for the GEMMs that follow, not written)
- *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na] */
+ *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na]; psum / psq (may be null) float [o, b ceil(p/64)]: partial sums of
+ *                             y - y[0,o,0,0] and of its square, the moments of the BatchNorm that follows (eap_bn_stats_f32's pivot) */
 int eap_so3_dense_supported(int p, int na, int ks, int rp, int o);
 int eap_so3_dense_form(int form);
 int eap_so3_dense_member(int b, int p, int n, int nn, int rp, int rows_ld, const int32_t *idx, const int32_t *rows,
@@ -364,7 +365,7 @@ int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pi
 int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows, const void *planes,
                               const float *scale,
                               const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream);
-int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, eap_stream_t stream);
+int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, float *psum, float *psq, eap_stream_t stream);
 
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 

@@ -58,7 +58,7 @@ for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
     t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', g, 1, B, o, P, NA, KS, rp, _hip._I64(0), _hip._F32(sigma), _hip._ptr(head.n_rows if TRIM else None), _hip._ptr(planes), _hip._ptr(scale),
                                         _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(1)), _hip._ptr(yt)))
     y = torch.empty(B, o, P, NA, device=dev)
-    t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_f32', g, B, o, P, NA, _hip._ptr(yt), _hip._ptr(y)))
+    t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_f32', g, B, o, P, NA, _hip._ptr(yt), _hip._ptr(y), None, None))
     print(f'form {form} forward:  split {t_split:.2f} ms, product {t_prod:.2f} ms = {fl / t_prod / 1e9:.0f} TFLOP/s fp16, untranspose {t_un:.2f} ms')
     del planes, scale, yt, y
 _hip.lib.eap_so3_dense_form(1)
