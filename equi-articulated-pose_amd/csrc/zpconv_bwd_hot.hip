@@ -49,7 +49,7 @@ constexpr int TM = 64 * AQ * NT;              // 8 waves: (anchor, neighbour hal
 constexpr int ROWB = AQ * CH * 4;             // bytes of accumulators per referenced row
 constexpr int STAGE_G = AQ * KS * CH * 4;     // grad stage [anchor][k][c]
 constexpr int STAGE_S = NN * 4;               // byte offsets of the accumulator rows of the point's 64 neighbours
-constexpr int LDS_BYTES = 160 * 1024;
+constexpr int LDS_BYTES = 158 * 1024;      // 2 KB stay free on every CU: the index check's workgroups run BESIDE this kernel
 constexpr int RCAP = (LDS_BYTES - STAGE_G - STAGE_S) / ROWB - 1;      // referenced rows a cloud may have (+ one dump row)
 
 // Timing ablations (WRONG RESULTS), compiled only with `make ABLATION=1` and selected by EAP_ZPHOT_DEBUG (bit mask): 1 no LDS
@@ -66,18 +66,60 @@ __device__ __forceinline__ V ld_off(const float *ubase, unsigned voff) {
     return *reinterpret_cast<const V *>(reinterpret_cast<const char *>(ubase) + voff);
 }
 
-// slot_of[b, q] = position of support row q among the cloud's referenced rows (rows[b, r] = q), status[b] = 1 when the
-// cloud cannot take this path
-__global__ __launch_bounds__(1024) void zp_hot_slot_of_kernel(int nq, const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows,
-                                                              int32_t *__restrict__ slot_of, int32_t *__restrict__ status) {
-    const int bi = blockIdx.x, t = threadIdx.x;
-    const int R = n_rows[bi];
-    const bool ok = R <= RCAP;
-    if (t == 0) status[bi] = ok ? 0 : 1;
+// One workgroup per cloud: the cloud's referenced support rows from its per-point lists idx0[b, p, :] -- a bit per row in LDS
+// (read before the atomic: after the first few hundred entries every bit is set), then ranks by a scan over the words:
+// rows[b, r] = q in ascending order, slot_of[b, q] = r, n_rows[b], status[b] = 1 when the cloud cannot take this path.
+// (csrc/inv_lists.hip's rows -- a histogram, then a bitonic sort by list length for the grouping kernels -- cost 1.9 ms here.)
+__global__ __launch_bounds__(1024) void zp_hot_rows_kernel(int np, int nq, const int32_t *__restrict__ idx0, int32_t *__restrict__ rows,
+                                                           int32_t *__restrict__ n_rows, int32_t *__restrict__ slot_of,
+                                                           int32_t *__restrict__ status) {
+    __shared__ unsigned s_bits[512];                                         // nq <= 16384
+    __shared__ int s_w[16];
+    const int bi = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < 512) s_bits[t] = 0u;
+    __syncthreads();
+    const int4 *src = reinterpret_cast<const int4 *>(idx0 + (size_t)bi * np * NN);
+    const int n4 = np * (NN / 4);
+    for (int e = t; e < n4; e += 1024) {
+        const int4 v = src[e];
+        const int q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((unsigned)q[u] < (unsigned)nq) {
+                const unsigned m = 1u << (q[u] & 31);
+                if (!(s_bits[q[u] >> 5] & m)) atomicOr(&s_bits[q[u] >> 5], m);
+            }
+    }
+    __syncthreads();
+    const unsigned word = t < 512 ? s_bits[t] : 0u;
+    const int cnt = __popc(word);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += v;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int v = s_w[i];
+        total += v;
+        if (i < wave) base += v;
+    }
+    const bool ok = total <= RCAP;
+    if (t == 0) {
+        n_rows[bi] = total;
+        status[bi] = ok ? 0 : 1;
+    }
     if (!ok) return;
-    for (int r = t; r < R; r += 1024) {
-        const int q = rows[(size_t)bi * nq + r];
-        if (q >= 0) slot_of[(size_t)bi * nq + q] = r;
+    int r = base + inc - cnt;
+    for (unsigned m = word; m != 0u; m &= m - 1u) {
+        const int q = 32 * t + __ffs((int)m) - 1;
+        slot_of[(size_t)bi * nq + q] = r;
+        rows[(size_t)bi * nq + r] = q;
+        ++r;
     }
 }
 
@@ -306,10 +348,10 @@ __global__ __launch_bounds__(256) void zp_hot_reduce_kernel(int S, int nq, int n
 }
 
 // Workspace layout, shared by the size query and the launcher (every chunk on a 256-byte boundary):
-//   flag [b] | n_rows [b] | idx0 [b,np,64] | counts, rows, off, cnt, slot_of [b,nq] | slot_off [b,np,64] |
+//   flag [b] | n_rows [b] | idx0 [b,np,64] | rows, slot_of [b,nq] | slot_off [b,np,64] |
 //   partial [b, S, members, RCAP, 4, 32] (S > 1 only)
 struct HotWorkspace {
-    int64_t flag, n_rows, idx0, counts, rows, off, cnt, slot_of, slot_off, partial, total;
+    int64_t flag, n_rows, idx0, rows, slot_of, slot_off, partial, total;
     int S;
     HotWorkspace(int b, int np, int nq, int na, int c) {
         S = b >= 8 ? 1 : (8 + b - 1) / b;                       // point ranges per cloud: at least 8 groups of 30 workgroups
@@ -319,7 +361,7 @@ struct HotWorkspace {
         auto take = [&](int64_t bytes) { const int64_t r = at; at += (bytes + 255) / 256 * 256; return r; };
         flag = take(fl); n_rows = take(fl);
         idx0 = take(ent);
-        counts = take(rq); rows = take(rq); off = take(rq); cnt = take(rq); slot_of = take(rq);
+        rows = take(rq); slot_of = take(rq);
         slot_off = take(ent);
         partial = take(S > 1 ? 4ll * b * S * (na / 4) * (c / CH) * RCAP * AQ * CH : 0);
         total = at;
@@ -353,29 +395,17 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     int32_t *flag = reinterpret_cast<int32_t *>(wsb + L.flag);
     int32_t *n_rows = reinterpret_cast<int32_t *>(wsb + L.n_rows);
     int32_t *idx0 = reinterpret_cast<int32_t *>(wsb + L.idx0);
-    int32_t *counts = reinterpret_cast<int32_t *>(wsb + L.counts);
     int32_t *rows = reinterpret_cast<int32_t *>(wsb + L.rows);
-    int32_t *off = reinterpret_cast<int32_t *>(wsb + L.off);
-    int32_t *cnt = reinterpret_cast<int32_t *>(wsb + L.cnt);
     int32_t *slot_of = reinterpret_cast<int32_t *>(wsb + L.slot_of);
     int32_t *slot_off = reinterpret_cast<int32_t *>(wsb + L.slot_off);
     float *partial = reinterpret_cast<float *>(wsb + L.partial);
 
     int e = eap::hip_fail(hipMemsetAsync(flag, 0, sizeof(int32_t) * b, s), "inter_zpconv_backward (on-chip rows) flags");
     if (e) return e;
-    // idx0 = every point's first (a,k) row; the comparison of all the other rows with it streams the 5-D index once on the
-    // side stream, beside the kernels below (they are bound by their barriers, not by bandwidth)
+    // idx0 = every point's first (a,k) row (what the kernels below walk), the cloud's referenced rows and the slot of every list entry
     e = eap::zpconv_first_rows(b, np, na * ks * ann, ann, idx, idx0, s);
     if (e) return e;
-    hipStream_t side;
-    e = eap::side_fork(s, &side);
-    if (e) return e;
-    eap::SideJoin joiner(s);              // (also on the error returns below)
-    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, nullptr, nullptr, flag, side);
-    if (e) return e;
-    e = eap_inv_lists_rows(b, np, nq, ann, idx0, counts, rows, off, cnt, n_rows, stream);
-    if (e) return e;
-    hipLaunchKernelGGL(zp_hot_slot_of_kernel, dim3(b), dim3(1024), 0, s, nq, rows, n_rows, slot_of, status);
+    hipLaunchKernelGGL(zp_hot_rows_kernel, dim3(b), dim3(1024), 0, s, np, nq, idx0, rows, n_rows, slot_of, status);
     hipLaunchKernelGGL(zp_hot_slot_off_kernel, dim3(eap::cdiv((long long)np * NN, 256), b), dim3(256), 0, s, np, nq, idx0, slot_of, n_rows, status,
                        slot_off);
     e = eap::check_launch("inter_zpconv_backward (on-chip rows) slots");
@@ -386,6 +416,13 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     e = eap::hip_fail(hipFuncSetAttribute((const void *)zp_hot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
                       "inter_zpconv_backward (on-chip rows) shared memory");
     if (e) return e;
+    // The comparison of every other (a,k) row with the first -- the op's 12 GB index read -- streams on the side stream BESIDE
+    // the matrix kernel (forked here: behind the short kernels above, which its 32768 workgroups would starve of wave slots;
+    // the matrix kernel leaves 2 KB of LDS per CU for them)
+    hipStream_t side;
+    e = eap::side_fork(s, &side);
+    if (e) return e;
+    eap::SideJoin joiner(s);              // (also on the error returns below)
     const int members = (na / 4) * (c / CH), groups = b * L.S;
     const long long blocks = 8ll * members * ((groups + 7) / 8);
     if (blocks >= (1ll << 31)) return eap::bad_arg("inter_zpconv_backward (on-chip rows): too many workgroups");
@@ -399,6 +436,9 @@ extern "C" int eap_inter_zpconv_bwd_hot_f32(int b, int np, int nq, int na, int k
     e = eap::check_launch("inter_zpconv_backward (on-chip rows)");
     if (e) return e;
     eap::set_kernel("zp_hot_kernel");
+    // (submitted behind the matrix kernel, whose workgroups take their CUs first)
+    e = eap::zpconv_index_check(b, np, na * ks * ann, ann, idx, nullptr, nullptr, flag, side);
+    if (e) return e;
     if (L.S > 1) {
         hipLaunchKernelGGL(zp_hot_reduce_kernel, dim3(members, b), dim3(256), 0, s, L.S, nq, na, c, partial, rows, n_rows, status, gfeats);
         e = eap::check_launch("inter_zpconv_backward (on-chip rows) reduce");
