@@ -358,7 +358,7 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
             'entry': 'eap_inter_zpconv_fwd_ws_f32', 'achieved': gbs,
             'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0, 'ms': ms, 'bytes': byts,
             'backward': {'entry': 'eap_inter_zpconv_bwd_hot_f32',
-                         'kernels': 'zpconv_index_check_kernel + inv_lists rows + zp_hot_kernel (v_mfma_f32_32x32x2_f32, scatter target in LDS: '
+                         'kernels': 'zp_hot_rows_kernel + zp_hot_kernel with zpconv_index_check_kernel streaming beside it (v_mfma_f32_32x32x2_f32, scatter target in LDS: '
                                     'no per-(point, neighbour) intermediate; the weights are read by the two channel halves of an anchor quad)',
                          'ms': ms_b, 'achieved': byts / ms_b / 1e6, 'frac': byts / ms_b / 1e6 / 8000.0,
                          'bytes': byts, 'intermediate_bytes': 0.0,

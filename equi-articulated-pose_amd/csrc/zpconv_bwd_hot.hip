@@ -12,8 +12,9 @@
 //
 //   workgroup = (cloud, point range, anchor QUAD, 32 channels), one per CU (all 160 KB of LDS), 8 waves = (anchor of the
 //              quad, half of the point's 64 neighbours), two per SIMD;
-//   LDS      = acc[row slot][4 anchors][32 channels] (512 B per referenced row, at most 295 rows + a dump row for
-//              out-of-range indices) + one operand stage (12.25 KB), two when the rows leave room (<= 271);
+//   LDS      = acc[row slot][4 anchors][32 channels] (512 B per referenced row, at most 290 rows + a dump row for
+//              out-of-range indices) + one operand stage (12.25 KB), two when the rows leave room (<= 266); 2 KB of the CU's 160 stay free
+//              for the index check's workgroups, which stream beside this kernel;
 //   per point and wave: T[32 n, 32 c] = sum_k w[p,a,k,n] grad[c,k,p,a] as 12 v_mfma_f32_32x32x2_f32 (M = neighbours,
 //              N = channels, K = kernel points: no padding), then acc[slot(idx[p,n])][a][c] += T as read - add - write;
 //              lanes run along the channels (conflict-free).  A word receives at most ONE contribution per point -- a list
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(TM, 2) void zp_hot_kernel(int nb, int S, int np, in
     const int p0 = (int)((long long)np * sp / S), p1 = (int)((long long)np * (sp + 1) / S);
 
     // LDS: acc[R + 1][AQ][CH] (row R = the dump row of out-of-range indices), then one or -- when the rows leave room,
-    // R <= 270 -- two operand stages: with two, a point's pieces are staged while the previous point's matrix work runs
+    // R <= 266 -- two operand stages: with two, a point's pieces are staged while the previous point's matrix work runs
     // and the workgroup meets at ONE barrier per point
     float *acc_f = reinterpret_cast<float *>(smem);
     const unsigned stage0 = (unsigned)(R + 1) * ROWB;
