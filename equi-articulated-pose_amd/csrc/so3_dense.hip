@@ -215,11 +215,14 @@ __global__ __launch_bounds__(256) void dense_points_kernel(int p, int p_pad, int
 }
 
 // kr[b][a][dense index of (k, r)], u = x~_row(r) - rk[a][k]: FORM 1 (u, 0); FORM 0 (u, 1 - |u|^2/sigma); entries past ks rp and empty
-// slots: far away (FORM 1) / zeros (FORM 0) -- weight 0 either way, and their mask bits are 0
+// slots: far away (FORM 1) / zeros (FORM 0) -- weight 0 either way, and their mask bits are 0.
+// row_rot (may be null) float [b][rows_ld][9]: a rotation M per row slot, u = x~_row(r) - M rk[a][k] -- clouds whose points carry ONE
+// pose rotation per rigid part: the reference rotates the offset by R_rel = R_p R_r^T (so3conv/functional.py:L1112-1160) and
+// |R_rel (x_r - x_p) - A kappa| = |x_r - x_p - R_rel^T A kappa|, so for the query points of one part M = R_rel^T depends on the row only
 __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int ks, int rp, int kd_pad, int rows_ld, int form, float inv_sigma,
                                                          const float *__restrict__ s_xyz, const float *__restrict__ centre,
                                                          const int32_t *__restrict__ rows, const float *__restrict__ rk,
-                                                         f32x4 *__restrict__ kr) {
+                                                         const float *__restrict__ row_rot, f32x4 *__restrict__ kr) {
     const int b = blockIdx.z, a = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kd_pad) return;
     f32x4 v = form ? (f32x4){1e4f, 1e4f, 1e4f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -230,9 +233,15 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int 
         if ((unsigned)row < (unsigned)n_sup) {
             const double is = (double)inv_sigma;
             const float *kp = rk + ((size_t)a * ks + k) * 3;
-            const double x = (double)s_xyz[((size_t)b * 3 + 0) * n_sup + row] - (double)centre[b * 4 + 0] - (double)kp[0];
-            const double y = (double)s_xyz[((size_t)b * 3 + 1) * n_sup + row] - (double)centre[b * 4 + 1] - (double)kp[1];
-            const double z = (double)s_xyz[((size_t)b * 3 + 2) * n_sup + row] - (double)centre[b * 4 + 2] - (double)kp[2];
+            double k0 = (double)kp[0], k1 = (double)kp[1], k2 = (double)kp[2];
+            if (row_rot != nullptr) {
+                const float *M = row_rot + ((size_t)b * rows_ld + r) * 9;
+                const double t0 = M[0] * k0 + M[1] * k1 + M[2] * k2, t1 = M[3] * k0 + M[4] * k1 + M[5] * k2, t2 = M[6] * k0 + M[7] * k1 + M[8] * k2;
+                k0 = t0; k1 = t1; k2 = t2;
+            }
+            const double x = (double)s_xyz[((size_t)b * 3 + 0) * n_sup + row] - (double)centre[b * 4 + 0] - k0;
+            const double y = (double)s_xyz[((size_t)b * 3 + 1) * n_sup + row] - (double)centre[b * 4 + 1] - k1;
+            const double z = (double)s_xyz[((size_t)b * 3 + 2) * n_sup + row] - (double)centre[b * 4 + 2] - k2;
             v = (f32x4){(float)x, (float)y, (float)z, form ? 0.f : (float)(1.0 - is * (x * x + y * y + z * z))};
         }
     }
@@ -247,20 +256,27 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int n_sup, int na, int 
 // (anchor quad aq, lane group pg) walks the row's float4 pieces aq + nq (pg + G j): consecutive threads, consecutive pieces
 // (a row's l elements may come in l / seg segments of seg elements, seg_pitch4 float4 apart: the rows of G as the small GEMM
 // leaves them, [o][k][pitch >= rp na])
-__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, int seg, long long seg_pitch4, const f32x4 *__restrict__ T,
-                                                           float *__restrict__ scale, float *__restrict__ scale2) {
+// colmap (may be null) int32 [b][l]: element i of a row is element colmap[b][i] of a source row of seg_pitch4 float4 x nq (one segment);
+// negative: a zero
+__global__ __launch_bounds__(256) void dense_rowmax_kernel(int m, int l, int na, int seg, long long seg_pitch4, const int32_t *__restrict__ colmap,
+                                                           const f32x4 *__restrict__ T, float *__restrict__ scale, float *__restrict__ scale2) {
     __shared__ unsigned s[256][4];
     const int nq = na >> 2, G = 256 / nq, b = blockIdx.y, row = blockIdx.x, t = threadIdx.x;
     const int aq = t % nq, pg = t / nq;
     unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     if (pg < G) {
-        const f32x4 *src = T + ((size_t)b * m + row) * (size_t)(l / seg) * seg_pitch4;
+        const f32x4 *src = T + ((size_t)b * m + row) * (colmap ? (size_t)1 : (size_t)(l / seg)) * seg_pitch4;
         for (int i0 = pg; i0 < l; i0 += 8 * G) {                   // eight independent 16-byte loads in flight per thread
             f32x4 q[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + u * G, l - 1), sg = i / seg;      // (past the end: the last element again -- a maximum does not mind)
-                q[u] = src[(size_t)sg * seg_pitch4 + (size_t)(i - sg * seg) * nq + aq];
+                if (colmap != nullptr) {
+                    const int ci = colmap[(size_t)b * l + i];
+                    q[u] = ci >= 0 ? src[(size_t)ci * nq + aq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+                    q[u] = src[(size_t)sg * seg_pitch4 + (size_t)(i - sg * seg) * nq + aq];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -304,9 +320,11 @@ __global__ __launch_bounds__(256) void dense_scale_kernel(long long total, int m
 // writes its 8 pieces; the 64 pieces of a 1 KB run come from one block within a few hundred cycles.
 // mapped (the forward's G, seg = rp, l = ks rp): element l of a row is the pair (k, r) with DENSE INDEX l, found at segment k,
 // position r; k-blocks past the cloud's own prefix (n_rows) are not written -- the product never reads them.
+// colmap: as dense_rowmax_kernel's (the columns of dY that are one rigid part's query points)
 __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, int kb_total, int seg, long long seg_pitch4, int mapped,
-                                                          const int32_t *__restrict__ n_rows, const f32x4 *__restrict__ T,
-                                                          const float *__restrict__ scale2, u32x4 *__restrict__ planes) {
+                                                          const int32_t *__restrict__ n_rows, const int32_t *__restrict__ colmap,
+                                                          const f32x4 *__restrict__ T, const float *__restrict__ scale2,
+                                                          u32x4 *__restrict__ planes) {
     const int b = blockIdx.z, mt = blockIdx.y, kb = blockIdx.x, t = threadIdx.x;
     const int nq = na >> 2, RG = 256 / nq;                      // rows per pass
     const int aq = t % nq, rr = t / nq;
@@ -322,13 +340,21 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
             const int it = min(it0 + u * RG, 63);
             const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
             rowv[u] = row; lanef[u] = i + 32 * kg;
-            const f32x4 *src = T + ((size_t)b * m + row) * (size_t)nseg * seg_pitch4 + aq;
+            const f32x4 *src = T + ((size_t)b * m + row) * (colmap ? (size_t)1 : (size_t)nseg) * seg_pitch4 + aq;
             int sg = l0 / seg, sr = l0 - sg * seg;                // segment and position of element l0 + e
             if (mapped) dense_kr(l0, nseg, sg, sr);               // (8 consecutive dense indices: one kernel point, 8 consecutive slots)
+            if (colmap != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                q[u][e] = (l0 + e < l) ? src[(size_t)sg * seg_pitch4 + (size_t)sr * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (++sr == seg) { sr = 0; ++sg; }
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = (l0 + e < l) ? colmap[(size_t)b * l + l0 + e] : -1;
+                    q[u][e] = ci >= 0 ? src[(size_t)ci * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    q[u][e] = (l0 + e < l) ? src[(size_t)sg * seg_pitch4 + (size_t)sr * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (++sr == seg) { sr = 0; ++sg; }
+                }
             }
         }
 #pragma unroll
@@ -352,7 +378,10 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
 // sum and sum of squares of (y - pivot), pivot = Y[0][o][0][0] -- the partial moments the BatchNorm that follows would otherwise
 // read the whole tensor for (csrc/bn_act.hip bn_stats_kernel: the same pivot, summed in float64 by the caller), at
 // [o][b * chunks + chunk].
-__global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int p, int na, const float *__restrict__ yt, float *__restrict__ y,
+// map (may be null) int32 [b][p]: column pp of cloud b is point map[b][pp] of a Y with p_dst points (< 0: the column is padding, not
+// written) -- the query points of one rigid part of a posed cloud, computed as a launch of their own
+__global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int p, int na, int p_dst, const int32_t *__restrict__ map,
+                                                                const float *__restrict__ yt, float *__restrict__ y,
                                                                 float *__restrict__ psum, float *__restrict__ psq) {
     extern __shared__ float tile[];
     __shared__ float red[2][256];
@@ -371,6 +400,15 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int
     }
     red[0][t] = s; red[1][t] = q;
     __syncthreads();
+    if (map != nullptr) {
+        float *row = y + ((size_t)b * o_total + o) * p_dst * na;
+        for (int i = t; i < np * na; i += 256) {
+            const int pp = i / na, a = i - pp * na;
+            const int q = map[(size_t)b * p + p0 + pp];
+            if ((unsigned)q < (unsigned)p_dst) row[(size_t)q * na + a] = tile[a * 65 + pp];
+        }
+        return;
+    }
     float *dst = y + (((size_t)b * o_total + o) * p + p0) * na;
     for (int i = t; i < np * na; i += 256) {
         const int pp = i / na, a = i - pp * na;
@@ -750,8 +788,8 @@ extern "C" int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const 
 }
 
 extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
-                                        const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
-                                        eap_stream_t stream) {
+                                        const float *s_xyz, const int32_t *rows, const float *rk, const float *row_rot, float *centre, float *pt,
+                                        float *kr, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (b > 65535 || na > 65535 || !(sigma > 0.f)) return eap::bad_arg("so3_dense_tables: b, na <= 65535, sigma > 0");
     hipStream_t s = eap::S(stream);
@@ -760,7 +798,7 @@ extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks,
     hipLaunchKernelGGL(dense_points_kernel, dim3(eap::cdiv(p_pad, 256), b), dim3(256), 0, s, p, p_pad, g_dense_form, 1.0f / sigma, q_xyz, centre,
                        reinterpret_cast<f32x4 *>(pt));
     hipLaunchKernelGGL(dense_rows_kernel, dim3(eap::cdiv(kd_pad, 256), na, b), dim3(256), 0, s, n_sup, na, ks, rp, kd_pad, rows_ld, g_dense_form, 1.0f / sigma, s_xyz,
-                       centre, rows, rk, reinterpret_cast<f32x4 *>(kr));
+                       centre, rows, rk, row_rot, reinterpret_cast<f32x4 *>(kr));
     return eap::check_launch("so3_dense_tables");
 }
 
@@ -769,12 +807,19 @@ extern "C" int eap_so3_dense_tables_f32(int b, int p, int n_sup, int na, int ks,
 // whose dense index is l (eap_so3_dense_product_f32), read from segment k, position r; with n_rows [b] the k-blocks past a
 // cloud's own prefix are left unwritten.
 // rowmax (may be null): max |src| per (cloud, row, anchor) as float bit patterns, [b][m][na] -- saves the pass that finds them
+// (an upper bound will do: the scale is the power of two that brings it below 2^15)
+// colmap (may be null; not with mapped) int32 [b][l]: element i of every row is element colmap[b][i] of a source row of seg_pitch floats
+// (negative: zero) -- the columns of dY [b,o,P,na] that are the query points of one rigid part, seg_pitch = P na
 extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const uint32_t *rowmax,
-                                       const float *src, float *scale, void *planes, eap_stream_t stream) {
+                                       const int32_t *colmap, const float *src, float *scale, void *planes, eap_stream_t stream) {
     if (b <= 0) return 0;
+    if (colmap != nullptr) {
+        if (mapped || seg_pitch <= 0) return eap::bad_arg("so3_dense_split: a column map comes with the source row pitch and without the dense-index mapping");
+        seg = l;
+    }
     if (seg <= 0) { seg = l; seg_pitch = (int64_t)l * na; }
     if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || (reinterpret_cast<uintptr_t>(src) & 15) || l % seg != 0 ||
-        (seg_pitch & 3) != 0 || seg_pitch < (int64_t)seg * na || (mapped && ((seg % 16) != 0 || ((l / seg) % 2) != 0)))
+        (seg_pitch & 3) != 0 || (colmap == nullptr && seg_pitch < (int64_t)seg * na) || (mapped && ((seg % 16) != 0 || ((l / seg) % 2) != 0)))
         return eap::bad_arg("so3_dense_split: m % 32, na % 4, na <= 64, 16-byte aligned source, whole segments of a 16-byte aligned pitch (mapped: seg % 16, an even number of segments)");
     hipStream_t s = eap::S(stream);
     const int kb_total = ceil_to(l, KC_BK) / 16;
@@ -782,9 +827,9 @@ extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int
     if (rowmax != nullptr)
         hipLaunchKernelGGL(dense_scale_kernel, dim3(eap::cdiv((long long)b * m * na, 256)), dim3(256), 0, s, (long long)b * m * na, m, na, rowmax, scale, scale2);
     else
-        hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), reinterpret_cast<const f32x4 *>(src), scale, scale2);
+        hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), colmap, reinterpret_cast<const f32x4 *>(src), scale, scale2);
     hipLaunchKernelGGL(dense_split_kernel, dim3(kb_total, m / 32, b), dim3(256), 0, s, m, l, na, kb_total, seg, (long long)(seg_pitch / 4), mapped ? 1 : 0,
-                       n_rows, reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
+                       n_rows, colmap, reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
     return eap::check_launch("so3_dense_split");
 }
 
@@ -849,7 +894,18 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
 extern "C" int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, float *psum, float *psq, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (o > 65535 || b > 65535) return eap::bad_arg("so3_dense_untranspose: o, b <= 65535");
-    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, yt, y,
-                       psum, psum ? psq : nullptr);
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p, nullptr,
+                       yt, y, psum, psum ? psq : nullptr);
     return eap::check_launch("so3_dense_untranspose");
+}
+
+// the same re-ordering into a Y [b,o,p_dst,na] that other launches fill too: column pp of cloud b goes to point map[b][pp] (int32 [b,p];
+// negative: padding, dropped)
+extern "C" int eap_so3_dense_untranspose_map_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *yt, float *y,
+                                                 eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (o > 65535 || b > 65535 || map == nullptr || p_dst <= 0) return eap::bad_arg("so3_dense_untranspose_map: o, b <= 65535, a map, p_dst > 0");
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p_dst, map,
+                       yt, y, nullptr, nullptr);
+    return eap::check_launch("so3_dense_untranspose_map");
 }

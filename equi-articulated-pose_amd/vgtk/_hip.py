@@ -515,7 +515,9 @@ class DenseGeometry:
     rotations: the lane masks of both directions (built on demand from the membership bits) and the two float4 tables of the
     expanded weight, for the first rp referenced rows of every cloud."""
 
-    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn, n_rows=None):
+    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn, n_rows=None, row_rot=None):
+        """row_rot float32 [b, rows.stride(0), 3, 3] (optional): one rotation per row slot applied to the kernel offsets -- the query
+        points are ONE rigid part of a posed cloud (include/eap_hip.h: eap_so3_dense_tables_f32)."""
         b, p = memb.shape[:2]
         n = s_xyz.shape[2]
         na, ks, _ = rk.shape
@@ -526,8 +528,10 @@ class DenseGeometry:
         self.centre = torch.empty(b, 4, dtype=torch.float32, device=dev)
         self.pt = torch.empty(b, p_pad, 4, dtype=torch.float32, device=dev)
         self.kr = torch.empty(b, na, kd_pad, 4, dtype=torch.float32, device=dev)
+        if row_rot is not None and (row_rot.dtype != torch.float32 or not row_rot.is_contiguous() or row_rot.numel() != b * rows.stride(0) * 9):
+            raise RuntimeError('DenseGeometry: row_rot must be a contiguous float32 [b, rows.stride(0), 3, 3]')
         call('eap_so3_dense_tables_f32', memb, b, p, n, na, ks, self.rp, rows.stride(0), _F32(sigma), _ptr(q_xyz), _ptr(s_xyz), _ptr(rows),
-             _ptr(rk), _ptr(self.centre), _ptr(self.pt), _ptr(self.kr))
+             _ptr(rk), _ptr(row_rot), _ptr(self.centre), _ptr(self.pt), _ptr(self.kr))
         self._masks = {}
 
     def mask(self, direction):
@@ -540,16 +544,22 @@ class DenseGeometry:
         return m
 
 
-def so3_dense_split(src, seg=0, seg_pitch=0, shape=None, mapped=False, n_rows=None, rowmax=None):
+def so3_dense_split(src, seg=0, seg_pitch=0, shape=None, mapped=False, n_rows=None, rowmax=None, colmap=None):
     """src [b,m,l,na] -> (scale [2,b,na,m], planes): the stored operand of the dense product (two fp16 planes of the scaled rows,
     fragment order).  seg > 0 (with shape = (b, m, l, na)): a row's l elements lie in l / seg segments of seg elements whose
     starts are seg_pitch floats apart (the rows of a GEMM output with padded columns).  mapped: the output's element l is the
     (k, r) pair with dense index l (the forward's operand), n_rows trims every cloud to its own rows.  rowmax int32 [b,m,na]: the
-    rows' largest magnitudes (float bit patterns) when the producer already has them -- no pass over src for them."""
+    rows' largest magnitudes (float bit patterns) when the producer already has them -- no pass over src for them (an upper bound will
+    do).  colmap int32 [b,l']: the operand is the columns colmap[b, :] of src [b,m,l,na] (negative: a zero column)."""
     b, m, l, na = src.shape if shape is None else shape
+    if colmap is not None:
+        if colmap.dtype != torch.int32 or not colmap.is_contiguous() or colmap.shape[0] != b:
+            raise RuntimeError('so3_dense_split: colmap must be a contiguous int32 [b, columns]')
+        seg_pitch, l = l * na, colmap.shape[1]
     scale = torch.empty(2, b, na, m, dtype=torch.float32, device=src.device)      # [0]: [b,na,m]; [1]: the same numbers as [b,m,na]
     planes = torch.empty(b * na * m * ((l + 31) // 32 * 32), dtype=torch.int32, device=src.device)       # 4 bytes per element
-    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), int(bool(mapped)), _ptr(n_rows), _ptr(rowmax), _ptr(src), _ptr(scale), _ptr(planes))
+    call('eap_so3_dense_split_f32', src, b, m, l, na, int(seg), _I64(seg_pitch), int(bool(mapped)), _ptr(n_rows), _ptr(rowmax), _ptr(colmap), _ptr(src), _ptr(scale),
+         _ptr(planes))
     return scale, planes
 
 
@@ -568,12 +578,16 @@ def _dense_executed_flops(geo, o, p):
     return 6.0 * o * p * geo.na * geo.ks * rows
 
 
-def so3_dense_bwd(gy, geo, ldz=None):
+def so3_dense_bwd(gy, geo, ldz=None, colmap=None, rowmax=False):
     """gy [b,o,p,na] -> Z [b,o,ks,ldz] whose rows hold [na,rp] (the inverse-list kernel's Z with the anchor axis in front of the row
-    axis); ldz >= na*rp (default: equal) pads the rows for the GEMMs that follow -- the padding is NOT written."""
+    axis); ldz >= na*rp (default: equal) pads the rows for the GEMMs that follow -- the padding is NOT written.
+    colmap int32 [b,p']: the product runs over the columns colmap[b, :] of gy (the query points of one rigid part: geo is that part's);
+    rowmax: row maxima of gy somebody already took from the hint (None: none available; default: ask the hint)."""
     b, o, p, na = gy.shape
     ldz = na * geo.rp if ldz is None else int(ldz)
-    scale, planes = so3_dense_split(gy, rowmax=take_rowmax_hint(gy))
+    scale, planes = so3_dense_split(gy, rowmax=take_rowmax_hint(gy) if rowmax is False else rowmax, colmap=colmap)
+    if colmap is not None:
+        p = colmap.shape[1]
     z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
     call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
          _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': _dense_executed_flops(geo, o, p),
@@ -581,9 +595,11 @@ def so3_dense_bwd(gy, geo, ldz=None):
     return z
 
 
-def so3_dense_fwd(g, geo, p, c=0, ldg=None):
+def so3_dense_fwd(g, geo, p, c=0, ldg=None, out=None, col_map=None):
     """g [b,o,ks,ldg] (rows hold [rp,na]: W . F over the referenced rows, F with c channels; ldg >= rp*na, default equal) -> y [b,o,p,na].
-    (c only prices the launch for bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)"""
+    (c only prices the launch for bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)
+    out [b,o,p_dst,na] with col_map int32 [b,p]: the p columns are the points col_map[b, :] of `out` (negative: padding) -- the launch
+    of one rigid part of posed clouds; returns out."""
     b, o = g.shape[:2]
     na = geo.na
     ldg = geo.rp * na if ldg is None else int(ldg)
@@ -593,6 +609,11 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None):
          _ptr(geo.mask(1)), _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp),
                                          'executed_f16_flops': _dense_executed_flops(geo, o, p), 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes
+    if col_map is not None:
+        if out is None or col_map.dtype != torch.int32 or tuple(col_map.shape) != (b, p) or not col_map.is_contiguous() or not out.is_contiguous():
+            raise RuntimeError('so3_dense_fwd: col_map must be a contiguous int32 [b,p] and come with a contiguous out')
+        call('eap_so3_dense_untranspose_map_f32', g, b, o, p, na, out.shape[2], _ptr(col_map), _ptr(yt), _ptr(out))
+        return out
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
     # the re-ordering pass also leaves the channel moments a BatchNorm right behind this layer starts with (its own pass otherwise)
     chunks = (p + 63) // 64

@@ -640,23 +640,156 @@ def _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz=None):
     return d.view(o, ks, c).permute(0, 2, 1).reshape(o, c * ks).contiguous()
 
 
-def _dense_forward(feats, W, rows, geo, p):
-    """y [b,o,p,a] = sum_(k,r) G[o,(k,r),a] Wd[p,(k,r),a] with G = W F over the referenced rows (csrc/so3_dense.hip).  The small
-    GEMM that makes G runs on the split-operand kernels where its shapes allow: its columns (row, anchor) padded to whole
-    128-column tiles (the padding of F is zero, G's padded columns are skipped by the split that follows)."""
-    b, c, n, na = feats.shape
-    o, ks, rp = W.shape[0], geo.ks, geo.rp
+# Posed clouds whose points carry ONE rotation per rigid part (articulated objects: every point takes the pose of its part): the
+# reference rotates an entry's offset by R_rel = R_p R_r^T and permutes the neighbour's anchor axis by the group element nearest to
+# R_rel (so3conv/functional.py:L1112-1160; csrc/so3_inter.hip so3_prep_kernel) -- both depend on (part of p, part of r) only.  The dense
+# product then runs once per part over that part's query points: its k-side table takes R_rel^T per ROW (a row's part is fixed), the
+# stored operand is built from the rows' features with their anchor axis permuted per row.  DENSE_MAX_PARTS bounds the launches.
+DENSE_PARTS = os.environ.get('EAP_DENSE_PARTS', '1') != '0'
+DENSE_MAX_PARTS = 6
+_POSE_PARTS = {}            # (storage pointer, version, shape) of a pose tensor -> (weakref, _PoseParts or None)
+
+
+class _PoseParts:
+    """The points of every cloud grouped by their pose rotation (bit-equal 3x3 blocks): part slots 0 .. n-1 per cloud, largest part
+    first; slot i of the batch is one launch over pts[i] int64 [b, p_i] (p_i = the largest part i of any cloud rounded to the product
+    kernel's 256-column blocks;
+    entries past a cloud's own part size repeat a valid point and are marked in col_map[i] int32 [b, p_i] = -1)."""
+
+    def __init__(self, labels, reps, sizes, p):
+        dev = labels.device
+        b = labels.shape[0]
+        self.labels, self.reps, self.sizes, self.n = labels, reps, sizes, len(sizes[0])
+        self.single = self.n == 1
+        order = torch.argsort(labels, dim=1, stable=True)                   # points sorted by part
+        self.pts, self.col_map, self.width = [], [], []
+        start = [0] * b
+        for i in range(self.n):
+            width = (max(sizes[bi][i] for bi in range(b)) + 255) // 256 * 256
+            st = torch.tensor(start, dtype=torch.int64, device=dev)[:, None]
+            sz = torch.tensor([sizes[bi][i] for bi in range(b)], dtype=torch.int64, device=dev)[:, None]
+            t = torch.arange(width, dtype=torch.int64, device=dev)[None, :]
+            valid = t < sz
+            pts = order.gather(1, (st + torch.where(valid, t, torch.zeros_like(t))).clamp(max=p - 1))
+            self.pts.append(pts.contiguous())
+            self.col_map.append(torch.where(valid, pts, torch.full_like(pts, -1)).to(torch.int32).contiguous())
+            self.width.append(width)
+            start = [start[bi] + sizes[bi][i] for bi in range(b)]
+
+
+def _pose_parts(rot):
+    """-> _PoseParts of pose [b,p,4,4], or None when a cloud has more than DENSE_MAX_PARTS distinct rotations.  One host read per pose
+    tensor (remembered by tensor identity + version: the layers of a backbone share their poses)."""
+    key = (rot.data_ptr(), rot._version, tuple(rot.shape))
+    hit = _POSE_PARTS.get(key)
+    if hit is not None and hit[0]() is rot:
+        return hit[1]
+    b, p = rot.shape[:2]
+    dev = rot.device
+    r9 = rot[:, :, :3, :3].reshape(b * p, 9).contiguous()
+    bits = r9.view(torch.int32).to(torch.int64)
+    mul = torch.tensor([0x9E3779B97F4A7C15 - (1 << 64), 0xC2B2AE3D27D4EB4F - (1 << 64), 0x165667B19E3779F9, 0x27D4EB2F165667C5, 0x85EBCA77C2B2AE63 - (1 << 64),
+                        0x2545F4914F6CDD1D, 0x5851F42D4C957F2D, 0x14057B7EF767814F, 0x3C6EF372FE94F82B], dtype=torch.int64, device=dev)
+    h = (bits * mul).sum(1)
+    h = (h ^ (h >> 31)) & ((1 << 55) - 1)
+    keys = h + (torch.arange(b, dtype=torch.int64, device=dev).repeat_interleave(p) << 55)
+    uniq, inv, counts = torch.unique(keys, return_inverse=True, return_counts=True)     # (sorted: a cloud's parts are consecutive)
+    result = None
+    if uniq.numel() <= b * DENSE_MAX_PARTS:
+        nu = uniq.numel()
+        first = torch.full((nu,), b * p, dtype=torch.int64, device=dev).scatter_reduce(0, inv, torch.arange(b * p, dtype=torch.int64, device=dev), 'amin')
+        rep = r9[first]                                                                     # [nu, 9]
+        same = (rep[inv] == r9).all().to(torch.int64)                                       # (a hash collision would show here)
+        host = torch.cat([same[None], uniq >> 55, counts]).tolist()
+        ok, cloud, cnt = host[0], host[1:1 + nu], host[1 + nu:]
+        per = [[] for _ in range(b)]
+        for u in range(nu):
+            per[cloud[u]].append((cnt[u], u))
+        n = max(len(x) for x in per)
+        if ok and n <= DENSE_MAX_PARTS and min(len(x) for x in per) >= 1:
+            slot = [0] * nu
+            sizes = [[0] * n for _ in range(b)]
+            rep_idx = [[per[bi][0][1]] * n for bi in range(b)]
+            for bi in range(b):
+                for i, (c_, u) in enumerate(sorted(per[bi], key=lambda x: (-x[0], x[1]))):
+                    slot[u], sizes[bi][i], rep_idx[bi][i] = i, c_, u
+            labels = torch.tensor(slot, dtype=torch.int64, device=dev)[inv].view(b, p)
+            reps = rep[torch.tensor(rep_idx, dtype=torch.int64, device=dev)].view(b, n, 3, 3)
+            result = _PoseParts(labels, reps, sizes, p)
+    if len(_POSE_PARTS) > 16:
+        _POSE_PARTS.clear()
+    _POSE_PARTS[key] = (weakref.ref(rot), result)
+    return result
+
+
+class _PartsDense:
+    """Per part slot of a _PoseParts: the dense product's geometry over that part's query points (row rotations in its k-side table)
+    and the per-row anchor permutation of the stored operand."""
+
+    def __init__(self, parts, xyz, memb, rows, rp, rk, sigma, nn, n_rows, mult, anchors):
+        b, p = parts.labels.shape
+        dev = xyz.device
+        self.parts, self.rp, self.ks, self.na = parts, int(rp), rk.shape[1], rk.shape[0]
+        ld = rows.stride(0)
+        rows_all = torch.as_strided(rows, (b, ld), (ld, 1))
+        row_part = parts.labels.gather(1, rows_all.clamp(min=0, max=p - 1).long())                     # [b, ld] (empty slots: anything)
+        R_row = parts.reps.double().gather(1, row_part[:, :, None, None].expand(b, ld, 3, 3))        # R_j of every row slot
+        self.geo, self.perm = [], []
+        A = anchors.double() if anchors is not None else None
+        for i in range(parts.n):
+            R_i = parts.reps[:, i].double()                                                           # [b,3,3]
+            M = torch.matmul(R_row, R_i[:, None].transpose(-1, -2))                                   # R_rel^T = R_j R_i^T   [b,ld,3,3]
+            pts = parts.pts[i]
+            q_xyz = xyz.gather(2, pts[:, None, :].expand(b, 3, pts.shape[1])).contiguous()
+            valid = (parts.col_map[i] >= 0)
+            memb_i = (memb.gather(1, pts[:, :, None].expand(b, pts.shape[1], memb.shape[2])) * valid[:, :, None].to(memb.dtype)).contiguous()
+            self.geo.append(_hip.DenseGeometry(q_xyz, xyz, memb_i, rows, rp, rk, sigma, nn, n_rows, row_rot=M.float().contiguous()))
+            if mult is None:
+                self.perm.append(None)
+            else:
+                # the group element nearest to R_rel = M^T: argmax_g tr(R_rel A_g) (so3_prep_kernel; first maximum)
+                t = torch.einsum('brji,gji->brg', M[:, :rp], A)
+                ridx = t.float().argmax(dim=2)                                                        # [b,rp]
+                self.perm.append(mult.long()[ridx])                                                   # [b,rp,na]: F_i[.., r, a] = F[.., r, perm[r, a]]
+
+
+def _dense_g(fc4, W, geo):
+    """G = W F over the referenced rows as the dense forward's stored operand: fc4 [b,c,rp,na] -> (g [b,o,ks,ld], ld or None).  The
+    small GEMM runs on the split-operand kernels where its shapes allow: its columns (row, anchor) padded to whole 128-column
+    tiles (the padding of F is zero, G's padded columns are skipped by the split that follows)."""
+    b, c, rp, na = fc4.shape
+    o, ks = W.shape[0], geo.ks
     ra = rp * na
     W3 = W.view(o, c, ks).permute(0, 2, 1).reshape(o * ks, c).contiguous()
     ld = _hip.dense_pitch(ra) if (c % 16 == 0 and c >= 16 and (o * ks) % 128 == 0) else ra
     if ld == ra:
-        fc = _hip.rows_gather(feats, rows, rp).view(b, c, ra)                     # [b,c,(r,a)]; empty slots: zeros
+        fc = fc4.reshape(b, c, ra)                                                  # [b,c,(r,a)]; empty slots: zeros
     else:
-        fc = torch.zeros(b, c, ld, dtype=torch.float32, device=feats.device)
-        fc[:, :, :ra] = _hip.rows_gather(feats, rows, rp).view(b, c, ra)
-    g = torch.empty(b, o * ks, ld, dtype=torch.float32, device=feats.device)
+        fc = torch.zeros(b, c, ld, dtype=torch.float32, device=fc4.device)
+        fc[:, :, :ra] = fc4.reshape(b, c, ra)
+    g = torch.empty(b, o * ks, ld, dtype=torch.float32, device=fc4.device)
     _hip.gemm(0, 0, o * ks, ld, c, W3, c, 0, fc, ld, c * ld, g, ld, o * ks * ld, b)
-    return _hip.so3_dense_fwd(g.view(b, o, ks, ld), geo, p, c, ldg=None if ld == ra else ld)
+    return g.view(b, o, ks, ld), (None if ld == ra else ld)
+
+
+def _dense_forward_parts(feats, W, rows, pd, p):
+    """the dense forward of posed clouds, one launch per part slot (see _PartsDense) -> y [b,o,p,a]"""
+    b, c, n, na = feats.shape
+    o = W.shape[0]
+    fc0 = _hip.rows_gather(feats, rows, pd.rp)                                      # [b,c,rp,na]
+    y = torch.empty(b, o, p, na, dtype=torch.float32, device=feats.device)
+    for i, geo in enumerate(pd.geo):
+        perm = pd.perm[i]
+        fc4 = fc0 if perm is None else fc0.gather(3, perm[:, None].expand(b, c, pd.rp, na))
+        g, ldg = _dense_g(fc4, W, geo)
+        _hip.so3_dense_fwd(g, geo, pd.parts.width[i], c, ldg=ldg, out=y, col_map=pd.parts.col_map[i])
+    return y
+
+
+def _dense_forward(feats, W, rows, geo, p):
+    """y [b,o,p,a] = sum_(k,r) G[o,(k,r),a] Wd[p,(k,r),a] with G = W F over the referenced rows (csrc/so3_dense.hip)."""
+    g, ldg = _dense_g(_hip.rows_gather(feats, rows, geo.rp), W, geo)
+    return _hip.so3_dense_fwd(g, geo, p, feats.shape[1], ldg=ldg)
 
 
 class _InterConv(torch.autograd.Function):
@@ -688,23 +821,34 @@ class _InterConv(torch.autograd.Function):
         # geometry = (q_xyz, xyz, q_rot, rot): what the dense product over the referenced rows is built from (csrc/so3_dense.hip);
         # whether the batch can take it is known on the host once the lists' first half has run -- one host wait per layer,
         # only for layers whose width fills the dense kernel's blocks
-        probe = None
+        probe = parts = None
         # (a folded inference epilogue does not stop it: the dense forward leaves `epilogue.applied` False and the caller runs the
         # norm as a pass of its own -- cheaper than giving up the dense product for the 128 -> 512 layer)
         if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0)
                 and _hip.so3_dense_supported(p, na, ks, 16, o)):
             probe = (geometry[2], geometry[3])
+            if (DENSE_PARTS and geometry[3] is not None and geometry[0] is geometry[1] and geometry[2] is geometry[3] and p == n):
+                parts = _pose_parts(geometry[3])           # (one host read per pose tensor)
+                if parts is not None:
+                    probe = ()                             # the rotations are accounted for per part: no "exactly the identity" requirement
+                    if parts.single:
+                        parts = None                       # one rotation per cloud: every relative rotation is the identity -- the plain product
         head = None
         if (lists_ok and needs_grad) or probe is not None:
             head = _ListHead(idx, n, nonident, gx, prefill=(not keep) and probe is None, dense_probe=probe)
         rp, dense_fwd = _dense_wanted(head, o, p, na, ks, idx.shape[2], n) if probe is not None else (0, False)
         ctx.dense = None
+        ctx.parts = parts if rp > 0 else None
         if rp > 0 and needs_grad:                         # (built by whoever needs it first: the forward below, or the backward)
             ctx.dense = [None, (geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)]
         if rp > 0 and dense_fwd:
             head.wait()
-            geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)
-            y = _dense_forward(feats, W, head.rows, geo, p)
+            if parts is None:
+                geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)
+                y = _dense_forward(feats, W, head.rows, geo, p)
+            else:
+                geo = _PartsDense(parts, geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows, mult, ctx.anchors)
+                y = _dense_forward_parts(feats, W, head.rows, geo, p)
             ctx.head = head if needs_grad else None
             if needs_grad:
                 ctx.dense[0] = geo
@@ -774,7 +918,13 @@ class _InterConv(torch.autograd.Function):
         if ctx.dense is not None:
             if ctx.dense[0] is None:                       # list-kernel forward, dense backward
                 head.wait()
-                ctx.dense[0] = _hip.DenseGeometry(*ctx.dense[1])
+                if ctx.parts is None:
+                    ctx.dense[0] = _hip.DenseGeometry(*ctx.dense[1])
+                else:
+                    a_ = ctx.dense[1]
+                    ctx.dense[0] = _PartsDense(ctx.parts, a_[1], a_[2], a_[3], a_[4], a_[5], a_[6], a_[7], a_[8], mult, ctx.anchors)
+            if ctx.parts is not None:
+                return _InterConv._backward_parts(ctx, gy, W, feats, head, ctx.dense[0]) + (None,) * 11
             geo = ctx.dense[0]
             if BACKWARD_LOG is not None:
                 BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(geo.rp), 'regime': 'dense rows'})
@@ -854,6 +1004,45 @@ class _InterConv(torch.autograd.Function):
                 _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
         return gF, gW, None, None, None, None, None, None, None, None, None, None, None
+
+
+    @staticmethod
+    def _backward_parts(ctx, gy, W, feats, head, pd):
+        """the dense backward of posed clouds, one product per part slot (_PartsDense): Z_i over the part's query points, the two small
+        GEMMs per part, the rows' anchor axis permuted back before the sum over the parts -> (gF, gW)"""
+        b, c, n, na = feats.shape
+        o, ks, rp = W.shape[0], pd.ks, pd.rp
+        ra = na * rp
+        if BACKWARD_LOG is not None:
+            BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(rp), 'regime': 'dense rows', 'parts': pd.parts.n})
+        need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ldz = _hip.dense_pitch(ra) if (c % 128 == 0 and (o * ks) % 16 == 0 and need_f) else ra
+        W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous() if need_f else None
+        fc0 = _hip.rows_gather(feats, head.rows, rp) if need_w else None                        # [b,c,rp,na]
+        gFr = gW = None
+        # (the row maxima the BatchNorm backward left are those of ALL points: an upper bound for every part's columns)
+        rowmax = _hip.take_rowmax_hint(gy)
+        for i, geo in enumerate(pd.geo):
+            perm = pd.perm[i]
+            z = _hip.so3_dense_bwd(gy, geo, ldz, colmap=pd.parts.col_map[i], rowmax=rowmax)      # [b,o,ks,ldz] rows = [na,rp]
+            pe = None if perm is None else perm[:, None].expand(b, c, rp, na)
+            if need_f:
+                gFc = torch.empty(b, c, ldz, dtype=torch.float32, device=gy.device)
+                _hip.gemm(0, 0, c, ldz, o * ks, W2, o * ks, 0, z, ldz, o * ks * ldz, gFc, ldz, c * ldz, b)
+                t = gFc[:, :, :ra].reshape(b, c, na, rp).transpose(2, 3)                          # [b,c,rp,na]: gradient of F_i[.., r, a] = F[.., r, perm[r, a]]
+                if gFr is None:
+                    gFr = torch.zeros(b, c, rp, na, dtype=torch.float32, device=gy.device)
+                if pe is None:
+                    gFr += t
+                else:
+                    gFr.scatter_add_(3, pe, t.contiguous())
+            if need_w:
+                fci = fc0 if pe is None else fc0.gather(3, pe)
+                gw = _weight_grad_from_z(z, fci.transpose(2, 3).contiguous().view(b, c, ra), b, c, o, ks, ra, ldz)
+                gW = gw if gW is None else gW + gw
+            del z
+        gF = _hip.rows_scatter(gFr, head.rows, n) if need_f else None
+        return gF, gW
 
 
 INTRA_DW_SLICE = 64      # channels whose 12-tap gather is materialised at a time for the intra weight gradient

@@ -341,16 +341,21 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *   eap_so3_dense_mask_words  uint64 words of the mask table of one direction; eap_so3_dense_masks fills it:
  *                             [b][64-column wave tile][k-step of 32][64 lanes] one bit per weight a lane of the product kernel generates
  *   eap_so3_dense_tables_f32  centre [b,4] (centroid of the support points), pt float4 [b, ceil32(p)] and
- *                             kr float4 [b, na, ceil32(ks rp)]: the two sides of the weight (centred coordinates), evaluated in float64
+ *                             kr float4 [b, na, ceil32(ks rp)]: the two sides of the weight (centred coordinates), evaluated in float64;
+ *                             row_rot (may be null) float [b, rows_ld, 9]: a rotation per row slot applied to the kernel offsets --
+ *                             the query points of ONE rigid part of a posed cloud (R_rel^T of so3conv/functional.py:L1112-1160)
  *   eap_so3_dense_split_f32   src [b,m,l,na] -> scale [2][b,na,m] (power of two per row; the second copy as [b,m,na]) and the two fp16 planes of the scaled
  *                             rows in the product kernel's fragment order: 4 b na m ceil32(l) bytes
  *                             (rowmax uint32 [b,m,na], may be null: the rows' largest magnitudes as float bit patterns when the producer
  *                             of src already has them, eap_bn_act_bwd_apply_rowmax_f32; seg > 0: a row's l elements come in segments of seg elements seg_pitch floats apart -- G as a GEMM with
- *                             padded columns leaves it)
+ *                             padded columns leaves it; colmap int32 [b,l], may be null: element i of a row is element colmap[b,i] of a source row of
+ *                             seg_pitch floats, negative = zero -- the columns of dY that are the query points of one rigid part)
  *   eap_so3_dense_product_f32 the product (planes / scale of dY [b,o,p,na] for dir 0, of G [b,o,ks rp,na] for dir 1); dir 0 writes
  *                             Z with ldz >= na rp floats between its (o, k) rows (padding for the GEMMs that follow, not written)
  *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na]; psum / psq (may be null) float [o, b ceil(p/64)]: partial sums of
- *                             y - y[0,o,0,0] and of its square, the moments of the BatchNorm that follows (eap_bn_stats_f32's pivot) */
+ *                             y - y[0,o,0,0] and of its square, the moments of the BatchNorm that follows (eap_bn_stats_f32's pivot)
+ *   eap_so3_dense_untranspose_map_f32   the same into a Y [b,o,p_dst,na] that several launches fill: column pp of cloud b is point
+ *                             map[b,pp] (int32 [b,p]; negative: padding, dropped) -- the rigid parts of posed clouds, one launch each */
 int eap_so3_dense_supported(int p, int na, int ks, int rp, int o);
 int eap_so3_dense_form(int form);
 int eap_so3_dense_member(int b, int p, int n, int nn, int rp, int rows_ld, const int32_t *idx, const int32_t *rows,
@@ -358,14 +363,16 @@ int eap_so3_dense_member(int b, int p, int n, int nn, int rp, int rows_ld, const
 int64_t eap_so3_dense_mask_words(int b, int p, int ks, int rp, int dir);
 int eap_so3_dense_masks(int b, int p, int ks, int rp, int dir, const uint32_t *memb, uint64_t *mask, eap_stream_t stream);
 int eap_so3_dense_tables_f32(int b, int p, int n, int na, int ks, int rp, int rows_ld, float sigma, const float *q_xyz,
-                             const float *s_xyz, const int32_t *rows, const float *rk, float *centre, float *pt, float *kr,
-                             eap_stream_t stream);
+                             const float *s_xyz, const int32_t *rows, const float *rk, const float *row_rot, float *centre, float *pt,
+                             float *kr, eap_stream_t stream);
 int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int64_t seg_pitch, int mapped, const int32_t *n_rows, const uint32_t *rowmax,
-                            const float *src, float *scale, void *planes, eap_stream_t stream);
+                            const int32_t *colmap, const float *src, float *scale, void *planes, eap_stream_t stream);
 int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows, const void *planes,
                               const float *scale,
                               const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream);
 int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, float *psum, float *psq, eap_stream_t stream);
+int eap_so3_dense_untranspose_map_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *yt, float *y,
+                                      eap_stream_t stream);
 
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 

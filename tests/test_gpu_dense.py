@@ -244,14 +244,70 @@ def test_clouds_the_dense_product_cannot_take_fall_back(dev, monkeypatch):
     r0 = _layer_run(dev, monkeypatch, 'off', xyz, None, feats0, W0, c, o, 0.05, 0.002)
     r1 = _layer_run(dev, monkeypatch, 'force', xyz, None, feats0, W0, c, o, 0.05, 0.002)
     assert r1[3][0]['regime'] != 'dense rows' and all(torch.equal(a, b) for a, b in zip(r0[:3], r1[:3]))
-    # (b) one rotated pose in the batch
+    # (b) more distinct pose rotations in a cloud than the per-part launches take (DENSE_MAX_PARTS)
     _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
     pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
-    a = 0.3
-    pose[1, 17, :3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0.], [np.sin(a), np.cos(a), 0.], [0., 0., 1.]], device=dev)
+    for j in range(L.DENSE_MAX_PARTS):
+        a = 0.3 + 0.1 * j
+        pose[1, 17 + 5 * j, :3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0.], [np.sin(a), np.cos(a), 0.], [0., 0., 1.]], device=dev)
     r0 = _layer_run(dev, monkeypatch, 'off', xyz, pose, feats0, W0, c, o, radius, sigma)
     r1 = _layer_run(dev, monkeypatch, 'force', xyz, pose, feats0, W0, c, o, radius, sigma)
     assert r1[3][0]['regime'] != 'dense rows' and all(torch.equal(a_, b_) for a_, b_ in zip(r0[:3], r1[:3]))
+
+
+def _quat_rot(rng, n):
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(n, 3, 3).astype(np.float32)
+
+
+@pytest.mark.parametrize('o,mode', [(256, 'force'), (128, 'auto')])
+def test_one_rotation_per_rigid_part_runs_the_dense_product_per_part(dev, monkeypatch, o, mode):
+    """Articulated input: every point carries the rotation of its rigid part (2 parts in one cloud, 3 of very different sizes in
+    another, 1 in the third; arbitrary rotations, so the relative rotation across a joint rotates the offsets AND selects a real
+    anchor permutation: so3conv/functional.py:L1112-1160).  The dense product runs once per part slot (vgtk/so3conv/functional.py
+    _PartsDense); y, dF, dW against the permuted list kernels (pinned by inter_pose_artmode.npz / inter_pose_perm.npz) to the bars
+    of the identity-pose comparison.  O = 128: list-kernel forward (bit-equal), per-part dense backward."""
+    import synth_clouds
+    import vgtk.so3conv.functional as L
+    B, P, c = 3, 512, 32
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    xyz_np, lab_np, _ = synth_clouds.laptop_batch(81, B, P)
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    rng = np.random.default_rng(5)
+    R = _quat_rot(rng, 6)
+    part = np.zeros((B, P), np.int64)
+    part[0] = lab_np[0] % 2                                        # the cloud's own two rigid parts
+    part[1] = lab_np[1] % 2
+    part[1, 100:117] = 2                                           # a third, tiny part
+    pose_np = np.tile(np.eye(4, dtype=np.float32), (B, P, 1, 1))
+    pose_np[0, :, :3, :3] = R[0:2][part[0]]
+    pose_np[1, :, :3, :3] = R[2:5][part[1]]
+    pose_np[2, :, :3, :3] = R[5]                                   # one rotation for the whole cloud
+    pose = torch.from_numpy(pose_np).to(dev)
+    parts = L._pose_parts(pose)
+    assert parts is not None and parts.n == 3 and sorted(parts.sizes[1]) == sorted(np.bincount(part[1]).tolist()) and parts.sizes[2][1:] == [0, 0]
+    gen = torch.Generator(device=dev).manual_seed(23)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    y0, gF0, gW0, log0, _ = _layer_run(dev, monkeypatch, 'off', xyz, pose, feats0, W0, c, o, radius, sigma)
+    y1, gF1, gW1, log1, y1n = _layer_run(dev, monkeypatch, mode, xyz, pose, feats0, W0, c, o, radius, sigma)
+    assert [r['regime'] for r in log1] == ['dense rows'] and log1[0].get('parts') == 3 and log0[0]['regime'] != 'dense rows'
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    if o == 128:
+        assert torch.equal(y1, y0)
+    else:
+        assert rel(y1, y0) < 2e-5 and torch.equal(y1n, y1)
+    assert rel(gF1, gF0) < 2e-5 and rel(gW1, gW0) < 5e-5
+    # the same rotation everywhere in every cloud: relative rotations are the identity -- the plain product, no part launches
+    pose_one = torch.from_numpy(np.tile(np.eye(4, dtype=np.float32), (B, P, 1, 1))).to(dev)
+    pose_one[:, :, :3, :3] = torch.from_numpy(R[:3]).to(dev)[:, None]
+    y2, gF2, gW2, log2, _ = _layer_run(dev, monkeypatch, mode, xyz, pose_one, feats0, W0, c, o, radius, sigma)
+    y3, gF3, gW3, _, _ = _layer_run(dev, monkeypatch, 'off', xyz, pose_one, feats0, W0, c, o, radius, sigma)
+    assert log2[0]['regime'] == 'dense rows' and 'parts' not in log2[0]
+    assert rel(y2, y3) < 2e-5 and rel(gF2, gF3) < 2e-5 and rel(gW2, gW3) < 5e-5
 
 
 def test_narrow_layer_takes_the_dense_backward_only(dev, monkeypatch):
