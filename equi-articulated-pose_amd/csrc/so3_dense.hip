@@ -454,6 +454,7 @@ struct KcArgs {
     const int32_t *n_rows; int ks, trim;  // referenced rows per cloud; trim 1: the columns are dense indices cut at the cloud's prefix (backward), 3: not cut,
                                           // 2: the k axis is cut at the cloud's prefix (forward), 0: not cut
     float *C; long long cB, cA, ldm; int rp; long long kstride;     // element (row, n) of (b, a) at C[b cB + a cA + row ldm + (n / rp) kstride + n % rp]
+    int row_slots;                        // row slots of the dense index range (the launcher's rp; `rp` above is the output's column split)
 };
 
 // DBG (timing ablations, `make ABLATION=1` + EAP_DENSE_DEBUG, WRONG results): 1 = no mask (all lanes kept), 2 = no k-side table
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     const int bm = local % g.tiles_m, bn = local / g.tiles_m;
     const int b = z / g.na, a = z - b * g.na;
     // this cloud's prefix of the dense index range (see dense_kr): whole 16-row groups of its own referenced rows
-    const int used = (g.trim == 1 || g.trim == 2) ? ((min(g.n_rows[b], g.rp) + 15) & ~15) * g.ks : 0;      // (trim 3 / 0: dense indices, every slot)
+    const int used = (g.trim == 1 || g.trim == 2) ? ((min(g.n_rows[b], g.row_slots) + 15) & ~15) * g.ks : 0;      // (trim 3 / 0: dense indices, every slot)
     const int N = g.trim == 1 ? min(g.N, used) : g.N;
     const int KS = g.trim == 2 ? max(min(g.KS, used / KC_BK), 1) : g.KS;
     if (256 * bn >= N) return;                             // (block-uniform, before any barrier)
@@ -842,7 +843,7 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     if (!eap_so3_dense_supported(p, na, ks, rp, o)) return eap::bad_arg("so3_dense_product: shape not taken (eap_so3_dense_supported)");
     const int p_pad = ceil_to(p, KC_BK), kd_pad = ceil_to(ks * rp, KC_BK);
     KcArgs g;
-    g.MT = o / 32; g.na = na; g.zcount = b * na;
+    g.MT = o / 32; g.na = na; g.zcount = b * na; g.row_slots = rp;
     g.N = dir ? p : ks * rp;
     g.KS = (dir ? kd_pad : p) / KC_BK;
     const bool wide = (o % 256) == 0;                     // 256-row blocks; else 128-row blocks (half the matrix work per generated weight)

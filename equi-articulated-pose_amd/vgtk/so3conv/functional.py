@@ -652,8 +652,7 @@ _POSE_PARTS = {}            # (storage pointer, version, shape) of a pose tensor
 
 class _PoseParts:
     """The points of every cloud grouped by their pose rotation (bit-equal 3x3 blocks): part slots 0 .. n-1 per cloud, largest part
-    first; slot i of the batch is one launch over pts[i] int64 [b, p_i] (p_i = the largest part i of any cloud rounded to the product
-    kernel's 256-column blocks;
+    first; slot i of the batch is one launch over pts[i] int64 [b, p_i] (p_i = the largest part i of any cloud rounded to 32;
     entries past a cloud's own part size repeat a valid point and are marked in col_map[i] int32 [b, p_i] = -1)."""
 
     def __init__(self, labels, reps, sizes, p):
@@ -665,7 +664,7 @@ class _PoseParts:
         self.pts, self.col_map, self.width = [], [], []
         start = [0] * b
         for i in range(self.n):
-            width = (max(sizes[bi][i] for bi in range(b)) + 255) // 256 * 256
+            width = (max(sizes[bi][i] for bi in range(b)) + 31) // 32 * 32
             st = torch.tensor(start, dtype=torch.int64, device=dev)[:, None]
             sz = torch.tensor([sizes[bi][i] for bi in range(b)], dtype=torch.int64, device=dev)[:, None]
             t = torch.arange(width, dtype=torch.int64, device=dev)[None, :]

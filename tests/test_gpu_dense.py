@@ -102,7 +102,7 @@ def test_split_planes_reconstruct_the_operand(dev):
     assert float(scale[0, :, 3].min()) == 1.0 and float(scale[0, :, 3].max()) == 1.0       # an all-zero row
 
 
-@pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1)])
+@pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1), (288, 2)])
 def test_generated_weights_and_backward_product(dev, P, layer):
     """Z[b,o,k,a,r] = sum_p dY[b,o,p,a] Wd[p,(k,r),a]: with dY = one-hot rows the product IS the generated operand -> the bar on
     the weights; with random dY against the float64 sum."""
@@ -160,7 +160,7 @@ def test_backward_product_matches_the_list_kernel(dev):
     assert torch.equal(zp[..., :NA * rp].reshape(2, 256, KS, NA, rp), z) and float((zp[..., NA * rp:] - 7.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1)])
+@pytest.mark.parametrize('P,layer', [(512, 2), (1024, 1), (288, 2)])
 def test_forward_product(dev, P, layer):
     """Yt[b,a,o,p] = sum_(k,r) G[b,o,(k,r),a] Wd[p,(k,r),a] against the float64 sum, and back in the reference layout."""
     from vgtk import _hip
@@ -182,6 +182,34 @@ def test_forward_product(dev, P, layer):
     magm = torch.einsum('bokra,bpr->bopa', g.double().abs(), _member(s, head.rows, rp))
     assert float(((y.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
     assert torch.equal(y, _hip.so3_dense_fwd(g.view(B, o, KS, rp * NA), geo, P))
+
+
+@pytest.mark.parametrize('pq', [32, 64, 96, 224, 320])
+def test_products_over_few_query_points(dev, pq):
+    """Query points = the first pq points of a 512-point cloud (a rigid part's launch, a strided layer): fewer columns than one
+    256-column block of the forward product / fewer than eight k-steps of the backward's, and FEWER QUERY POINTS THAN REFERENCED
+    ROWS (the forward once cut its row range at the point count), against the float64 sums."""
+    from vgtk import _hip
+    s = _setup(dev, 2, 512, layer=2)
+    head, _, rp = _geometry(s, dev)
+    xyz = s['xyz']
+    geo = _hip.DenseGeometry(xyz[:, :, :pq].contiguous(), xyz, head.memb[:, :pq].contiguous(), head.rows, rp, s['rk'], s['sigma'], NN, head.n_rows)
+    B, o = 2, 256
+    wd = _dense_weights64(s, head.rows, rp)[:, :pq]                           # [B,pq,rp,A,K]
+    memb = _member(s, head.rows, rp)[:, :pq]
+    gen = torch.Generator(device=dev).manual_seed(29)
+    g = torch.randn(B, o, KS, rp, NA, device=dev, generator=gen)
+    y = _hip.so3_dense_fwd(g.view(B, o, KS, rp * NA), geo, pq)
+    ref = torch.einsum('bokra,bprak->bopa', g.double(), wd)
+    mag = torch.einsum('bokra,bprak->bopa', g.double().abs(), wd)
+    magm = torch.einsum('bokra,bpr->bopa', g.double().abs(), memb)
+    assert float(((y.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
+    gy = torch.randn(B, o, pq, NA, device=dev, generator=gen)
+    z = _hip.so3_dense_bwd(gy, geo).view(B, o, KS, NA, rp)
+    ref = torch.einsum('bopa,bprak->bokar', gy.double(), wd)
+    mag = torch.einsum('bopa,bprak->bokar', gy.double().abs(), wd)
+    magm = torch.einsum('bopa,bpr->boar', gy.double().abs(), memb)[:, :, None]
+    assert float(((z.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm).clamp(min=1e-30)).max()) < 1.0
 
 
 def _layer_run(dev, monkeypatch, mode, xyz, pose, feats0, W0, c, o, radius, sigma):
