@@ -137,6 +137,16 @@ def test_4096_layers_mixed_poses(dev, monkeypatch, layer, mode):
                [(0, 64), (1, 2048), (2, 4032)], q=32)
 
 
+# ---- articulated input: one rotation per rigid part -> the dense product, one launch per part (vgtk/so3conv/functional.py
+#      _PartsDense: row rotations in the k-side table, per-row anchor permutation of the stored operand), straight against the oracle
+@pytest.mark.parametrize('layer', [1, 2])
+def test_4096_layers_one_rotation_per_rigid_part(dev, monkeypatch, layer):
+    import vgtk.so3conv.functional as L
+    monkeypatch.setattr(L, 'BACKWARD_LOG', [])
+    slab_check(dev, monkeypatch, 4096, layer, ['parts', 'identity', 'parts'], 'inverse', [(0, 64), (1, 2048), (2, 4032)], q=32)
+    assert [r['regime'] for r in L.BACKWARD_LOG] == ['dense rows'] and L.BACKWARD_LOG[0].get('parts') == 2
+
+
 # ---- config 4: 16 clouds of 4096 points per GPU --------------------------------------------------------
 def test_4096_batch16_deepest_layer(dev, monkeypatch):
     slab_check(dev, monkeypatch, 4096, 2, ['identity'] * 16, 'auto', [(0, 0), (15, 4032)], seed=60)
