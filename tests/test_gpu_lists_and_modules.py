@@ -1142,6 +1142,7 @@ def test_permuted_clouds_on_the_two_tile_kernel(dev, monkeypatch, kind):
     from vgtk import _hip
     torch.manual_seed(5)
     monkeypatch.setattr(L, 'BACKWARD_MODE', 'inverse')          # the re-associated backward whatever the number of referenced rows
+    monkeypatch.setattr(L, 'DENSE_MODE', 'off')                 # (one rotation per rigid part would take the per-part dense product: this test is about the list kernels)
     B, P, c, o = 3, 640, 64, 128
     xyz, lab, pose = synth_clouds.laptop_batch(11, B, P)
     rng = np.random.default_rng(4)
