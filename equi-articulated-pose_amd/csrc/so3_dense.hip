@@ -344,11 +344,14 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
             int sg = l0 / seg, sr = l0 - sg * seg;                // segment and position of element l0 + e
             if (mapped) dense_kr(l0, nseg, sg, sr);               // (8 consecutive dense indices: one kernel point, 8 consecutive slots)
             if (colmap != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ci = (l0 + e < l) ? colmap[(size_t)b * l + l0 + e] : -1;
-                    q[u][e] = ci >= 0 ? src[(size_t)ci * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                // (l is a multiple of 8 here -- the launcher checks -- so the 8 map entries are two aligned 16-byte words)
+                int ci[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+                if (l0 < l) {
+                    const int4 c0 = *reinterpret_cast<const int4 *>(colmap + (size_t)b * l + l0), c1 = *reinterpret_cast<const int4 *>(colmap + (size_t)b * l + l0 + 4);
+                    ci[0] = c0.x; ci[1] = c0.y; ci[2] = c0.z; ci[3] = c0.w; ci[4] = c1.x; ci[5] = c1.y; ci[6] = c1.z; ci[7] = c1.w;
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[u][e] = ci[e] >= 0 ? src[(size_t)ci[e] * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -815,7 +818,8 @@ extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int
                                        const int32_t *colmap, const float *src, float *scale, void *planes, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (colmap != nullptr) {
-        if (mapped || seg_pitch <= 0) return eap::bad_arg("so3_dense_split: a column map comes with the source row pitch and without the dense-index mapping");
+        if (mapped || seg_pitch <= 0 || (l & 7) != 0 || (reinterpret_cast<uintptr_t>(colmap) & 15) != 0)
+            return eap::bad_arg("so3_dense_split: a column map (16-byte aligned, a multiple of 8 columns) comes with the source row pitch and without the dense-index mapping");
         seg = l;
     }
     if (seg <= 0) { seg = l; seg_pitch = (int64_t)l * na; }
