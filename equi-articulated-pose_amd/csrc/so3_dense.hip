@@ -464,7 +464,7 @@ struct KcArgs {
 // reads (constants), 4 = no weight evaluation at all (the B fragments of the prologue for every k-block), 8 = no DMA inside the k-loop,
 // 16 = no fragment reads of the stored operand inside the k-loop
 template <int MI, int FORM, int DBG = 0>
-__global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
+__global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g) {
     static_assert(MI == 8 || MI == 4, "the DMA piece schedule below: 8 or 4 KB of the stored operand per wave and k-step");
     constexpr unsigned WB = MI * 1024u;                    // bytes of the stored operand a wave moves per k-step
     constexpr unsigned SUB_A = MI * 2048u;                 // bytes of the stored operand per k-block (16 k) of a block
@@ -558,6 +558,12 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // LEAN (the 128-row variant): 256 registers, so that TWO workgroups share a CU (72 KB of LDS each) and one wave's matrix
+    // instructions run in the shadow of the other's reads and barriers -- the k-side entries without their unused fourth component and
+    // for ONE k-block at a time (read at the end of the k-block that consumed the previous ones)
+    constexpr bool LEAN = MI == 4;
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    using SV = std::conditional_t<(LEAN && FORM == 1), f32x3, f32x4>;
     // B operand of one k-block: [tile j][plane] 8 halves per lane
     struct BFrag { u32x4 h[2], l[2]; };
     auto frag_a = [&](const unsigned char *st, int sub, int plane, u32x4 (&f)[MI]) __attribute__((always_inline)) {
@@ -572,12 +578,12 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     };
     // weights of tile j, elements e0, e0 + 1 of a k-block (k-side entries sv[e]; mask bits 16 tb + 8 j + e of mb) -> word e0 / 2 of h, l.
     // The mask is the fma's addend: 1.0 for a list member, 0.0 otherwise -- the clamp then returns 0 (the product term is <= 0).
-    auto gen2 = [&](const f32x4 (&sv)[8], unsigned mb, int tb, int j, int e0, BFrag &f, bool prologue = false) __attribute__((always_inline)) {
+    auto gen2 = [&](const SV (&sv)[8], unsigned mb, int tb, int j, int e0, BFrag &f, bool prologue = false) __attribute__((always_inline)) {
         if ((DBG & 4) && !prologue) return;
         float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const f32x4 s = sv[e0 + e];
+            const SV s = sv[e0 + e];
             const int keep = (DBG & 1) ? -1 : ((int)(mb << (31 - (16 * tb + 8 * j + e0 + e))) >> 31);
             const float one = __int_as_float(keep & 0x3f800000);
             if constexpr (FORM == 1) {
@@ -594,9 +600,12 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
         f.h[j][e0 / 2] = h;
         f.l[j][e0 / 2] = l;
     };
-    auto load_sv = [&](const f32x4 *str, f32x4 (&sv)[8]) __attribute__((always_inline)) {
+    auto load_sv = [&](const f32x4 *str, SV (&sv)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = (DBG & 2) ? (f32x4){0.01f * (float)e, 0.02f, 0.03f * (float)kg, 0.f} : str[8 * kg + e];
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (DBG & 2) sv[e] = SV{0.01f * (float)e, 0.02f, 0.03f * (float)kg};
+            else sv[e] = *reinterpret_cast<const SV *>(str + 8 * kg + e);
+        }
     };
     auto mm = [&](const u32x4 &fa, const u32x4 &fb, f32x16 &c) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), c, 0, 0, 0);
@@ -616,19 +625,19 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     // the k-side entries of k-block u + 2 (`nsv`) are read at the head of the first product, the first plane of A(u + 1) between
     // the second and the third -- no LDS read is waited for less than a product after its issue.
     auto kblock = [&](const unsigned char *st, int sub, const unsigned char *nst, int nsub, const f32x4 *nnstr, unsigned mb, int tb,
-                      const BFrag &Bc, BFrag &Bn, u32x4 (&ah)[MI], const f32x4 (&sv)[8], f32x4 (&nsv)[8], auto dma) __attribute__((always_inline)) {
+                      const BFrag &Bc, BFrag &Bn, u32x4 (&ah)[MI], const SV (&sv)[8], SV (&nsv)[8], auto dma) __attribute__((always_inline)) {
         u32x4 al[MI];
         // vector instructions per matrix instruction of the three products (MI = 4: half the matrix work per generated weight --
         // the kernel is bound by the weight evaluation there) and LDS reads behind the first / second MI matrix instructions
         constexpr int NV1 = (MI == 8 ? 3 : 6) + (FORM ? 1 : 0), NV3 = (MI == 8 ? 2 : 4) + (FORM ? 1 : 0);
         SB();
         frag_loop(st, sub, 1, al);
-        load_sv(nnstr, nsv);
+        if constexpr (!LEAN) load_sv(nnstr, nsv);
         dma(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i) { mm(ah[i], Bc.h[0], acc[i][0]); mm(ah[i], Bc.h[1], acc[i][1]); }
         gen2(sv, mb, tb, 0, 0, Bn); gen2(sv, mb, tb, 0, 2, Bn); gen2(sv, mb, tb, 0, 4, Bn);
-        PIPE(NV1, (MI == 8 ? 1 : 2), 1)      // the MI + 8 LDS reads behind the matrix instructions
+        if constexpr (LEAN) { PIPE(NV1, 1, 0) } else { PIPE(NV1, (MI == 8 ? 1 : 2), 1) }     // the MI (+ 8) LDS reads behind the matrix instructions
         SB();
         dma(1);
 #pragma unroll
@@ -643,6 +652,7 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
         gen2(sv, mb, tb, 1, 4, Bn); gen2(sv, mb, tb, 1, 6, Bn);
         PIPE(NV3, 1, 0)                      // the next k-block's MI fragment reads behind the first MI matrix instructions
         SB();
+        if constexpr (LEAN) { load_sv(nnstr, nsv); SB(); }      // (nsv IS sv here: after its last use)
     };
 
     // ---- prologue: stages 0, 1, 2 <- k-steps 0, 1, 2 (past the last step: the last step again, into a stage nobody reads) ----
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
     // around the k-blocks would put the 256 accumulators across a control-flow join)
     BFrag B0, B1;
     u32x4 ah[MI];
-    f32x4 sv[8], sw[8];
+    SV sv[8], sw[8];              // (LEAN: sw unused)
     unsigned mbc = *reinterpret_cast<const unsigned *>(smem + BIT_OFF + (unsigned)t * 4u);        // mask bits of step 0
     {
         load_sv(reinterpret_cast<const f32x4 *>(smem + STR_OFF), sv);
@@ -684,12 +694,12 @@ __global__ __launch_bounds__(256, 1) void kc_gemm_kernel(KcArgs g) {
         const f32x4 *str1 = reinterpret_cast<const f32x4 *>(smem + s1 + STR_OFF);
         // k-block 2s: generates k-block 2s + 1 (sv = its k-side entries, mask bits 16..31 of this step's dword); reads the entries of
         // k-block 2s + 2 (first slice of the next stage) for the next call
-        kblock(smem + s0, 0, smem + s0, 1, str1, mbc, 1, B0, B1, ah, sv, sw, [&](int slot) __attribute__((always_inline)) {
+        kblock(smem + s0, 0, smem + s0, 1, str1, mbc, 1, B0, B1, ah, sv, LEAN ? sv : sw, [&](int slot) __attribute__((always_inline)) {
             if constexpr (!(DBG & 8)) dma_slot(nxt, dst, slot);
         });
         // k-block 2s + 1: generates k-block 2s + 2 (mask bits 0..15 of the NEXT step's dword); reads the entries of k-block 2s + 3
         // (past the end: stale data nobody uses)
-        kblock(smem + s0, 1, smem + s1, 0, str1 + 16, mbn, 0, B1, B0, ah, sw, sv, [&](int slot) __attribute__((always_inline)) {
+        kblock(smem + s0, 1, smem + s1, 0, str1 + 16, mbn, 0, B1, B0, ah, LEAN ? sv : sw, sv, [&](int slot) __attribute__((always_inline)) {
             if constexpr (!(DBG & 8)) dma_slot(nxt, dst, 3 + slot);
         });
         mbc = mbn;
@@ -745,6 +755,7 @@ int kc_launch(const KcArgs &g, hipStream_t s) {
 }
 
 int g_dense_form = 1;
+int g_dense_rows = 0;       // 0: 256-row blocks where o % 256 == 0, else 128; 128: always 128-row blocks (A/B runs)
 
 inline int ceil_to(int v, int q) { return (v + q - 1) / q * q; }
 
@@ -752,6 +763,13 @@ inline int ceil_to(int v, int q) { return (v + q - 1) / q * q; }
 
 // 1 (default): the weights from the squared distance; 0: from the expanded square (see the head of this file).  The tables and the
 // product of one layer must be built under the same setting.  -> the previous setting
+// rows per workgroup of the product: 0 = 256 where the width allows (default), 128 = always 128 (two workgroups per CU); -> old setting
+extern "C" int eap_so3_dense_block_rows(int rows) {
+    const int old = g_dense_rows;
+    if (rows == 0 || rows == 128) g_dense_rows = rows;
+    return old;
+}
+
 extern "C" int eap_so3_dense_form(int form) {
     const int old = g_dense_form;
     if (form == 0 || form == 1) g_dense_form = form;
@@ -850,7 +868,7 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     g.MT = o / 32; g.na = na; g.zcount = b * na; g.row_slots = rp;
     g.N = dir ? p : ks * rp;
     g.KS = (dir ? kd_pad : p) / KC_BK;
-    const bool wide = (o % 256) == 0;                     // 256-row blocks; else 128-row blocks (half the matrix work per generated weight)
+    const bool wide = (o % 256) == 0 && g_dense_rows != 128;     // 256-row blocks; else 128-row blocks (half the matrix work per generated weight, two workgroups per CU)
     g.tiles_m = wide ? o / 256 : o / 128;
     g.blocks_n = (g.N + 255) / 256;
     g.mask_tiles = 4 * g.blocks_n;

@@ -358,6 +358,7 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *                             map[b,pp] (int32 [b,p]; negative: padding, dropped) -- the rigid parts of posed clouds, one launch each */
 int eap_so3_dense_supported(int p, int na, int ks, int rp, int o);
 int eap_so3_dense_form(int form);
+int eap_so3_dense_block_rows(int rows);      /* 0 (default): 256-row blocks where o % 256 == 0; 128: always 128-row blocks; -> old setting */
 int eap_so3_dense_member(int b, int p, int n, int nn, int rp, int rows_ld, const int32_t *idx, const int32_t *rows,
                          const int32_t *n_rows, int32_t *slot_of, uint32_t *memb, int32_t *flags, eap_stream_t stream);
 int64_t eap_so3_dense_mask_words(int b, int p, int ks, int rp, int dir);

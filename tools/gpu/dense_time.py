@@ -38,6 +38,7 @@ def timed(fn, n=int(os.environ.get('REPS', 5))):
 
 gen = torch.Generator(device=dev).manual_seed(1)
 TRIM = os.environ.get('TRIM', '1') != '0'
+_hip.lib.eap_so3_dense_block_rows(int(os.environ.get('ROWS', 0)))
 gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
 g = torch.randn(B, o, KS, rp * NA, device=dev, generator=gen)
 for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
