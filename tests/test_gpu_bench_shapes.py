@@ -56,6 +56,10 @@ def make_poses(gen, kinds, labels, p):
         elif kind == 'parts':
             R = _rand_rot(gen, 2)
             pose[b, :, :3, :3] = R[torch.from_numpy(labels[b])]
+        elif kind == 'parts4':                       # four rigid parts of very different sizes: each of the two labels split 7 : 1 by index
+            R = _rand_rot(gen, 4)
+            lab4 = 2 * torch.from_numpy(labels[b]) + (torch.arange(p) % 8 == 0).long()
+            pose[b, :, :3, :3] = R[lab4]
     return pose
 
 
@@ -145,6 +149,14 @@ def test_4096_layers_one_rotation_per_rigid_part(dev, monkeypatch, layer):
     monkeypatch.setattr(L, 'BACKWARD_LOG', [])
     slab_check(dev, monkeypatch, 4096, layer, ['parts', 'identity', 'parts'], 'inverse', [(0, 64), (1, 2048), (2, 4032)], q=32)
     assert [r['regime'] for r in L.BACKWARD_LOG] == ['dense rows'] and L.BACKWARD_LOG[0].get('parts') == 2
+
+
+def test_4096_deepest_layer_four_rigid_parts(dev, monkeypatch):
+    """four parts per cloud (sizes ~ 7 : 1 : 7 : 1), three clouds: four launches of the product per direction, against the oracle"""
+    import vgtk.so3conv.functional as L
+    monkeypatch.setattr(L, 'BACKWARD_LOG', [])
+    slab_check(dev, monkeypatch, 4096, 2, ['parts4', 'parts4', 'parts'], 'inverse', [(0, 64), (1, 2048), (2, 4032)], q=32)
+    assert [r['regime'] for r in L.BACKWARD_LOG] == ['dense rows'] and L.BACKWARD_LOG[0].get('parts') == 4
 
 
 # ---- config 4: 16 clouds of 4096 points per GPU --------------------------------------------------------
