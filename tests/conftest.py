@@ -29,3 +29,21 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _drain_gpu_between_tests(request):
+    """GPU tests only: every test starts and ends on an idle device with the allocator's cache returned (the suite's largest tests
+    hold 50 - 90 GB: they should not depend on what the tests before them left cached)."""
+    if request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+    yield
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()

