@@ -10,6 +10,7 @@ print('articulated', r['value'], r['ms_per_step'])
 P
 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o p --output-format csv -- python /tmp/art.py 2>&1 | grep articulated
 f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1)
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out && cp $f $GRAFT_REPO_ROOT/gpurun_out/articulated_kernel_stats.csv
 python - "$f" <<'P'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
