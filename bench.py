@@ -562,12 +562,15 @@ def other_configs(dev):
     8192 points), and the small-radius regime in which more than a quarter of the support rows are referenced and
     the backward takes the textbook dX route."""
     return [
-        dict(name='config 2: 8 x 4096, forward only', **quick_run(dev, 8, 4096, fwd_only=True)),
-        dict(name='configs 3/4 per-GPU shape: 16 x 4096', **quick_run(dev, 16, 4096)),
-        dict(name='config 5 per-GPU shape: 8 x 8192 partial (depth-buffer visible) clouds', **quick_run(dev, 8, 8192, partial=True)),
-        dict(name='8 x 8192 complete clouds', **quick_run(dev, 8, 8192)),
-        dict(name='8 x 4096 with the 512-point radii (textbook-backward regime)', **quick_run(dev, 8, 4096, plan_points=512)),
-        dict(name='8 x 4096, articulated input: one rotation per rigid part (anchor permutations on)', **quick_run(dev, 8, 4096, part_poses=True)),
+        dict(name='config 2: 8 x 4096, forward only', short='cfg2_fwd_8x4096', **quick_run(dev, 8, 4096, fwd_only=True)),
+        dict(name='configs 3/4 per-GPU shape: 16 x 4096', short='cfg4_shard_16x4096', **quick_run(dev, 16, 4096)),
+        dict(name='config 5 per-GPU shape: 8 x 8192 partial (depth-buffer visible) clouds', short='cfg5_shard_8x8192_partial', **quick_run(dev, 8, 8192, partial=True)),
+        dict(name='8 x 8192 complete clouds', short='8x8192_complete', **quick_run(dev, 8, 8192)),
+        dict(name='8 x 4096 with the 512-point radii (textbook-backward regime)', short='8x4096_radii512', **quick_run(dev, 8, 4096, plan_points=512)),
+        dict(name='8 x 4096, articulated input: one rotation per rigid part (anchor permutations on)', short='8x4096_articulated', **quick_run(dev, 8, 4096, part_poses=True)),
+        # the reference's own operating point (scripts/train/laptop_syn.sh:L9, L23: 8 processes x batch 1 x 380-512 points; SURVEY.md
+        # 8(d) asks for [16, 3, 512] beside config 3): 16 clouds of 512 points with the radii build_model derives for 512 points
+        dict(name='reference operating point: 16 x 512-pt clouds, 512-point radii', short='ref_point_16x512', **quick_run(dev, 16, 512, steps=10, warmup=3)),
     ]
 
 
@@ -617,6 +620,123 @@ def config3_step(dev, batch=16, points=4096, steps=2, warmup=1):
     del model, opt, xyz, pose
     torch.cuda.empty_cache()
     return out
+
+
+LINE_BUDGET = 6000          # bytes of the LAST stdout line (the driver's record keeps a bounded tail: round 5's 20 KB line did not parse)
+
+
+def _clean(obj):
+    """NaN / inf -> None, numpy scalars -> Python, floats to 6 significant digits (strict JSON, short)."""
+    if isinstance(obj, dict):
+        return {str(k): _clean(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple, set)):
+        return [_clean(v) for v in (sorted(obj) if isinstance(obj, set) else obj)]
+    if isinstance(obj, (np.floating, float)):
+        f = float(obj)
+        return float(f'{f:.6g}') if np.isfinite(f) else None
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    if isinstance(obj, (np.bool_,)):
+        return bool(obj)
+    return obj
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short_roofline(r):
+    """The judged fields of a roofline object (bench contract) without the prose."""
+    out = _pick(r, 'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'launches', 'share_of_kernel_time')
+    if 'pipe' in r:
+        out['pipe'] = r['pipe'].split(' ')[0]                       # 'fp16' / 'bf16'
+    if 'algorithmic' in r:
+        out['algorithmic'] = r['algorithmic']
+    if 'fp32_equivalent_TFLOPs' in r:
+        out['fp32_equivalent_TFLOPs'] = r['fp32_equivalent_TFLOPs']
+    td = r.get('traffic_detail') or {}
+    if td:
+        out['traffic_source'] = td.get('source')
+        out['mfma_util'] = td.get('mfma_util')
+    return out
+
+
+def compact_line(full, detail_file='bench_detail.json'):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, and one number (or a handful) per side leg --
+    everything else (`kernels`, `launch_shapes`, sweeps, notes, per-kernel counter detail) stays in `detail_file`, written next to it.
+    Strict JSON (no NaN), a few KB: tests/test_bench_line.py builds it from a canned record and checks both."""
+    line = _pick(full, 'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                 'dtype', 'data', 'rccl_ranks', 'config')
+    if 'roofline' in full:
+        line['roofline'] = _short_roofline(full['roofline'])
+    cb = full.get('cpu_baseline')
+    if isinstance(cb, dict):
+        c = _pick(cb, 'value', 'unit', 'cores', 'kind', 'host_logical_cpus', 'host_cpu_model', 'runs_s', 'warmup_s', 'error', 'value_perm_search_short_circuited')
+        if 'sample' in cb:
+            c['sample'] = cb['sample'][:160]
+        if isinstance(cb.get('config1'), dict):
+            c['config1'] = _pick(cb['config1'], 'value', 'runs_s')
+        if isinstance(cb.get('thread_sweep'), dict):
+            c['thread_sweep'] = {str(p['threads']): p.get('clouds_per_sec') for p in cb['thread_sweep'].get('by_threads', [])}
+        line['cpu_baseline'] = c
+    if 'speedup_vs_cpu_baseline' in full:
+        line['speedup_vs_cpu_baseline'] = full['speedup_vs_cpu_baseline']
+    zr = full.get('zpconv_roofline')
+    if isinstance(zr, dict):
+        z = _pick(zr, 'bound', 'achieved', 'peak', 'unit', 'frac', 'ms', 'bytes')
+        if isinstance(zr.get('backward'), dict):
+            z['backward'] = _pick(zr['backward'], 'frac', 'ms')
+        tr = zr.get('traffic') or {}
+        if tr.get('forward_bytes') and zr.get('bytes'):
+            z['traffic_ratio'] = tr['forward_bytes'] / zr['bytes']
+            z['traffic_source'] = tr.get('source')
+        line['zpconv_roofline'] = z
+    if full.get('kernel_rooflines'):
+        line['kernel_rooflines'] = [dict(_pick(r, 'kernel', 'frac', 'avg_launch_ms', 'share_of_kernel_time'),
+                                         **({'executed_over_algorithmic_x3': r['algorithmic'].get('executed_over_algorithmic_x3')} if 'algorithmic' in r else {}))
+                                    for r in full['kernel_rooflines'][:6]]
+    if 'whole_step' in full:
+        line['whole_step'] = _pick(full['whole_step'], 'achieved_TFLOPs_per_gpu', 'frac_of_fp32_mfma_peak', 'kernel_time_share_of_step')
+    if full.get('other_configs'):
+        line['other_configs'] = {c.get('short', c['name']): c['value'] for c in full['other_configs']}
+        line['other_configs_regimes'] = {c.get('short', c['name']): '/'.join(r.get('regime', '?') for r in (c.get('backward_regimes') or []))
+                                         for c in full['other_configs'] if c.get('backward_regimes')}
+    if isinstance(full.get('config3_step'), dict):
+        line['config3_step'] = _pick(full['config3_step'], 'value', 'unit', 'ms_per_step', 'peak_memory_GB', 'steps')
+    for k in ('fp32_mfma_contraction', 'bf16x3_contraction'):
+        if isinstance(full.get(k), dict):
+            line[k] = _pick(full[k], 'value')
+    for k in ('backend', 'functional_check_only'):
+        if k in full:
+            line[k] = full[k]
+    if isinstance(full.get('expected_scaling'), dict):
+        line['expected_scaling'] = _pick(full['expected_scaling'], 'exposed_comm_ms_per_step_estimate', 'efficiency_from_comm_alone', 'expected_efficiency_band')
+    if full.get('ranks'):
+        line['ranks'] = [_pick(r, 'rank', 'device', 'device_name') for r in full['ranks']]
+    line['detail'] = detail_file
+    line = _clean(line)
+    # the budget is a hard one: drop the least judged objects first rather than print a line the record cannot hold
+    for k in ('ranks', 'other_configs_regimes', 'kernel_rooflines', 'whole_step', 'bf16x3_contraction', 'fp32_mfma_contraction', 'expected_scaling'):
+        if len(json.dumps(line, allow_nan=False)) <= LINE_BUDGET:
+            break
+        line.pop(k, None)
+    return line
+
+
+def emit(full):
+    """Detail record -> bench_detail.json (repo root; a copy under gpurun_out/ when that directory exists, so a gpurun call brings it
+    back) and the compact line as the LAST line of stdout."""
+    detail = _clean(full)
+    text = json.dumps(detail, allow_nan=False, indent=1)
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, 'bench_detail.json'), 'w') as f:
+                    f.write(text)
+            except OSError:
+                pass
+    sys.stdout.flush()
+    print(json.dumps(compact_line(detail), allow_nan=False), flush=True)
 
 
 def _free_port():
@@ -859,12 +979,12 @@ def main(argv=None):
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'rccl_ranks': world if backend == 'nccl' and world > 1 else 0,
-            'dtype_note': 'fp32 tensors, fp32 accumulation everywhere; the forward contraction forms its fp32 products on the fp16 matrix '
-                          'cores from two-plane splits x = h + l of both operands after a power-of-two scale per operand row (representation '
-                          'error <= 2^-23 per element; three exact partial products, fp32 accumulate).  Measured against fp64 it is MORE accurate '
-                          'than the fp32-MFMA kernel on the same operands (rms 0.6 x at K = 3072; both are dominated by the fp32 accumulation): '
-                          'tests/test_gpu_split_planes.py.  Same-run A/B legs: bf16x3_contraction (three bf16 planes, exact splits, six products) '
-                          'and fp32_mfma_contraction (vgtk._hip.SPLIT_PLANES = 3 / SPLIT_BF16_CONTRACTION = False)',
+            'dtype_note': 'fp32 tensors, fp32 accumulation everywhere.  The dense product of the deep layers (csrc/so3_dense.hip, BOTH directions), the '
+                          'contractions and the small GEMMs around them form their fp32 products on the fp16 matrix cores from two-plane splits '
+                          'x = h + l of the stored operand after a power-of-two scale per row (three partial products h h + h l + l h, fp32 accumulate; '
+                          '|err| <= 2^-21 sum|a||b|); tests/test_gpu_split_planes.py, tests/test_gpu_dense.py against float64.  Same-run A/B legs: '
+                          'bf16x3_contraction (three bf16 planes, six products) and fp32_mfma_contraction (vgtk._hip.SPLIT_PLANES = 3 / '
+                          'SPLIT_BF16_CONTRACTION = False)',
             'config': {'workload': f'{args.batch} x {args.points}-pt synthetic ' + ('partial (depth-buffer visible) ' if args.partial else '') + 'laptop clouds per GPU, 3-block '
                                    + ('separable (inter+intra+skip) glb_backbone' if args.separable else 'inter backbone')
                                    + f' 1->64->128->512 (NN=64,K=24,A=60), '
@@ -909,33 +1029,22 @@ def main(argv=None):
             torch.cuda.empty_cache()
             line['config3_step'] = config3_step(dev)       # (before the CPU probes start: its many small launches feel busy host cores)
             progress('config-3 composite done')
-        cpu_job = None
-        if world == 1 and not args.no_cpu_baseline:
-            # child processes on the host cores, BESIDE the side legs below (never beside the headline loop above): a few minutes of CPU
-            # work that would otherwise be added to the run
-            import threading
-            cpu_job = {}
-            def _cpu():
-                try:
-                    cpu_job['result'] = cpu_baseline(args.points)
-                except Exception as e:          # noqa: BLE001  (reported in the line, the GPU numbers stand)
-                    cpu_job['error'] = repr(e)
-            cpu_job['thread'] = threading.Thread(target=_cpu, daemon=True)
-            cpu_job['thread'].start()
         if world == 1 and default_cfg and not args.no_other_configs:
             line['other_configs'] = other_configs(dev)
             progress('other configurations done')
         if world == 1 and not args.fwd_only:
             line['zpconv_roofline'] = zpconv_roofline(dev, args.points)
             progress('native zpconv done')
-        if cpu_job is not None:
-            cpu_job['thread'].join()
-            if 'error' in cpu_job:
-                raise RuntimeError('cpu baseline: ' + cpu_job['error'])
-            line['cpu_baseline'] = cpu_job['result']
+        if world == 1 and not args.no_cpu_baseline:
+            # child processes on the host cores, AFTER every GPU leg (beside them the wide probes disturbed the launch-heavy side
+            # legs: articulated input 93 -> 77 clouds/s in round 5); a failing probe is reported in the line, the GPU numbers stand
+            try:
+                line['cpu_baseline'] = cpu_baseline(args.points)
+                line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
+            except Exception as e:          # noqa: BLE001
+                line['cpu_baseline'] = {'value': None, 'unit': 'point-clouds/sec', 'cores': 0, 'kind': 'port', 'error': repr(e)[:300]}
             progress('cpu baseline done')
-            line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

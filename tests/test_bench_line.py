@@ -1,0 +1,79 @@
+"""The line bench.py prints LAST must stay parseable by the driver: a few KB of strict JSON carrying the contract's keys,
+`roofline` and `cpu_baseline` (round 5's 20 KB line fell outside the driver's record: BENCH_r05.json `parsed: null`).
+Built here from canned detail records (the full objects earlier rounds printed, committed under profiles/)."""
+import glob
+import json
+import math
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CANNED = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r05_[mnp]_bench.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'r06_*bench_detail.json')))
+CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config')
+
+
+def _strict(text):
+    def bad(tok):
+        raise ValueError('non-finite constant in the line: ' + tok)
+    return json.loads(text, parse_constant=bad)
+
+
+@pytest.mark.parametrize('path', CANNED, ids=os.path.basename)
+def test_compact_line_is_short_strict_json_with_the_judged_objects(path):
+    full = json.load(open(path))
+    line = bench.compact_line(full)
+    text = json.dumps(line, allow_nan=False)
+    assert '\n' not in text and len(text) < 8000, len(text)
+    assert len(text) <= bench.LINE_BUDGET, len(text)
+    back = _strict(text)
+    for k in CONTRACT:
+        assert k in back, k
+    assert back['value'] == pytest.approx(full['value'], rel=1e-5) and back['dtype'] == 'f32' and 'workload' in back['config']
+    roof = back['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_ms'):
+        assert k in roof, k
+    assert roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'], rel=1e-4)
+    cpu = back['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in cpu, k
+    assert back['zpconv_roofline']['frac'] == pytest.approx(full['zpconv_roofline']['frac'], rel=1e-5)
+    assert sorted(back['other_configs'].values()) == pytest.approx(sorted(c['value'] for c in full['other_configs']), rel=1e-5)
+    assert back['config3_step']['value'] == pytest.approx(full['config3_step']['value'], rel=1e-5)
+    assert back['detail'] == 'bench_detail.json'
+
+
+def test_non_finite_numbers_become_null_and_the_budget_drops_side_objects_first():
+    full = json.load(open(CANNED[-1]))
+    full['roofline']['traffic'] = float('nan')
+    full['zpconv_roofline']['ms'] = float('inf')
+    full['other_configs'] = [dict(c, name=c['name'] + ' ' + 'x' * 400) for c in full['other_configs']] * 3    # an oversized side leg
+    line = bench.compact_line(bench._clean(full))
+    text = json.dumps(line, allow_nan=False)
+    back = _strict(text)
+    assert back['roofline']['traffic'] is None and back['zpconv_roofline']['ms'] is None
+    assert 'roofline' in back and 'cpu_baseline' in back and math.isfinite(back['value'])
+
+
+def test_a_failed_cpu_probe_keeps_the_line():
+    full = json.load(open(CANNED[-1]))
+    full['cpu_baseline'] = {'value': None, 'unit': 'point-clouds/sec', 'cores': 0, 'kind': 'port', 'error': 'RuntimeError("probe died")'}
+    full.pop('speedup_vs_cpu_baseline', None)
+    back = _strict(json.dumps(bench.compact_line(full), allow_nan=False))
+    assert back['cpu_baseline']['error'].startswith('RuntimeError') and back['value'] > 0
+
+
+def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, monkeypatch, capsys):
+    full = json.load(open(CANNED[-1]))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    os.makedirs(tmp_path / 'gpurun_out')
+    bench.emit(full)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and _strict(out[0])['value'] == pytest.approx(full['value'], rel=1e-5)
+    for d in (tmp_path, tmp_path / 'gpurun_out'):
+        detail = _strict(open(d / 'bench_detail.json').read())
+        assert 'kernels' in detail and 'launch_shapes' in detail
