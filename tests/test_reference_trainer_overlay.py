@@ -19,12 +19,17 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'vgtk', 'vgtk', 'app')), reason='needs /root/reference (build container only)')
 
 
-def test_root_exports_with_the_reference_runtime_overlaid(tmp_path):
+def _overlay(tmp_path):
     pkg = tmp_path / 'overlay'
     shutil.copytree(os.path.join(ROOT, 'equi-articulated-pose_amd'), pkg, ignore=shutil.ignore_patterns('csrc', '__pycache__', '*.o'))
     shutil.copytree(os.path.join(REF, 'vgtk', 'vgtk', 'app'), pkg / 'vgtk' / 'app', ignore=shutil.ignore_patterns('__pycache__'))
     shutil.copy(os.path.join(REF, 'vgtk', 'vgtk', 'loss.py'), pkg / 'vgtk' / 'loss.py')
-    script = textwrap.dedent(f'''
+    return pkg
+
+
+def _prelude(pkg, extra_roots=()):
+    """Child-interpreter prelude: stubs for the third-party / dataset modules, the overlay first on sys.path, the reference behind it."""
+    return textwrap.dedent(f'''
         import importlib, importlib.abc, importlib.machinery, sys, types
         import numpy as np
         np.float = float
@@ -43,7 +48,7 @@ def test_root_exports_with_the_reference_runtime_overlaid(tmp_path):
             """stubs every module that cannot be found, below the listed roots"""
             ROOTS = ('tensorboardX', 'colour', 'parse', 'trimesh', 'plyfile', 'imageio', 'skimage', 'ipdb', 'pyrender', 'transforms3d',
                      'torch_cluster', 'torch_scatter', 'open3d', 'cv2', 'matplotlib', 'SPConvNets.datasets', 'SPConvNets.pose_utils',
-                     'SPConvNets.ransac', 'SPConvNets.models.common_utils', 'SPConvNets.utils.loss_util', 'model_util')
+                     'SPConvNets.ransac') + {tuple(extra_roots)!r}
             def find_spec(self, name, path=None, target=None):
                 if any(name == r or name.startswith(r + '.') for r in self.ROOTS):
                     return importlib.machinery.ModuleSpec(name, self)
@@ -57,6 +62,19 @@ def test_root_exports_with_the_reference_runtime_overlaid(tmp_path):
         sys.path[:0] = [{str(pkg)!r}, {REF!r}]
         import vgtk
         assert {str(pkg)!r} in vgtk.__file__, vgtk.__file__
+    ''')
+
+
+def _run(script, tmp_path, token):
+    env = dict(os.environ, PYTHONPATH='', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', LOCAL_RANK='0')    # (the model reads LOCAL_RANK: ...pn_38_multi_stage.py:L103)
+    out = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0 and token in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    return out.stdout
+
+
+def test_root_exports_with_the_reference_runtime_overlaid(tmp_path):
+    pkg = _overlay(tmp_path)
+    script = _prelude(pkg, ('SPConvNets.models.common_utils', 'SPConvNets.utils.loss_util', 'model_util')) + textwrap.dedent('''
         for name in ('Trainer', 'Logger', 'Summary', 'Timer', 'HierarchyArgmentParser', 'dump_args', 'LearningRateScheduler', 'batch_gather',
                      'CrossEntropyLossPerP', 'AttentionCrossEntropyLoss'):
             assert hasattr(vgtk, name), name
@@ -69,9 +87,51 @@ def test_root_exports_with_the_reference_runtime_overlaid(tmp_path):
         assert issubclass(T.Trainer, vgtk.Trainer)
         print('OVERLAY-OK')
     ''')
-    env = dict(os.environ, PYTHONPATH='')
-    out = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
-    assert out.returncode == 0 and 'OVERLAY-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    _run(script, tmp_path, 'OVERLAY-OK')
+
+
+def test_reference_model_builder_yields_the_product_operators_with_the_reference_state_dict(tmp_path):
+    """SPConvNets/models/unsup_seg_so3_pose_conv_pn_38_multi_stage.py:L2067-2325 `build_model_from(opt)` -- the call the trainer
+    makes (trainer_unsup_arti_align.py:L333-334) -- on product + overlay, with the reference's own option parser
+    (SPConvNets/options.py) fed the shipped script's model arguments (scripts/train/laptop_syn.sh).  The model it returns must be
+    made of the PRODUCT's conv modules and carry the reference's parameter names and shapes (its checkpoints load)."""
+    pkg = _overlay(tmp_path)
+    script = _prelude(pkg) + textwrap.dedent(f'''
+        import os
+        import torch
+        sys.path.insert(2, os.path.join({REF!r}, 'SPConvNets', 'models'))         # `from DGCNN import PrimitiveNet`
+        sys.argv = ['run.py', 'experiment', '-d', {str(tmp_path)!r}, '--experiment-id', 'overlay',
+                    'model', '--model', 'unsup_seg_so3_pose_conv_pn_38_multi_stage', '--input-num', '512', '--kanchor', '60']
+        from SPConvNets.options import opt
+        opt.device = torch.device('cpu')
+        # (no GPU in the build container; the model's constructor calls .cuda() on its constants: ...pn_38_multi_stage.py:L117)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        if not hasattr(opt, 'nmasks'):
+            opt.nmasks = 2
+        import SPConvNets.models.unsup_seg_so3_pose_conv_pn_38_multi_stage as MS
+        model = MS.build_model_from(opt)
+        assert type(model).__name__ == 'ClsSO3ConvModel'
+        import vgtk.so3conv as sptk
+        assert 'overlay' in sptk.__file__
+        convs = [m for m in model.modules() if type(m).__name__ in ('InterSO3PoseConv', 'InterSO3Conv', 'IntraSO3Conv', 'BasicSO3Conv')]
+        assert convs and all(type(m).__module__.startswith('vgtk.so3conv') and 'overlay' in sys.modules[type(m).__module__].__file__ for m in convs), \
+            sorted({{type(m).__module__ for m in convs}})
+        sd = model.state_dict()
+        # the reference's names and shapes (BasicSO3PoseConvBlock -> InterSO3PoseConvBlock -> InterSO3PoseConv -> BasicSO3Conv.W:
+        # SPConvNets/utils/base_so3poseconv.py:L205-222, vgtk/vgtk/so3conv/modules.py:L33-55)
+        want = {{'glb_backbone.0.blocks.0.inter_conv.conv.basic_conv.W': (64, 1, 24), 'backbone.1.blocks.0.conv.basic_conv.W': (128, 64, 24),
+                'backbone_sec.2.blocks.0.conv.basic_conv.W': (512, 128, 24),
+                'glb_backbone.2.blocks.0.intra_conv.conv.basic_conv.W': (512, 512, 12)}}
+        for k, shp in want.items():
+            assert k in sd, (k, [n for n in sd if n.startswith(k.split('.')[0])][:8])
+            assert tuple(sd[k].shape) == shp or sd[k].numel() == shp[0] * shp[1] * shp[2], (k, tuple(sd[k].shape))
+        n_params = sum(p.numel() for p in model.parameters())
+        print('BUILD-OK', n_params, len(sd), len(convs))
+    ''')
+    out = _run(script, tmp_path, 'BUILD-OK')
+    n_params = int(out.split('BUILD-OK')[1].split()[0])
+    assert n_params > 10_000_000, n_params          # (21.2 M with the shipped hyper-parameters)
 
 
 def test_root_without_the_overlay_has_no_runtime_names():
