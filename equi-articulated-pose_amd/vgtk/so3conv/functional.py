@@ -592,6 +592,7 @@ def _grouped_bound(feats, idx):
 
 
 BACKWARD_LOG = None      # a list while someone wants to know the backward regime of every inter conv (bench.py, tests)
+FORWARD_LOG = None       # the same for the forward: {'channels', 'dense': the dense product ran, 'parts'}
 
 
 # The dense product over the referenced rows (csrc/so3_dense.hip): 'auto' takes it when every cloud of the batch can (no pose
@@ -840,6 +841,8 @@ class _InterConv(torch.autograd.Function):
         ctx.parts = parts if rp > 0 else None
         if rp > 0 and needs_grad:                         # (built by whoever needs it first: the forward below, or the backward)
             ctx.dense = [None, (geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)]
+        if FORWARD_LOG is not None:
+            FORWARD_LOG.append({'channels': (c, o), 'dense': bool(rp > 0 and dense_fwd), 'parts': None if parts is None else parts.n})
         if rp > 0 and dense_fwd:
             head.wait()
             if parts is None:
