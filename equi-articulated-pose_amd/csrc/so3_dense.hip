@@ -40,6 +40,7 @@
 // per k-block) rides in the same ring; four stages, one barrier per k-step.  Every wave generates the operand of ITS 64
 // columns for all 256 rows: 16 weights per lane and k-block against 48 matrix instructions, ~2.5 vector instructions per
 // matrix instruction, issued in their shadow.
+#include <atomic>
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -740,12 +741,17 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
 template <int MI, int FORM, int DBG = 0>
 int kc_launch(const KcArgs &g, hipStream_t s) {
     constexpr size_t shmem = 4 * (2 * (size_t)MI * 2048u + 2048u);
-    static bool set = false;
-    if (!set) {
+    // per DEVICE (a process may drive several GPUs: the attribute belongs to the function object of the current device) and
+    // race-free: a bit per device id, set after the call succeeded -- two threads may both make the (idempotent) call
+    static std::atomic<unsigned long long> set_on{0};
+    int dev = 0;
+    if (int e = eap::hip_fail(hipGetDevice(&dev), "so3_dense: hipGetDevice")) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(set_on.load(std::memory_order_acquire) & bit)) {
         if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_gemm_kernel<MI, FORM, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       (int)shmem), "so3_dense: shared memory attribute"))
             return e;
-        set = true;
+        set_on.fetch_or(bit, std::memory_order_release);
     }
     const long long blocks = (long long)g.zcount * g.tiles_m * g.blocks_n;
     if (blocks > 0x7fffffffLL) return eap::bad_arg("so3_dense: too many workgroups");

@@ -70,17 +70,41 @@ ON_CHIP_BACKWARD = True     # False: always the product pipeline of csrc/zpconv_
 
 
 _HOT_VERDICTS = {}          # (storage pointer, version, shape) of an index tensor -> (weakref, clouds the on-chip kernel left)
+_HOT_PENDING = []           # [event, pinned status copy, expected clouds, key]: verdict re-checks whose device result has not been looked at yet
 
 
 def _verdict_key(idx):
     return (idx.data_ptr(), idx._version, tuple(idx.shape))
 
 
+def _check_pending_verdicts(block=False):
+    """The remembered verdict of an index tensor is trusted WITHOUT a host read (no stall in a training loop), but every later call
+    still gets the kernel's status back asynchronously and it is compared here, at the next call into this module (block=True:
+    now).  A mismatch means the index CONTENTS changed under an unchanged version counter (`idx.data.copy_`, memory shared with
+    numpy / dlpack, a raw-pointer kernel writing into the buffer): the clouds the on-chip kernel then rejected were not redone, so the
+    previous result is wrong -- raise, and forget the verdict.  Contract: an index tensor handed to inter_zpconv_backward is either
+    left alone or modified through torch in-place ops (which bump `_version`)."""
+    for item in list(_HOT_PENDING):
+        ev, host, known, key = item
+        if not (block or ev.query()):
+            continue
+        if block:
+            ev.synchronize()
+        _HOT_PENDING.remove(item)
+        seen = tuple(i for i, s_ in enumerate(host.tolist()) if s_ != 0)
+        if seen != tuple(known):
+            _HOT_VERDICTS.pop(key, None)
+            raise RuntimeError('inter_zpconv_backward: the index tensor\'s contents changed without a version bump (clouds left by the on-chip kernel '
+                               f'were {list(known)}, now {list(seen)}); the result of the previous call with it is invalid -- modify index tensors '
+                               'through torch in-place ops or pass a new tensor')
+
+
 def _backward_on_chip(idx, w, grad, out):
     """-> clouds still to do (all of them when the shape is not taken).  The verdict depends on the INDEX alone (which clouds
     name a row twice / reference too many rows), so it is remembered per index tensor: a training loop that keeps its
     neighbourhood pays the status read once, and a batch the kernel cannot take at all (padded lists: small radii, sparse or
-    partial input) skips its prelude from the second call on."""
+    partial input) skips its prelude from the second call on.  Re-checked on the device every call: _check_pending_verdicts."""
+    _check_pending_verdicts()
     b, np_, na, ks, ann = idx.shape
     c, nq = grad.shape[1], out.shape[2]
     nbytes = int(_hip.lib.eap_inter_zpconv_bwd_hot_workspace(b, np_, nq, na, ks, ann, c)) if ON_CHIP_BACKWARD else 0
@@ -90,13 +114,21 @@ def _backward_on_chip(idx, w, grad, out):
     hit = _HOT_VERDICTS.get(key)
     known = hit[1] if (hit is not None and hit[0]() is idx) else None
     if known is not None and len(known) == b:
-        return list(known)                                   # nothing for the on-chip kernel here
+        return list(known)                                   # nothing for the on-chip kernel here (every cloud goes to the product pipeline: correct whatever the index holds)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=grad.device)
     status = torch.empty(b, dtype=torch.int32, device=grad.device)
     _hip.call('eap_inter_zpconv_bwd_hot_f32', out, b, np_, nq, na, ks, ann, c, _hip._ptr(idx), _hip._ptr(w), _hip._ptr(grad),
               _hip._ptr(out), _hip._ptr(ws), _hip._ptr(status))
     if known is not None:
-        return list(known)                                   # (same index, same shapes: the same clouds as last time; no host read)
+        # same index, same shapes: the same clouds as last time, no host read now -- the status travels to pinned memory behind the
+        # kernel and is compared at the next call
+        if len(_HOT_PENDING) < 8:
+            host = torch.empty(b, dtype=torch.int32, pin_memory=True)
+            host.copy_(status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _HOT_PENDING.append([ev, host, tuple(known), key])
+        return list(known)
     todo = [i for i, s in enumerate(status.tolist()) if s != 0]
     if len(_HOT_VERDICTS) > 64:
         _HOT_VERDICTS.clear()

@@ -449,7 +449,7 @@ class _ListHead:
         self.memb = None
         if side is not main:
             side.wait_stream(main)                        # idx / gx / nonident were produced on the main stream
-            for t in (idx, gx, nonident) + tuple(dense_probe or ()):
+            for t in (idx, gx, nonident) + tuple(x[1] if isinstance(x, tuple) else x for x in (dense_probe or ())):
                 if t is not None:
                     t.record_stream(side)                 # (read on the side stream: the allocator must not recycle them under it)
         with torch.cuda.stream(side):
@@ -461,7 +461,13 @@ class _ListHead:
                 dense_bad = dflags.max()
                 eye = torch.eye(3, dtype=torch.float32, device=dev)
                 for rot in dense_probe:
-                    if rot is not None:
+                    if isinstance(rot, tuple):
+                        # ('orthonormal', [b,3,3] one rotation per cloud): the plain product stands for R_rel = R R^T = I, which holds
+                        # for an orthonormal block only -- a predicted, not-quite-orthonormal 3x3 must stay on the list kernels
+                        # (they form R_p R_n^T as the reference does, so3conv/functional.py:L1112-1120)
+                        r = rot[1].double()
+                        dense_bad = dense_bad + ((torch.matmul(r, r.transpose(-1, -2)) - eye.double()).abs().max() > 1e-6).to(torch.int32)
+                    elif rot is not None:
                         dense_bad = dense_bad + (rot[:, :, :3, :3] != eye).any().to(torch.int32)
             stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32), dense_bad.to(torch.int32)])
             self.host = torch.empty(3, dtype=torch.int32, pin_memory=True)
@@ -824,7 +830,10 @@ class _InterConv(torch.autograd.Function):
         probe = parts = None
         # (a folded inference epilogue does not stop it: the dense forward leaves `epilogue.applied` False and the caller runs the
         # norm as a pass of its own -- cheaper than giving up the dense product for the 128 -> 512 layer)
+        # (without gradients only the forward can use the product, and 'auto' takes it at o % 256 == 0 only: no probe -- and no host wait --
+        # for an inference call it could not change)
         if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0)
+                and (needs_grad or o % 256 == 0 or DENSE_MODE == 'force')
                 and _hip.so3_dense_supported(p, na, ks, 16, o)):
             probe = (geometry[2], geometry[3])
             if (DENSE_PARTS and geometry[3] is not None and geometry[0] is geometry[1] and geometry[2] is geometry[3] and p == n):
@@ -832,7 +841,10 @@ class _InterConv(torch.autograd.Function):
                 if parts is not None:
                     probe = ()                             # the rotations are accounted for per part: no "exactly the identity" requirement
                     if parts.single:
-                        parts = None                       # one rotation per cloud: every relative rotation is the identity -- the plain product
+                        # one rotation per cloud: every relative rotation R R^T is the identity -- the plain product -- PROVIDED the
+                        # block is orthonormal (checked on the device with the other conditions)
+                        probe = (('orthonormal', parts.reps[:, 0].contiguous()),)
+                        parts = None
         head = None
         if (lists_ok and needs_grad) or probe is not None:
             head = _ListHead(idx, n, nonident, gx, prefill=(not keep) and probe is None, dense_probe=probe)

@@ -1069,3 +1069,37 @@ def test_inter_zpconv_backward_remembers_the_verdict_per_index(dev):
     for _ in range(2):
         assert rel_err(Z.inter_zpconv_backward(d_idx, d_w, d_g, q).cpu().numpy(), ref2) < 1e-5
     assert any(v[1] == (0, 1, 2, 3, 4) for v in Z._HOT_VERDICTS.values())
+
+
+@pytest.mark.gpu
+def test_inter_zpconv_backward_notices_an_index_changed_behind_its_version_counter(dev):
+    """Round-5 advisor finding: the remembered verdict is keyed on (pointer, version, shape); `idx.data.copy_` changes the contents
+    without a version bump.  The remembered call still runs without a host read, but the kernel's status comes back asynchronously
+    and the NEXT call into the module compares it: the mismatch raises and the verdict is forgotten, after which the same tensor
+    gives the oracle's result again."""
+    import vgtk.cuda.zpconv as Z
+    rng = np.random.default_rng(29)
+    b, p, q, a, k, ann, c = 4, 8, 80, 60, 24, 64, 32
+    idx = np.stack([np.stack([rng.permutation(q)[:ann] for _ in range(p)]) for _ in range(b)])
+    idx5 = np.broadcast_to(idx[:, :, None, None, :], (b, p, a, k, ann)).astype(np.int32).copy()
+    w = rng.random((b, p, a, k, ann)).astype(np.float32)
+    g = rng.standard_normal((b, c, k, p, a)).astype(np.float32)
+    d_idx, d_w, d_g = T(idx5).to(dev), T(w).to(dev), T(g).to(dev)
+    Z._HOT_VERDICTS.clear()
+    del Z._HOT_PENDING[:]
+    first = Z.inter_zpconv_backward(d_idx, d_w, d_g, q)
+    assert rel_err(first.cpu().numpy(), native.inter_zpconv_backward(idx5, w, g, q)) < 1e-5
+    assert list(Z._HOT_VERDICTS.values())[0][1] == ()                       # every cloud on chip
+    changed = idx5.copy()
+    changed[2, :, :, :, ann // 2:] = changed[2, :, :, :, :1]                  # cloud 2 now names rows twice: the on-chip kernel rejects it
+    version = d_idx._version
+    d_idx.data.copy_(T(changed).to(dev))
+    assert d_idx._version == version                                        # (the case: contents moved, counter did not)
+    Z.inter_zpconv_backward(d_idx, d_w, d_g, q)                             # trusted the stale verdict: cloud 2 is not redone ...
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='without a version bump'):       # ... and the next call says so
+        Z.inter_zpconv_backward(d_idx, d_w, d_g, q)
+    assert not Z._HOT_VERDICTS and not Z._HOT_PENDING
+    again = Z.inter_zpconv_backward(d_idx, d_w, d_g, q)                     # verdict taken afresh
+    assert rel_err(again.cpu().numpy(), native.inter_zpconv_backward(changed, w, g, q)) < 1e-5
+    Z._check_pending_verdicts(block=True)
