@@ -612,7 +612,7 @@ def config3_step(dev, batch=16, points=4096, steps=2, warmup=1):
     out = {'workload': f'{batch} x {points}-pt clouds: 3 separable blocks forward (frozen, no_grad) + 2 x 3 inter blocks forward+backward + '
                        f'InvPPOutBlockOurs + {C3.SLOTS} batched SO3OutBlockRTWithMaskSep heads + chamfer [{batch},{points},3] forward+backward + Adam',
            'value': batch * steps / dt, 'unit': 'point-clouds/sec', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': warmup,
-           'loss': float(loss), 'peak_memory_GB': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+           'loss': float(loss.detach()), 'peak_memory_GB': torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            'whole_step': {'algorithmic_flops_of_the_hot_path_launches': flops, 'textbook_flops': C3.algorithmic_flops(batch, points, synth_clouds.backbone_layers(points)), 'achieved_TFLOPs': flops / (dt / steps) / 1e12,
                           'frac_of_fp32_mfma_peak': flops / (dt / steps) / 1e12 / PEAK_F32_MFMA_TFLOPS},
            'kernel_time_share': sum(k['ms'] for k in kern.values()) / (dt * 1e3),

@@ -57,6 +57,7 @@ typedef unsigned long long u64;
 typedef const __attribute__((address_space(4))) unsigned long long *cu64p;      // constant address space: uniform loads go through the scalar cache
 
 constexpr int KC_BK = 32;                 // contraction elements per k-step (two MFMA k-blocks of 16)
+constexpr int KC_LIST_BYTES = 2048;       // LDS behind the operand ring for a column block's k-step list: at most 512 k-steps with a list
 
 // The DENSE INDEX d of a (kernel point k, row slot r) pair: d = (r / 16) 16 ks + 16 k + r % 16 -- groups of 16 row slots outermost,
 // then the kernel point, then the 16 slots.  Rows are sorted longest list first and every cloud has its own count R <= rp, so a
@@ -176,6 +177,67 @@ __global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, 
         }
     }
     bits[(((size_t)b * wtiles + wt) * steps + step) * 64 + lane] = word;
+}
+
+// keys[b][p]: bit g = point p's list names a row of the 16-row group g (row slots 16 g .. 16 g + 15; rp <= 512: 32 groups).  Sorting a
+// cloud's points by this key (any total order: equal keys become neighbours, and keys that share their high groups stay close) makes
+// the 0/1 mask of the dense product BLOCK-sparse: the first-nsample-by-index ball query (grouping_cuda_kernel.cu:L68-113) gives
+// every point 64 of the R referenced rows, i.e. rows of only 0.45-0.7 of the 16-row groups, and points with the same groups meet
+// in the same 32-point k-steps (backward) / 256-point column blocks (forward) -- dense_steps_kernel lists the non-empty ones.
+__global__ __launch_bounds__(256) void dense_keys_kernel(long long total, const unsigned *__restrict__ memb, int32_t *__restrict__ keys) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;            // (b, p)
+    if (i >= total) return;
+    const u32x4 *w = reinterpret_cast<const u32x4 *>(memb + i * MEMB_WORDS);
+    unsigned key = 0;
+#pragma unroll
+    for (int q = 0; q < MEMB_WORDS / 4; ++q) {
+        const u32x4 v = w[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = 2 * (4 * q + e);
+            key |= ((v[e] & 0xffffu) ? 1u : 0u) << g;
+            key |= ((v[e] >> 16) ? 1u : 0u) << (g + 1);
+        }
+    }
+    keys[i] = (int32_t)key;
+}
+
+// steps[(b blocks_n + bn) (KS + 1)]: [0] = count >= 1, [1 ..] = the k-steps (ascending) of column block bn of cloud b in which at least
+// one of the block's 4 x 64 lanes generates a weight that is not masked out -- every other k-step multiplies the stored operand by
+// exact zeros and is skipped by the product kernel.  skip = 0: every k-step (dir 1 with n_rows: of the cloud's own prefix).  A block
+// without any listed step gets step 0 (it still has to write its zeros).
+__global__ __launch_bounds__(256) void dense_steps_kernel(int KS, int blocks_n, int wtiles, int dir, int ks, int row_slots, int skip,
+                                                          const int32_t *__restrict__ n_rows, const unsigned *__restrict__ bits,
+                                                          int32_t *__restrict__ steps) {
+    extern __shared__ int nz[];
+    const int b = blockIdx.y, bn = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < KS; i += 256) nz[i] = 0;
+    __syncthreads();
+    int limit = KS;
+    if (dir == 1 && n_rows != nullptr) limit = max(min(KS, ((min(n_rows[b], row_slots) + 15) & ~15) * ks / KC_BK), 1);
+    if (skip) {
+        const int wt = min(4 * bn + wave, wtiles - 1);
+        const unsigned *src = bits + ((size_t)b * wtiles + wt) * (size_t)KS * 64 + lane;
+        for (int s = 0; s < limit; s += 4) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (s + u < limit) ? src[(size_t)(s + u) * 64] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (__builtin_amdgcn_ballot_w64(v[u] != 0u) != 0ull && lane == 0 && s + u < limit) nz[s + u] = 1;      // (all writers store 1)
+        }
+    } else {
+        for (int i = t; i < limit; i += 256) nz[i] = 1;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int32_t *dst = steps + ((size_t)b * blocks_n + bn) * (size_t)(KS + 1);
+        int n = 0;
+        for (int i = 0; i < KS; ++i)
+            if (nz[i]) dst[1 + n++] = i;
+        if (n == 0) dst[1 + n++] = 0;
+        dst[0] = n;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -384,22 +446,26 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int m, int l, int na, 
 // [o][b * chunks + chunk].
 // map (may be null) int32 [b][p]: column pp of cloud b is point map[b][pp] of a Y with p_dst points (< 0: the column is padding, not
 // written) -- the query points of one rigid part of a posed cloud, computed as a launch of their own
+// pivot_pos (may be null; with map): the column of cloud 0 that is point 0 -- the pivot is Y[0][o][0][0] whatever the column order
 __global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int p, int na, int p_dst, const int32_t *__restrict__ map,
+                                                                const int32_t *__restrict__ pivot_pos,
                                                                 const float *__restrict__ yt, float *__restrict__ y,
                                                                 float *__restrict__ psum, float *__restrict__ psq) {
     extern __shared__ float tile[];
     __shared__ float red[2][256];
     const int b = blockIdx.z, o = blockIdx.y, p0 = blockIdx.x * 64, t = threadIdx.x;
     const int np = min(64, p - p0);
-    const float pivot = psum ? yt[(size_t)o * p] : 0.f;                    // Yt[0][0][o][0]
+    const float pivot = psum ? yt[(size_t)o * p + (pivot_pos ? *pivot_pos : 0)] : 0.f;        // Yt[0][0][o][column of point 0]
     float s = 0.f, q = 0.f;
     for (int i = t; i < na * 64; i += 256) {
         const int a = i >> 6, pp = i & 63;
         if (pp < np) {
             const float v = yt[(((size_t)b * na + a) * o_total + o) * p + p0 + pp];
             tile[a * 65 + pp] = v;
-            const float d = v - pivot;
-            s += d; q = fmaf(d, d, q);
+            if (psum != nullptr && (map == nullptr || map[(size_t)b * p + p0 + pp] >= 0)) {      // (padding columns of a mapped launch: not in the moments)
+                const float d = v - pivot;
+                s += d; q = fmaf(d, d, q);
+            }
         }
     }
     red[0][t] = s; red[1][t] = q;
@@ -411,14 +477,15 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int o_total, int
             const int q = map[(size_t)b * p + p0 + pp];
             if ((unsigned)q < (unsigned)p_dst) row[(size_t)q * na + a] = tile[a * 65 + pp];
         }
-        return;
+        if (psum == nullptr) return;                                       // (block-uniform)
+    } else {
+        float *dst = y + (((size_t)b * o_total + o) * p + p0) * na;
+        for (int i = t; i < np * na; i += 256) {
+            const int pp = i / na, a = i - pp * na;
+            dst[i] = tile[a * 65 + pp];
+        }
+        if (psum == nullptr) return;
     }
-    float *dst = y + (((size_t)b * o_total + o) * p + p0) * na;
-    for (int i = t; i < np * na; i += 256) {
-        const int pp = i / na, a = i - pp * na;
-        dst[i] = tile[a * 65 + pp];
-    }
-    if (psum == nullptr) return;
     for (int h = 128; h > 0; h >>= 1) {                                    // (fixed order: bit-reproducible)
         if (t < h) { red[0][t] += red[0][t + h]; red[1][t] += red[1][t + h]; }
         __syncthreads();
@@ -459,6 +526,7 @@ struct KcArgs {
                                           // 2: the k axis is cut at the cloud's prefix (forward), 0: not cut
     float *C; long long cB, cA, ldm; int rp; long long kstride;     // element (row, n) of (b, a) at C[b cB + a cA + row ldm + (n / rp) kstride + n % rp]
     int row_slots;                        // row slots of the dense index range (the launcher's rp; `rp` above is the output's column split)
+    const int32_t *steps;                 // (may be null) [b][blocks_n][KS + 1]: count, then the k-steps this column block runs (dense_steps_kernel)
 };
 
 // DBG (timing ablations, `make ABLATION=1` + EAP_DENSE_DEBUG, WRONG results): 1 = no mask (all lanes kept), 2 = no k-side table
@@ -495,8 +563,19 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
     // this cloud's prefix of the dense index range (see dense_kr): whole 16-row groups of its own referenced rows
     const int used = (g.trim == 1 || g.trim == 2) ? ((min(g.n_rows[b], g.row_slots) + 15) & ~15) * g.ks : 0;      // (trim 3 / 0: dense indices, every slot)
     const int N = g.trim == 1 ? min(g.N, used) : g.N;
-    const int KS = g.trim == 2 ? max(min(g.KS, used / KC_BK), 1) : g.KS;
     if (256 * bn >= N) return;                             // (block-uniform, before any barrier)
+    // the k-steps this column block runs: the listed ones (dense_steps_kernel: those with a weight that is not masked out), else all of
+    // them / the cloud's own prefix.  The list is copied into LDS behind the ring and read one step ahead of its use with a plain
+    // ds_read + v_readfirstlane: LDS reads return in order, so the counted waits of the products stay counted (a scalar load in flight
+    // turns every lgkmcnt wait into "everything", the first version's 2 ms)
+    const int32_t *lstG = g.steps ? g.steps + ((size_t)b * g.blocks_n + bn) * (size_t)(g.KS + 1) : nullptr;
+    const int KS = lstG ? __builtin_amdgcn_readfirstlane(lstG[0]) : (g.trim == 2 ? max(min(g.KS, used / KC_BK), 1) : g.KS);
+    int *lstL = reinterpret_cast<int *>(smem + 4 * STAGE);
+    if (lstG != nullptr) {
+        for (int i = threadIdx.x; i < KS; i += 256) lstL[i] = lstG[1 + i];
+        __syncthreads();
+    }
+    auto step_at = [&](int i) __attribute__((always_inline)) { return lstG ? __builtin_amdgcn_readfirstlane(lstL[i]) : i; };
 
     const int t = threadIdx.x, lane = t & 63, li = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -527,8 +606,13 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
                                             :: "v"(voff16), "s"(src), "s"(dst) : "memory")
 #define DMA1(src, dst, o0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #o0 :: "v"(voff16), "s"(src), "s"(dst) : "memory")
 #define DMA4B(src, dst) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff4), "s"(src), "s"(dst) : "memory")
-    auto dma_slot = [&](int step, unsigned stage_off, int slot) __attribute__((always_inline)) {
-        const unsigned char *src = Aw + (size_t)step * step_bytes;
+    // the three sources of a k-step
+    struct StepSrc { const unsigned char *a, *str, *bit; };
+    auto src_of = [&](int step) __attribute__((always_inline)) {
+        return StepSrc{Aw + (size_t)step * step_bytes, strw + (size_t)step * 512u, bitw + (size_t)step * 256u};
+    };
+    auto dma_slot = [&](const StepSrc &ss, unsigned stage_off, int slot) __attribute__((always_inline)) {
+        const unsigned char *src = ss.a;
         const unsigned dst = ldsA + stage_off;
         if constexpr (MI == 8) {
             if (slot == 0) DMA2(src, dst, 0, 1024);
@@ -542,13 +626,14 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
             if (slot == 3) DMA1(src, dst, 3072);
         }
         if (slot == 5) {
-            DMA4B(strw + (size_t)step * 512u, lds0 + stage_off + STR_OFF + (unsigned)wave * 256u);
-            DMA4B(bitw + (size_t)step * 256u, lds0 + stage_off + BIT_OFF + (unsigned)wave * 256u);
+            DMA4B(ss.str, lds0 + stage_off + STR_OFF + (unsigned)wave * 256u);
+            DMA4B(ss.bit, lds0 + stage_off + BIT_OFF + (unsigned)wave * 256u);
         }
     };
     auto issue = [&](int step, unsigned stage_off) __attribute__((always_inline)) {
+        const StepSrc ss = src_of(step);
 #pragma unroll
-        for (int slot = 0; slot < 6; ++slot) dma_slot(step, stage_off, slot);
+        for (int slot = 0; slot < 6; ++slot) dma_slot(ss, stage_off, slot);
     };
 
     f32x16 acc[MI][2];
@@ -658,9 +743,10 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
 
     // ---- prologue: stages 0, 1, 2 <- k-steps 0, 1, 2 (past the last step: the last step again, into a stage nobody reads) ----
     const int last = KS - 1;
-    issue(0, 0);
-    issue(min(1, last), STAGE);
-    issue(min(2, last), 2 * STAGE);
+    issue(step_at(0), 0);
+    issue(step_at(min(1, last)), STAGE);
+    issue(step_at(min(2, last)), 2 * STAGE);
+    int ahead = lstG ? lstL[min(3, last)] : 0;              // (a VGPR, all lanes equal) the k-step whose pieces the first pass of the loop issues
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // (a wave whose 64 columns lie past N runs the same instruction stream on clamped columns and an all-zero mask: a branch
@@ -689,19 +775,22 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        const int nxt = min(s + 3, last);
+        // (the list entry was read a whole step ago)
+        const int nxt = lstG ? __builtin_amdgcn_readfirstlane(ahead) : min(s + 3, last);
+        const StepSrc ssn = src_of(nxt);
+        if (lstG != nullptr) ahead = lstL[min(s + 4, last)];
         const unsigned dst = s3;
         const unsigned mbn = *reinterpret_cast<const unsigned *>(smem + s1 + BIT_OFF + (unsigned)t * 4u);      // mask bits of step s + 1
         const f32x4 *str1 = reinterpret_cast<const f32x4 *>(smem + s1 + STR_OFF);
         // k-block 2s: generates k-block 2s + 1 (sv = its k-side entries, mask bits 16..31 of this step's dword); reads the entries of
         // k-block 2s + 2 (first slice of the next stage) for the next call
         kblock(smem + s0, 0, smem + s0, 1, str1, mbc, 1, B0, B1, ah, sv, LEAN ? sv : sw, [&](int slot) __attribute__((always_inline)) {
-            if constexpr (!(DBG & 8)) dma_slot(nxt, dst, slot);
+            if constexpr (!(DBG & 8)) dma_slot(ssn, dst, slot);
         });
         // k-block 2s + 1: generates k-block 2s + 2 (mask bits 0..15 of the NEXT step's dword); reads the entries of k-block 2s + 3
         // (past the end: stale data nobody uses)
         kblock(smem + s0, 1, smem + s1, 0, str1 + 16, mbn, 0, B1, B0, ah, LEAN ? sv : sw, sv, [&](int slot) __attribute__((always_inline)) {
-            if constexpr (!(DBG & 8)) dma_slot(nxt, dst, 3 + slot);
+            if constexpr (!(DBG & 8)) dma_slot(ssn, dst, 3 + slot);
         });
         mbc = mbn;
         { const unsigned r = s0; s0 = s1; s1 = s2; s2 = s3; s3 = r; }
@@ -740,7 +829,7 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
 
 template <int MI, int FORM, int DBG = 0>
 int kc_launch(const KcArgs &g, hipStream_t s) {
-    constexpr size_t shmem = 4 * (2 * (size_t)MI * 2048u + 2048u);
+    constexpr size_t shmem = 4 * (2 * (size_t)MI * 2048u + 2048u) + KC_LIST_BYTES;      // the ring + the k-step list
     // per DEVICE (a process may drive several GPUs: the attribute belongs to the function object of the current device) and
     // race-free: a bit per device id, set after the call succeeded -- two threads may both make the (idempotent) call
     static std::atomic<unsigned long long> set_on{0};
@@ -865,8 +954,10 @@ extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int
 // ldz (dir 0): floats between consecutive (o, k) rows of Z, >= na rp (the columns past na rp are not written)
 // n_rows [b] (may be null: no trimming): referenced rows per cloud -- a cloud's products end at ceil16(n_rows[b]) row slots (dir 0: the
 // slots past it are ZEROED in Z, not computed)
-extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
-                                         const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream) {
+// steps (may be null): the k-step lists of eap_so3_dense_steps for this direction -- column blocks run their listed k-steps only
+extern "C" int eap_so3_dense_product_steps_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
+                                               const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask,
+                                               const int32_t *steps, float *out, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (!eap_so3_dense_supported(p, na, ks, rp, o)) return eap::bad_arg("so3_dense_product: shape not taken (eap_so3_dense_supported)");
     const int p_pad = ceil_to(p, KC_BK), kd_pad = ceil_to(ks * rp, KC_BK);
@@ -892,6 +983,7 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
         g.cB = (long long)na * o * p; g.cA = (long long)o * p; g.ldm = p; g.rp = p; g.kstride = 0;
     }
     g.mask = reinterpret_cast<const unsigned *>(mask);
+    g.steps = (steps != nullptr && g.KS <= KC_LIST_BYTES / 4) ? steps : nullptr;      // (longer contraction axes run every k-step)
     g.C = out;
     g.neg_inv_sigma = -1.0f / sigma;
     g.n_rows = n_rows; g.ks = ks; g.trim = dir ? 2 : 1;       // (columns / k axis are dense indices either way; without n_rows every slot counts)
@@ -919,11 +1011,44 @@ extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, i
     return g_dense_form ? kc_launch<8, 1>(g, eap::S(stream)) : kc_launch<8, 0>(g, eap::S(stream));
 }
 
+extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
+                                         const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask, float *out, eap_stream_t stream) {
+    return eap_so3_dense_product_steps_f32(dir, b, o, p, na, ks, rp, ldz, sigma, n_rows, planes, scale, pt, kr, mask, nullptr, out, stream);
+}
+
+// keys int32 [b,p]: the 16-row groups every point's list touches, one bit per group (see dense_keys_kernel) -- the sort key that makes the
+// mask block-sparse
+extern "C" int eap_so3_dense_point_keys(int b, int p, const uint32_t *memb, int32_t *keys, eap_stream_t stream) {
+    if (b <= 0 || p <= 0) return 0;
+    const long long total = (long long)b * p;
+    hipLaunchKernelGGL(dense_keys_kernel, dim3((unsigned)eap::cdiv(total, 256)), dim3(256), 0, eap::S(stream), total, memb, keys);
+    return eap::check_launch("so3_dense_point_keys");
+}
+
+// int32 words of the k-step lists of one direction: [b][column blocks of 256][k-steps + 1]
+extern "C" int64_t eap_so3_dense_steps_words(int b, int p, int ks, int rp, int dir) {
+    const int n = dir ? p : ks * rp, kd = dir ? ceil_to(ks * rp, KC_BK) : p;
+    return (int64_t)b * ((n + 255) / 256) * (kd / KC_BK + 1);
+}
+
+// the k-step lists of one direction from its mask table (eap_so3_dense_masks, same b, p, ks, rp, dir); skip = 0: every k-step is listed
+extern "C" int eap_so3_dense_steps(int b, int p, int ks, int rp, int dir, int skip, const int32_t *n_rows, const uint64_t *mask, int32_t *steps,
+                                   eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (!eap_so3_dense_supported(p, 4, ks, rp, 256) || b > 65535) return eap::bad_arg("so3_dense_steps: shape not taken");
+    const int n = dir ? p : ks * rp, kd = dir ? ceil_to(ks * rp, KC_BK) : p;
+    const int blocks_n = (n + 255) / 256, KS = kd / KC_BK;
+    if ((size_t)KS * sizeof(int) > 48 * 1024) return eap::bad_arg("so3_dense_steps: more than 12288 k-steps");
+    hipLaunchKernelGGL(dense_steps_kernel, dim3(blocks_n, b), dim3(256), sizeof(int) * (size_t)KS, eap::S(stream), KS, blocks_n, 4 * blocks_n, dir, ks, rp, skip,
+                       n_rows, reinterpret_cast<const unsigned *>(mask), steps);
+    return eap::check_launch("so3_dense_steps");
+}
+
 // psum, psq (may be null): float [o][b * ceil(p / 64)] partial sums of (y - y[0,o,0,0]) and of its square per 64-point chunk
 extern "C" int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, float *psum, float *psq, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (o > 65535 || b > 65535) return eap::bad_arg("so3_dense_untranspose: o, b <= 65535");
-    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p, nullptr,
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p, nullptr, nullptr,
                        yt, y, psum, psum ? psq : nullptr);
     return eap::check_launch("so3_dense_untranspose");
 }
@@ -934,7 +1059,19 @@ extern "C" int eap_so3_dense_untranspose_map_f32(int b, int o, int p, int na, in
                                                  eap_stream_t stream) {
     if (b <= 0) return 0;
     if (o > 65535 || b > 65535 || map == nullptr || p_dst <= 0) return eap::bad_arg("so3_dense_untranspose_map: o, b <= 65535, a map, p_dst > 0");
-    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p_dst, map,
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p_dst, map, nullptr,
                        yt, y, nullptr, nullptr);
     return eap::check_launch("so3_dense_untranspose_map");
+}
+
+// ... and with the channel moments of eap_so3_dense_untranspose_f32 (over the columns whose map entry is not negative); pivot_pos int32 [1]
+// (device): the column of cloud 0 that is point 0, so that the pivot is Y[0][o][0][0] as the BatchNorm behind it expects
+extern "C" int eap_so3_dense_untranspose_map_stats_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const int32_t *pivot_pos, const float *yt,
+                                                       float *y, float *psum, float *psq, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (o > 65535 || b > 65535 || map == nullptr || pivot_pos == nullptr || p_dst <= 0 || psum == nullptr || psq == nullptr)
+        return eap::bad_arg("so3_dense_untranspose_map_stats: o, b <= 65535, a map, the pivot column, both partial arrays");
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3(eap::cdiv(p, 64), o, b), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), o, p, na, p_dst, map,
+                       pivot_pos, yt, y, psum, psq);
+    return eap::check_launch("so3_dense_untranspose_map_stats");
 }

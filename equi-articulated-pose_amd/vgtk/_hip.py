@@ -510,18 +510,38 @@ def so3_dense_member(idx, rows, n_rows, n):
     return memb, flags
 
 
+# Occupancy-sorted query points (round 6): a cloud's query points are handed to the dense product sorted by WHICH 16-row groups of the
+# referenced rows their lists touch (eap_so3_dense_point_keys), and every 256-column block of the product runs only the k-steps in
+# which it generates a weight that is not masked out (eap_so3_dense_steps).  On the bench clouds 31 % (128 -> 512 layer) to 52 %
+# (64 -> 128) of the k-steps drop out; skipped steps would have added exact zeros, so the result is bit-equal to running them all
+# in the same point order.  The point order is internal: the backward reads dY through it as a column map, the forward's re-ordering
+# pass writes Y through it.  SORT_DENSE_POINTS = False: index order and every k-step, as round 5 (A/B runs, tests).
+SORT_DENSE_POINTS = os.environ.get('EAP_DENSE_SORT', '1') != '0'
+SKIP_DENSE_STEPS = os.environ.get('EAP_DENSE_SKIP', '1') != '0'
+lib.eap_so3_dense_steps_words.restype = ctypes.c_int64
+
+
 class DenseGeometry:
     """What the dense product needs besides its stored operand, for one neighbourhood of a batch of clouds WITHOUT pose
-    rotations: the lane masks of both directions (built on demand from the membership bits) and the two float4 tables of the
-    expanded weight, for the first rp referenced rows of every cloud."""
+    rotations: the lane masks of both directions (built on demand from the membership bits), the k-step lists of their column
+    blocks, and the two float4 tables of the expanded weight, for the first rp referenced rows of every cloud."""
 
-    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn, n_rows=None, row_rot=None):
+    def __init__(self, q_xyz, s_xyz, memb, rows, rp, rk, sigma, nn, n_rows=None, row_rot=None, sort=None):
         """row_rot float32 [b, rows.stride(0), 3, 3] (optional): one rotation per row slot applied to the kernel offsets -- the query
         points are ONE rigid part of a posed cloud (include/eap_hip.h: eap_so3_dense_tables_f32)."""
         b, p = memb.shape[:2]
         n = s_xyz.shape[2]
         na, ks, _ = rk.shape
         dev = memb.device
+        self.order = self.pivot_pos = None
+        if SORT_DENSE_POINTS if sort is None else sort:
+            keys = torch.empty(b, p, dtype=torch.int32, device=dev)
+            call('eap_so3_dense_point_keys', memb, b, p, _ptr(memb), _ptr(keys))
+            order = torch.sort(keys, dim=1, stable=True).indices                               # int64 [b,p]: column j of the product is point order[b, j]
+            q_xyz = q_xyz.gather(2, order[:, None, :].expand(b, 3, p)).contiguous()
+            memb = memb.gather(1, order[:, :, None].expand(b, p, memb.shape[2])).contiguous()
+            self.order = order.to(torch.int32).contiguous()
+            self.pivot_pos = (order[0] == 0).to(torch.int32).argmax().to(torch.int32).view(1)   # the column of cloud 0 that is point 0
         self.b, self.p, self.na, self.ks, self.rp, self.nn, self.memb, self.sigma = b, p, na, ks, int(rp), int(nn), memb, float(sigma)
         self.n_rows = n_rows                      # int32 [b] or None: the products stop at every cloud's own rows (include/eap_hip.h)
         p_pad, kd_pad = (p + 31) // 32 * 32, (ks * self.rp + 31) // 32 * 32
@@ -532,7 +552,7 @@ class DenseGeometry:
             raise RuntimeError('DenseGeometry: row_rot must be a contiguous float32 [b, rows.stride(0), 3, 3]')
         call('eap_so3_dense_tables_f32', memb, b, p, n, na, ks, self.rp, rows.stride(0), _F32(sigma), _ptr(q_xyz), _ptr(s_xyz), _ptr(rows),
              _ptr(rk), _ptr(row_rot), _ptr(self.centre), _ptr(self.pt), _ptr(self.kr))
-        self._masks = {}
+        self._masks, self._steps, self._composed = {}, {}, {}
 
     def mask(self, direction):
         m = self._masks.get(direction)
@@ -542,6 +562,35 @@ class DenseGeometry:
             call('eap_so3_dense_masks', m, self.b, self.p, self.ks, self.rp, int(direction), _ptr(self.memb), _ptr(m))
             self._masks[direction] = m
         return m
+
+    def steps(self, direction):
+        """int32 [b, column blocks, k-steps + 1] (count, then the k-steps a column block runs) or None (SKIP_DENSE_STEPS off: every k-step)."""
+        if not SKIP_DENSE_STEPS:
+            return None
+        st = self._steps.get(direction)
+        if st is None:
+            kd = (self.ks * self.rp + 31) // 32 * 32
+            blocks_n = ((self.p if direction else self.ks * self.rp) + 255) // 256
+            k_steps = (kd if direction else self.p) // 32
+            words = int(lib.eap_so3_dense_steps_words(self.b, self.p, self.ks, self.rp, int(direction)))
+            assert words == self.b * blocks_n * (k_steps + 1)
+            st = torch.empty(self.b, blocks_n, k_steps + 1, dtype=torch.int32, device=self.memb.device)
+            call('eap_so3_dense_steps', st, self.b, self.p, self.ks, self.rp, int(direction), 1, _ptr(self.n_rows), _ptr(self.mask(direction)), _ptr(st))
+            self._steps[direction] = st
+        return self._steps[direction]
+
+    def columns(self, col_map=None):
+        """The column map of a launch: this geometry's point order composed with the caller's map (int32 [b,p]; negative: padding) -> int32
+        [b,p] or None (index order, no map)."""
+        if self.order is None:
+            return col_map
+        if col_map is None:
+            return self.order
+        hit = self._composed.get(id(col_map))
+        if hit is None or hit[0] is not col_map:
+            hit = (col_map, col_map.gather(1, self.order.long()).contiguous())
+            self._composed = {id(col_map): hit}
+        return hit[1]
 
 
 def so3_dense_split(src, seg=0, seg_pitch=0, shape=None, mapped=False, n_rows=None, rowmax=None, colmap=None):
@@ -568,13 +617,17 @@ def dense_pitch(n):
     return (n + 127) // 128 * 128
 
 
-def _dense_executed_flops(geo, o, p):
-    """fp16 flops the product kernel executes for this geometry: 6 O P A K x (every cloud's own rows rounded to 16).  The per-cloud
-    row counts live on the device; they are read (a host wait) only while bench.py attributes launch times, else the batch-wide rp
-    is used (an upper bound nobody reads)."""
+def _dense_executed_flops(geo, o, p, direction):
+    """fp16 flops the product kernel executes for this geometry: 6 O A x 256 columns x 32 x (k-steps its column blocks run); without the
+    step lists 6 O P A K x (every cloud's own rows rounded to 16).  The counts live on the device; they are read (a host wait) only while
+    bench.py attributes launch times, else an upper bound nobody reads is returned."""
     rows = geo.rp * geo.b
-    if KERNEL_TIMES is not None and geo.n_rows is not None:
-        rows = sum(min((int(r) + 15) & ~15, geo.rp) for r in geo.n_rows.tolist())
+    if KERNEL_TIMES is not None:
+        st = geo.steps(direction)
+        if st is not None and st.shape[2] - 1 <= 512:
+            return 6.0 * o * geo.na * 256 * 32 * float(st[:, :, 0].sum().item())
+        if geo.n_rows is not None:
+            rows = sum(min((int(r) + 15) & ~15, geo.rp) for r in geo.n_rows.tolist())
     return 6.0 * o * p * geo.na * geo.ks * rows
 
 
@@ -585,13 +638,15 @@ def so3_dense_bwd(gy, geo, ldz=None, colmap=None, rowmax=False):
     rowmax: row maxima of gy somebody already took from the hint (None: none available; default: ask the hint)."""
     b, o, p, na = gy.shape
     ldz = na * geo.rp if ldz is None else int(ldz)
+    colmap = geo.columns(colmap)                                  # (the geometry's own point order: occupancy-sorted)
     scale, planes = so3_dense_split(gy, rowmax=take_rowmax_hint(gy) if rowmax is False else rowmax, colmap=colmap)
     if colmap is not None:
         p = colmap.shape[1]
     z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
-    call('eap_so3_dense_product_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
-         _ptr(geo.mask(0)), _ptr(z), tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': _dense_executed_flops(geo, o, p),
-                                        'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
+    call('eap_so3_dense_product_steps_f32', gy, 0, b, o, p, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
+         _ptr(geo.kr), _ptr(geo.mask(0)), _ptr(geo.steps(0)), _ptr(z),
+         tag={'flops': 2.0 * b * o * p * na * geo.ks * geo.nn, 'executed_f16_flops': _dense_executed_flops(geo, o, p, 0),
+              'shape': ('so3_dense', 0, b, o, p, na, geo.ks, geo.rp)})
     return z
 
 
@@ -605,21 +660,25 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None, out=None, col_map=None):
     ldg = geo.rp * na if ldg is None else int(ldg)
     scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg, shape=(b, o, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
     yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
-    call('eap_so3_dense_product_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
-         _ptr(geo.mask(1)), _ptr(yt), tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp),
-                                         'executed_f16_flops': _dense_executed_flops(geo, o, p), 'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
+    call('eap_so3_dense_product_steps_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
+         _ptr(geo.kr), _ptr(geo.mask(1)), _ptr(geo.steps(1)), _ptr(yt),
+         tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp), 'executed_f16_flops': _dense_executed_flops(geo, o, p, 1),
+              'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
     del planes
     if col_map is not None:
         if out is None or col_map.dtype != torch.int32 or tuple(col_map.shape) != (b, p) or not col_map.is_contiguous() or not out.is_contiguous():
             raise RuntimeError('so3_dense_fwd: col_map must be a contiguous int32 [b,p] and come with a contiguous out')
-        call('eap_so3_dense_untranspose_map_f32', g, b, o, p, na, out.shape[2], _ptr(col_map), _ptr(yt), _ptr(out))
+        call('eap_so3_dense_untranspose_map_f32', g, b, o, p, na, out.shape[2], _ptr(geo.columns(col_map)), _ptr(yt), _ptr(out))
         return out
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
     # the re-ordering pass also leaves the channel moments a BatchNorm right behind this layer starts with (its own pass otherwise)
     chunks = (p + 63) // 64
     ps = torch.empty(o, b * chunks, dtype=torch.float32, device=g.device)
     pq = torch.empty_like(ps)
-    call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y), _ptr(ps), _ptr(pq))
+    if geo.order is not None:                                     # columns in the geometry's point order: written through it
+        call('eap_so3_dense_untranspose_map_stats_f32', g, b, o, p, na, p, _ptr(geo.order), _ptr(geo.pivot_pos), _ptr(yt), _ptr(y), _ptr(ps), _ptr(pq))
+    else:
+        call('eap_so3_dense_untranspose_f32', g, b, o, p, na, _ptr(yt), _ptr(y), _ptr(ps), _ptr(pq))
     leave_stats_hint(y, (ps, pq))
     return y
 

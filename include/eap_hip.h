@@ -355,7 +355,21 @@ int eap_rows_scatter_f32(int b, int c, int n, int na, int rcap, int rows_ld, con
  *   eap_so3_dense_untranspose_f32   Yt [b,na,o,p] -> Y [b,o,p,na]; psum / psq (may be null) float [o, b ceil(p/64)]: partial sums of
  *                             y - y[0,o,0,0] and of its square, the moments of the BatchNorm that follows (eap_bn_stats_f32's pivot)
  *   eap_so3_dense_untranspose_map_f32   the same into a Y [b,o,p_dst,na] that several launches fill: column pp of cloud b is point
- *                             map[b,pp] (int32 [b,p]; negative: padding, dropped) -- the rigid parts of posed clouds, one launch each */
+ *                             map[b,pp] (int32 [b,p]; negative: padding, dropped) -- the rigid parts of posed clouds, one launch each
+ *   eap_so3_dense_untranspose_map_stats_f32   ... with the moments of eap_so3_dense_untranspose_f32 (columns whose map entry is >= 0);
+ *                             pivot_pos int32 [1] on the device: the column of cloud 0 that is point 0 (the pivot stays Y[0,o,0,0])
+ * Occupancy-sorted query points (round 6).  The reference's ball query keeps the first nsample hits in index order
+ * (grouping_cuda_kernel.cu:L68-113), so a point's list names rows of only 0.45-0.7 of a cloud's 16-row groups; with a cloud's query
+ * points sorted by WHICH groups they touch the 0/1 mask of the product is block-sparse and whole k-steps drop out:
+ *   eap_so3_dense_point_keys   memb [b,p,16] -> keys int32 [b,p], bit g = the list of p names a row slot of 16 g .. 16 g + 15; the host sorts
+ *                             a cloud's points by it and builds memb / pt / the masks in that order (the order is a column map for
+ *                             eap_so3_dense_split_f32 and eap_so3_dense_untranspose_map*_f32)
+ *   eap_so3_dense_steps_words / eap_so3_dense_steps   from the mask table of a direction: int32 [b][column blocks of 256][k-steps + 1] =
+ *                             count (>= 1) and the ascending k-steps in which the block generates a weight that is not masked out
+ *                             (skip = 0: every k-step; dir 1 with n_rows: of the cloud's prefix)
+ *   eap_so3_dense_product_steps_f32   eap_so3_dense_product_f32 whose column blocks run their listed k-steps only (steps may be null; lists
+ *                             longer than 512 k-steps are ignored: every k-step runs).  Skipped k-steps would have added exact zeros:
+ *                             bit-equal to running them all in the same point order.  so3conv/functional.py:L1221-1261 */
 int eap_so3_dense_supported(int p, int na, int ks, int rp, int o);
 int eap_so3_dense_form(int form);
 int eap_so3_dense_block_rows(int rows);      /* 0 (default): 256-row blocks where o % 256 == 0; 128: always 128-row blocks; -> old setting */
@@ -374,6 +388,15 @@ int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int 
 int eap_so3_dense_untranspose_f32(int b, int o, int p, int na, const float *yt, float *y, float *psum, float *psq, eap_stream_t stream);
 int eap_so3_dense_untranspose_map_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *yt, float *y,
                                       eap_stream_t stream);
+int eap_so3_dense_untranspose_map_stats_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const int32_t *pivot_pos, const float *yt,
+                                            float *y, float *psum, float *psq, eap_stream_t stream);
+int eap_so3_dense_point_keys(int b, int p, const uint32_t *memb, int32_t *keys, eap_stream_t stream);
+int64_t eap_so3_dense_steps_words(int b, int p, int ks, int rp, int dir);
+int eap_so3_dense_steps(int b, int p, int ks, int rp, int dir, int skip, const int32_t *n_rows, const uint64_t *mask, int32_t *steps,
+                        eap_stream_t stream);
+int eap_so3_dense_product_steps_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
+                                    const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask,
+                                    const int32_t *steps, float *out, eap_stream_t stream);
 
 /* ---- SO(3) intra convolution -------------------------------------------------------------- */
 

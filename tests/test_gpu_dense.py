@@ -154,7 +154,7 @@ def test_backward_product_matches_the_list_kernel(dev):
     ld = NA * rp + 40
     zp = torch.full((2, 256, KS, ld), 7.0, device=dev)
     from vgtk._hip import _ptr, _I64, _F32
-    sc, pl = _hip.so3_dense_split(gy)
+    sc, pl = _hip.so3_dense_split(gy, colmap=geo.columns())          # (the geometry's point order: occupancy-sorted)
     _hip.call('eap_so3_dense_product_f32', gy, 0, 2, 256, 512, NA, KS, rp, _I64(ld), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(pl), _ptr(sc), _ptr(geo.pt), _ptr(geo.kr),
               _ptr(geo.mask(0)), _ptr(zp))
     assert torch.equal(zp[..., :NA * rp].reshape(2, 256, KS, NA, rp), z) and float((zp[..., NA * rp:] - 7.0).abs().max()) == 0.0
@@ -445,3 +445,103 @@ def test_row_maxima_travel_from_the_batchnorm_backward_to_the_split(dev, monkeyp
     _hip.call('eap_bn_act_bwd_apply_f32', x, B, 128, _hip._I64(64 * NA), _hip._F32(0.01), _hip._ptr(gy), _hip._ptr(x), _hip._ptr(scale), _hip._ptr(shift),
               _hip._ptr(mean), _hip._ptr(invstd), _hip._ptr(k2), _hip._ptr(k3), _hip._ptr(plain))
     assert torch.equal(plain, gx)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# occupancy-sorted query points + skipped k-steps (round 6)
+# ------------------------------------------------------------------------------------------------------------------------
+def _group_membership(head, rp, P):
+    """[B, P, rp / 16] bool on the host: point p's list names a row of 16-row group g (from the membership words)."""
+    memb = head.memb.cpu().numpy().astype(np.uint32)                           # [B,P,16] words of 32 row slots
+    bits = ((memb[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(memb.shape[0], P, 512)[:, :, :rp]
+    return bits.reshape(bits.shape[0], P, rp // 16, 16).any(-1)
+
+
+@pytest.mark.parametrize('P,layer', [(1024, 2), (2048, 1)])
+def test_step_lists_name_exactly_the_nonempty_k_steps(dev, P, layer):
+    """eap_so3_dense_point_keys / eap_so3_dense_steps against a host computation from the membership bits: the sort keys, the point
+    order (stable sort by key), and for both directions the k-steps of every 256-column block in which some generated weight is not
+    masked out -- and that a worthwhile share of the k-steps IS empty on these clouds (the point of the exercise)."""
+    from vgtk import _hip
+    s = _setup(dev, 2, P, layer=layer)
+    head, geo, rp = _geometry(s, dev)
+    assert geo.order is not None
+    grp = _group_membership(head, rp, P)                                       # [B,P,G]
+    B, G = grp.shape[0], grp.shape[2]
+    keys = (grp.astype(np.int64) << np.arange(G, dtype=np.int64)).sum(-1)
+    keys = np.where(keys >= 2 ** 31, keys - 2 ** 32, keys)                     # (int32 order)
+    order = np.stack([np.argsort(keys[b], kind='stable') for b in range(B)])
+    assert np.array_equal(geo.order.cpu().numpy(), order)
+    assert int(geo.pivot_pos.item()) == int(np.nonzero(order[0] == 0)[0][0])
+    n_rows = head.n_rows.cpu().numpy()
+    sg = np.stack([grp[b][order[b]] for b in range(B)])                        # sorted points
+    total = kept = 0
+    # backward: k-steps of 32 points, column blocks of 256 dense indices (16 row slots x 24 kernel points per group)
+    st = geo.steps(0).cpu().numpy()
+    for b in range(B):
+        used = ((min(n_rows[b], rp) + 15) // 16 * 16) * KS
+        for bn in range(st.shape[1]):
+            d0, d1 = 256 * bn, min(256 * bn + 256, KS * rp) - 1
+            gs = np.arange(d0 // (16 * KS), d1 // (16 * KS) + 1)
+            want = np.nonzero(sg[b].reshape(P // 32, 32, G)[:, :, gs].any((1, 2)))[0]
+            want = want if len(want) else np.array([0])
+            n = st[b, bn, 0]
+            assert n == len(want) and np.array_equal(st[b, bn, 1:1 + n], want), (b, bn)
+            if d0 < used:
+                total += P // 32; kept += n
+    frac_b = kept / total
+    # forward: k-steps of 32 dense indices (two kernel points of one 16-row group), column blocks of 256 points
+    st = geo.steps(1).cpu().numpy()
+    total = kept = 0
+    for b in range(B):
+        for bn in range(st.shape[1]):
+            occ = sg[b][256 * bn:256 * bn + 256].any(0)                         # [G]
+            want = np.nonzero(np.repeat(occ, KS // 2))[0]
+            want = want if len(want) else np.array([0])
+            n = st[b, bn, 0]
+            assert n == len(want) and np.array_equal(st[b, bn, 1:1 + n], want), (b, bn)
+            total += ((min(n_rows[b], rp) + 15) // 16) * (KS // 2); kept += n
+    frac_f = kept / total
+    assert frac_b < 0.9 and frac_f < 0.95, (frac_b, frac_f)
+
+
+@pytest.mark.parametrize('o', [256, 128])
+def test_skipped_k_steps_contribute_exact_zeros(dev, o, monkeypatch):
+    """Both products with the k-step lists and with every k-step (same point order): bit-equal -- a skipped k-step multiplies the stored
+    operand by weights that are all exactly 0."""
+    from vgtk import _hip
+    s = _setup(dev, 2, 1024, layer=2 if o == 256 else 1)
+    head, geo, rp = _geometry(s, dev)
+    gen = torch.Generator(device=dev).manual_seed(31)
+    gy = torch.randn(2, o, 1024, NA, device=dev, generator=gen)
+    g = torch.randn(2, o, KS, rp * NA, device=dev, generator=gen)
+    assert geo.steps(0) is not None and int(geo.steps(0)[:, :, 0].sum()) < geo.steps(0).shape[0] * geo.steps(0).shape[1] * (geo.steps(0).shape[2] - 1)
+    z1, y1 = _hip.so3_dense_bwd(gy, geo), _hip.so3_dense_fwd(g, geo, 1024)
+    monkeypatch.setattr(_hip, 'SKIP_DENSE_STEPS', False)
+    assert geo.steps(0) is None
+    z0, y0 = _hip.so3_dense_bwd(gy, geo), _hip.so3_dense_fwd(g, geo, 1024)
+    assert torch.equal(z1, z0) and torch.equal(y1, y0)
+
+
+def test_sorted_points_against_index_order(dev):
+    """The same products with the query points in index order (round 5's form): the forward is bit-equal (a column's k-steps run in the
+    same order either way), the backward -- whose contraction runs over the points -- to rounding; the channel moments the re-ordering
+    pass leaves for the BatchNorm are those of the index-order pass to rounding, with the same pivot."""
+    from vgtk import _hip
+    s = _setup(dev, 2, 1024, layer=2)
+    head, geo, rp = _geometry(s, dev)
+    xyz = s['xyz']
+    geo0 = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, s['rk'], s['sigma'], NN, head.n_rows, sort=False)
+    assert geo0.order is None and geo.order is not None
+    gen = torch.Generator(device=dev).manual_seed(37)
+    gy = torch.randn(2, 256, 1024, NA, device=dev, generator=gen)
+    g = torch.randn(2, 256, KS, rp * NA, device=dev, generator=gen)
+    y1 = _hip.so3_dense_fwd(g, geo, 1024)
+    h1 = _hip.take_stats_hint(y1)
+    y0 = _hip.so3_dense_fwd(g, geo0, 1024)
+    h0 = _hip.take_stats_hint(y0)
+    assert torch.equal(y1, y0)
+    for a_, b_ in zip(h1, h0):
+        assert torch.allclose(a_.sum(1, dtype=torch.float64), b_.sum(1, dtype=torch.float64), rtol=1e-5, atol=1e-3)
+    z1, z0 = _hip.so3_dense_bwd(gy, geo), _hip.so3_dense_bwd(gy, geo0)
+    assert float((z1 - z0).abs().max()) < 2e-6 * float(z0.abs().max())

@@ -41,25 +41,37 @@ TRIM = os.environ.get('TRIM', '1') != '0'
 _hip.lib.eap_so3_dense_block_rows(int(os.environ.get('ROWS', 0)))
 gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
 g = torch.randn(B, o, KS, rp * NA, device=dev, generator=gen)
-for form in [int(f) for f in os.environ.get('FORMS', '1,0').split(',')]:
+SORT = os.environ.get('SORT', '1') != '0'       # occupancy-sorted query points + k-step lists (round 6); 0: index order, every k-step
+for form in [int(f) for f in os.environ.get('FORMS', '1').split(',')]:
     _hip.lib.eap_so3_dense_form(form)
-    geo = _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, rk, sigma, NN)
-    t_tab, _ = timed(lambda: _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, rk, sigma, NN))
+    mk = lambda: _hip.DenseGeometry(xyz, xyz, head.memb, head.rows, rp, rk, sigma, NN, head.n_rows if TRIM else None, sort=SORT)
+    geo = mk()
+    t_tab, _ = timed(mk)
     geo.mask(0); geo.mask(1)
-    t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(gy))
+    st0, st1 = (geo.steps(0), geo.steps(1)) if SORT else (None, None)
+    if SORT:
+        t_steps, _ = timed(lambda: (geo._masks.clear(), geo._steps.clear(), geo.mask(0), geo.steps(0), geo.mask(1), geo.steps(1)))
+        k0, k1 = st0[:, :, 0].float(), st1[:, :, 0].float()
+        print(f'masks + step lists of both directions {t_steps:.2f} ms; k-steps kept: backward {float(k0.mean()) / (st0.shape[2] - 1):.3f}, forward {float(k1.mean()) / (st1.shape[2] - 1):.3f} of all')
+    cm = geo.columns()
+    t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(gy, colmap=cm))
     z = torch.empty(B, o, KS, NA, rp, device=dev)
-    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', gy, 0, B, o, P, NA, KS, rp, _hip._I64(NA * rp), _hip._F32(sigma), _hip._ptr(head.n_rows if TRIM else None), _hip._ptr(planes), _hip._ptr(scale),
-                                        _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(0)), _hip._ptr(z)))
+    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_steps_f32', gy, 0, B, o, P, NA, KS, rp, _hip._I64(NA * rp), _hip._F32(sigma), _hip._ptr(geo.n_rows), _hip._ptr(planes), _hip._ptr(scale),
+                                        _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(0)), _hip._ptr(st0), _hip._ptr(z)))
     fl = 6.0 * B * o * P * NA * KS * rp
-    print(f'form {form} backward: tables {t_tab:.2f} ms, split {t_split:.2f} ms, product {t_prod:.2f} ms = {fl / t_prod / 1e9:.0f} TFLOP/s fp16 '
-          f'({fl / 3 / t_prod / 1e9:.0f} fp32-equivalent), algorithmic {2.0 * B * o * P * NA * KS * NN / t_prod / 1e9:.0f} TFLOP/s')
+    print(f'form {form} sort {int(SORT)} backward: tables {t_tab:.2f} ms, split {t_split:.2f} ms, product {t_prod:.2f} ms, algorithmic {2.0 * B * o * P * NA * KS * NN / t_prod / 1e9:.0f} TFLOP/s '
+          f'(x3 / fp16 peak {3 * 2.0 * B * o * P * NA * KS * NN / t_prod / 1e9 / 2500:.3f})')
     del planes, scale, z
-    t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(g, seg=rp, seg_pitch=rp * NA, shape=(B, o, KS * rp, NA), mapped=True, n_rows=head.n_rows if TRIM else None))
+    t_split, (scale, planes) = timed(lambda: _hip.so3_dense_split(g, seg=rp, seg_pitch=rp * NA, shape=(B, o, KS * rp, NA), mapped=True, n_rows=geo.n_rows))
     yt = torch.empty(B, NA, o, P, device=dev)
-    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_f32', g, 1, B, o, P, NA, KS, rp, _hip._I64(0), _hip._F32(sigma), _hip._ptr(head.n_rows if TRIM else None), _hip._ptr(planes), _hip._ptr(scale),
-                                        _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(1)), _hip._ptr(yt)))
+    t_prod, _ = timed(lambda: _hip.call('eap_so3_dense_product_steps_f32', g, 1, B, o, P, NA, KS, rp, _hip._I64(0), _hip._F32(sigma), _hip._ptr(geo.n_rows), _hip._ptr(planes), _hip._ptr(scale),
+                                        _hip._ptr(geo.pt), _hip._ptr(geo.kr), _hip._ptr(geo.mask(1)), _hip._ptr(st1), _hip._ptr(yt)))
     y = torch.empty(B, o, P, NA, device=dev)
-    t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_f32', g, B, o, P, NA, _hip._ptr(yt), _hip._ptr(y), None, None))
-    print(f'form {form} forward:  split {t_split:.2f} ms, product {t_prod:.2f} ms = {fl / t_prod / 1e9:.0f} TFLOP/s fp16, untranspose {t_un:.2f} ms')
+    ps = torch.empty(o, B * ((P + 63) // 64), device=dev); pq = torch.empty_like(ps)
+    if SORT:
+        t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_map_stats_f32', g, B, o, P, NA, P, _hip._ptr(geo.order), _hip._ptr(geo.pivot_pos), _hip._ptr(yt), _hip._ptr(y), _hip._ptr(ps), _hip._ptr(pq)))
+    else:
+        t_un, _ = timed(lambda: _hip.call('eap_so3_dense_untranspose_f32', g, B, o, P, NA, _hip._ptr(yt), _hip._ptr(y), _hip._ptr(ps), _hip._ptr(pq)))
+    print(f'form {form} sort {int(SORT)} forward:  split {t_split:.2f} ms, product {t_prod:.2f} ms, untranspose (+ moments) {t_un:.2f} ms')
     del planes, scale, yt, y
 _hip.lib.eap_so3_dense_form(1)
