@@ -609,6 +609,9 @@ FORWARD_LOG = None       # the same for the forward: {'channels', 'dense': the d
 # shapes are taken (tests).
 DENSE_MODE = os.environ.get('EAP_DENSE', 'auto')
 DENSE_ROW_FACTOR = 5.0
+# the forward at widths that fill 128-row blocks only (the 64 -> 128 layer): with every k-step it tied with grouping + contraction
+# (round 5: 9.0 against 9.1 ms); with the empty k-steps skipped (round 6) it is decided by measurement, profiles/r06_dense_forward_128.txt
+DENSE_FWD_NARROW = os.environ.get('EAP_DENSE_FWD_128', '1') != '0'
 
 
 def _dense_rows(rcap, n):
@@ -629,7 +632,7 @@ def _dense_wanted(head, o, p, na, ks, nn, n):
         return rp, True
     if rp > DENSE_ROW_FACTOR * nn:
         return 0, False
-    return rp, o % 256 == 0
+    return rp, (o % 256 == 0) or DENSE_FWD_NARROW
 
 
 def _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz=None):
@@ -833,7 +836,7 @@ class _InterConv(torch.autograd.Function):
         # (without gradients only the forward can use the product, and 'auto' takes it at o % 256 == 0 only: no probe -- and no host wait --
         # for an inference call it could not change)
         if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0)
-                and (needs_grad or o % 256 == 0 or DENSE_MODE == 'force')
+                and (needs_grad or o % 256 == 0 or DENSE_FWD_NARROW or DENSE_MODE == 'force')
                 and _hip.so3_dense_supported(p, na, ks, 16, o)):
             probe = (geometry[2], geometry[3])
             if (DENSE_PARTS and geometry[3] is not None and geometry[0] is geometry[1] and geometry[2] is geometry[3] and p == n):
