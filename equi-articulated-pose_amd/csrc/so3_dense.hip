@@ -495,22 +495,17 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int nb, int o_to
     }
     red[0][t] = s; red[1][t] = q;
     __syncthreads();
-    if (map != nullptr) {
-        float *row = y + ((size_t)b * o_total + o) * p_dst * na;
-        for (int i = t; i < np * na; i += 256) {
-            const int pp = i / na, a = i - pp * na;
-            const int q = map[(size_t)b * p + p0 + pp];
-            if ((unsigned)q < (unsigned)p_dst) row[(size_t)q * na + a] = tile[a * 65 + pp];
-        }
-        if (psum == nullptr) return;                                       // (block-uniform)
-    } else {
-        float *dst = y + (((size_t)b * o_total + o) * p + p0) * na;
-        for (int i = t; i < np * na; i += 256) {
-            const int pp = i / na, a = i - pp * na;
-            dst[i] = tile[a * 65 + pp];
-        }
-        if (psum == nullptr) return;
+    // 16-byte stores: a row of Y is na floats = na / 4 pieces (na % 4 == 0); mapped rows are scattered, 240 bytes each
+    const int nq = na >> 2;
+    float *rows_y = y + ((size_t)b * o_total + o) * (size_t)(map ? p_dst : p) * na;
+    for (int i = t; i < np * nq; i += 256) {
+        const int pp = i / nq, a4 = i - pp * nq;
+        const int q = map ? map[(size_t)b * p + p0 + pp] : p0 + pp;
+        if (map != nullptr && (unsigned)q >= (unsigned)p_dst) continue;
+        const float *src = tile + (4 * a4) * 65 + pp;
+        *reinterpret_cast<f32x4 *>(rows_y + (size_t)q * na + 4 * a4) = (f32x4){src[0], src[65], src[130], src[195]};
     }
+    if (psum == nullptr) return;                                           // (block-uniform)
     for (int h = 128; h > 0; h >>= 1) {                                    // (fixed order: bit-reproducible)
         if (t < h) { red[0][t] += red[0][t + h]; red[1][t] += red[1][t + h]; }
         __syncthreads();

@@ -291,15 +291,17 @@ def _quat_rot(rng, n):
                      2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(n, 3, 3).astype(np.float32)
 
 
-@pytest.mark.parametrize('o,mode', [(256, 'force'), (128, 'auto')])
-def test_one_rotation_per_rigid_part_runs_the_dense_product_per_part(dev, monkeypatch, o, mode):
+@pytest.mark.parametrize('o,mode,narrow', [(256, 'force', True), (128, 'auto', False), (128, 'auto', True)])
+def test_one_rotation_per_rigid_part_runs_the_dense_product_per_part(dev, monkeypatch, o, mode, narrow):
     """Articulated input: every point carries the rotation of its rigid part (2 parts in one cloud, 3 of very different sizes in
     another, 1 in the third; arbitrary rotations, so the relative rotation across a joint rotates the offsets AND selects a real
     anchor permutation: so3conv/functional.py:L1112-1160).  The dense product runs once per part slot (vgtk/so3conv/functional.py
     _PartsDense); y, dF, dW against the permuted list kernels (pinned by inter_pose_artmode.npz / inter_pose_perm.npz) to the bars
-    of the identity-pose comparison.  O = 128: list-kernel forward (bit-equal), per-part dense backward."""
+    of the identity-pose comparison.  O = 128 with DENSE_FWD_NARROW off (round 5's decision): list-kernel forward (bit-equal),
+    per-part dense backward; on (the default since the empty k-steps are skipped): the forward runs the product too."""
     import synth_clouds
     import vgtk.so3conv.functional as L
+    monkeypatch.setattr(L, 'DENSE_FWD_NARROW', narrow)
     B, P, c = 3, 512, 32
     _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
     xyz_np, lab_np, _ = synth_clouds.laptop_batch(81, B, P)
@@ -324,7 +326,7 @@ def test_one_rotation_per_rigid_part_runs_the_dense_product_per_part(dev, monkey
     y1, gF1, gW1, log1, y1n = _layer_run(dev, monkeypatch, mode, xyz, pose, feats0, W0, c, o, radius, sigma)
     assert [r['regime'] for r in log1] == ['dense rows'] and log1[0].get('parts') == 3 and log0[0]['regime'] != 'dense rows'
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-    if o == 128:
+    if o == 128 and not narrow:
         assert torch.equal(y1, y0)
     else:
         assert rel(y1, y0) < 2e-5 and torch.equal(y1n, y1)
@@ -338,10 +340,13 @@ def test_one_rotation_per_rigid_part_runs_the_dense_product_per_part(dev, monkey
     assert rel(y2, y3) < 2e-5 and rel(gF2, gF3) < 2e-5 and rel(gW2, gW3) < 5e-5
 
 
-def test_narrow_layer_takes_the_dense_backward_only(dev, monkeypatch):
-    """O = 128 in 'auto' mode: the forward stays on grouping + contraction (bit-equal to DENSE_MODE 'off'), the backward takes the
-    dense product on 128-row blocks."""
+@pytest.mark.parametrize('narrow', [False, True])
+def test_narrow_layer_takes_the_dense_backward_only(dev, monkeypatch, narrow):
+    """O = 128 in 'auto' mode.  DENSE_FWD_NARROW off (round 5's decision): the forward stays on grouping + contraction (bit-equal to
+    DENSE_MODE 'off'), the backward takes the dense product on 128-row blocks; on (the default of round 6): both directions take it."""
     import synth_clouds
+    import vgtk.so3conv.functional as L
+    monkeypatch.setattr(L, 'DENSE_FWD_NARROW', narrow)
     B, P, c, o = 2, 512, 32, 128
     _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
     xyz = torch.from_numpy(synth_clouds.laptop_batch(51, B, P)[0]).to(dev)
@@ -351,8 +356,11 @@ def test_narrow_layer_takes_the_dense_backward_only(dev, monkeypatch):
     y0, gF0, gW0, log0, _ = _layer_run(dev, monkeypatch, 'off', xyz, None, feats0, W0, c, o, radius, sigma)
     y1, gF1, gW1, log1, y1n = _layer_run(dev, monkeypatch, 'auto', xyz, None, feats0, W0, c, o, radius, sigma)
     assert [r['regime'] for r in log1] == ['dense rows'] and log0[0]['regime'] == 'inverse lists'
-    assert torch.equal(y1, y0) and torch.equal(y1n, y0)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    if narrow:
+        assert rel(y1, y0) < 2e-5 and torch.equal(y1n, y1)
+    else:
+        assert torch.equal(y1, y0) and torch.equal(y1n, y0)
     assert rel(gF1, gF0) < 2e-5 and rel(gW1, gW0) < 5e-5
 
 
