@@ -72,8 +72,8 @@ class Backbone(nn.Module):
         feats = sptk.get_occupancy_features(xyz.transpose(1, 2), NA, False)
         x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
         for conv, norm in zip(self.convs, self.norms):
-            _, _, _, x = conv(x)
-            x = zptk.SphericalPointCloudPose(x.xyz, norm(x.feats), x.anchors, x.pose)
+            # `x = conv(x); feat = relu(norm(x.feats))` (SPConvNets/utils/base_so3poseconv.py:L205-222) through the block-layer helper
+            _, _, _, x = sptk.conv_norm_act(conv, norm, x)
         return x.feats
 
     def hypotheses(self, feats, pooled=None):

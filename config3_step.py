@@ -41,8 +41,8 @@ class InterBackbone(nn.Module):
         import vgtk.spconv as zptk
         x = zptk.SphericalPointCloudPose(xyz, sptk.get_occupancy_features(xyz.transpose(1, 2), NA, False), None, pose)
         for conv, norm in zip(self.convs, self.norms):
-            _, _, _, x = conv(x)
-            x = zptk.SphericalPointCloudPose(x.xyz, norm(x.feats), x.anchors, x.pose)
+            # `x = conv(x); feat = relu(norm(x.feats))` (SPConvNets/utils/base_so3poseconv.py:L205-222) through the block-layer helper
+            _, _, _, x = sptk.conv_norm_act(conv, norm, x)
         return x.feats
 
 

@@ -238,6 +238,62 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_rowmax_kernel(int c, lon
     }
 }
 
+// The backward's reduction pass when the layer kept its OUTPUT y' = leaky(gamma xhat + beta) instead of its input (the conv + BatchNorm
+// node of vgtk/so3conv/functional.py: the pre-activation is recovered from y', leaky_relu with a positive slope being invertible):
+//     pre = y' > 0 ? y' : y' / slope,  xhat = (pre - beta) / gamma,  g = y' > 0 ? dy' : slope dy'
+// -> partials of sum(g) and sum(g xhat) per block at [(c B + b) nblk + block] (reduced in a fixed order by the caller), and per (cloud,
+// channel, anchor) the largest |g| and |xhat| (gmax, xmax [b, c, na]: float bit patterns, zero-initialised here; unsigned maximum = float
+// maximum, order-independent) -- from them the caller bounds the rows of gx = k1 g - k2 - k3 xhat for the stored-operand split that forms gx
+// on the way in (csrc/so3_dense.hip dense_split_kernel<true>).  Rows are [points][na], na a multiple of 4; thread t walks ONE anchor quad.
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_fromy_kernel(int c, long n4, int nq, int nblk, float slope, float inv_slope, const float4 *__restrict__ gy,
+                                                                      const float4 *__restrict__ y, const float *__restrict__ beta,
+                                                                      const float *__restrict__ inv_gamma, float *__restrict__ pg, float *__restrict__ pgx,
+                                                                      unsigned *__restrict__ gmax, unsigned *__restrict__ xmax) {
+    __shared__ unsigned s_max[256][8];
+    const int ci = blockIdx.y, bi = blockIdx.z, t = threadIdx.x;
+    const int T = nq * (256 / nq);
+    const float be = beta[ci], ig = inv_gamma[ci];
+    const size_t r0 = ((size_t)bi * c + ci) * (size_t)n4;
+    const long base = (long)blockIdx.x * RM_PIECES * T;
+    float s = 0.f, q = 0.f;
+    unsigned mg[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+    if (t < T) {
+        float4 g[RM_PIECES], a[RM_PIECES];
+#pragma unroll
+        for (int v = 0; v < RM_PIECES; ++v) {
+            const long i = base + (long)v * T + t;
+            if (i < n4) { g[v] = gy[r0 + i]; a[v] = y[r0 + i]; }
+        }
+#pragma unroll
+        for (int v = 0; v < RM_PIECES; ++v) {
+            const long i = base + (long)v * T + t;
+            if (i < n4) {
+                const float gv[4] = {g[v].x, g[v].y, g[v].z, g[v].w}, yv[4] = {a[v].x, a[v].y, a[v].z, a[v].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pos = yv[e] > 0.f;
+                    const float gg = pos ? gv[e] : gv[e] * slope, xh = ((pos ? yv[e] : yv[e] * inv_slope) - be) * ig;
+                    s += gg;
+                    q = fmaf(gg, xh, q);
+                    mg[e] = max(mg[e], __float_as_uint(gg) & 0x7fffffffu);
+                    mx[e] = max(mx[e], __float_as_uint(xh) & 0x7fffffffu);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s_max[t][e] = mg[e]; s_max[t][4 + e] = mx[e]; }
+    const size_t o = ((size_t)ci * gridDim.z + bi) * nblk + blockIdx.x;
+    block_reduce2(s, q, pg + o, pgx + o);                       // (its __syncthreads also publishes s_max)
+    if (t < 4 * nq) {
+        unsigned vg = 0, vx = 0;
+        for (int u = t >> 2; u < T; u += nq) { vg = max(vg, s_max[u][t & 3]); vx = max(vx, s_max[u][4 + (t & 3)]); }
+        const size_t at = ((size_t)bi * c + ci) * (4 * nq) + t;
+        if (vg) atomicMax(gmax + at, vg);
+        if (vx) atomicMax(xmax + at, vx);
+    }
+}
+
 inline int nseg_of(long n) { return (int)((n + SEG - 1) / SEG); }
 inline bool ok_dims(int b, int c, long n) { return b > 0 && c > 0 && n > 0 && c <= 65535 && b <= 65535; }
 
@@ -308,6 +364,31 @@ extern "C" int eap_bn_act_bwd_apply_rowmax_f32(int b, int c, int64_t n, int na, 
                        c, n4, nq, slope, reinterpret_cast<const float4 *>(gy), reinterpret_cast<const float4 *>(x), scale, shift, mean, invstd, k2, k3,
                        reinterpret_cast<float4 *>(gx), rowmax);
     return eap::check_launch("bn_act_bwd_apply_rowmax");
+}
+
+// blocks per (cloud, channel) row of eap_bn_act_bwd_reduce_fromy_f32: the partial arrays are [c][b * blocks]
+extern "C" int eap_bn_act_fromy_blocks(int64_t n, int na) {
+    if (na <= 0 || (na & 3) != 0 || na > 256) return 0;
+    const int nq = na / 4, T = nq * (256 / nq);
+    const long n4 = (long)(n / 4);
+    return (int)((n4 + (long)RM_PIECES * T - 1) / ((long)RM_PIECES * T));
+}
+
+// see bn_act_bwd_reduce_fromy_kernel: gy, y [b,c,n] with rows [points][na]; beta, inv_gamma [c]; pg, pgx float [c][b * eap_bn_act_fromy_blocks(n, na)];
+// gmax, xmax uint32 [b,c,na].  SPConvNets/utils/base_so3poseconv.py:L214-221 (autograd of norm + relu).
+extern "C" int eap_bn_act_bwd_reduce_fromy_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *y, const float *beta,
+                                               const float *inv_gamma, float *pg, float *pgx, uint32_t *gmax, uint32_t *xmax, eap_stream_t stream) {
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!ok_dims(b, c, n) || na <= 0 || (na & 3) != 0 || na > 256 || n % na != 0 || !(slope > 0.f) ||
+        ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y)) & 15) != 0)
+        return eap::bad_arg("bn_act_bwd_reduce_fromy: rows of [points][na], na a multiple of 4 up to 256, 16-byte aligned tensors, a positive slope");
+    hipStream_t s = eap::S(stream);
+    if (int e = eap::hip_fail(hipMemsetAsync(gmax, 0, sizeof(uint32_t) * (size_t)b * c * na, s), "bn_act_bwd_reduce_fromy memset")) return e;
+    if (int e = eap::hip_fail(hipMemsetAsync(xmax, 0, sizeof(uint32_t) * (size_t)b * c * na, s), "bn_act_bwd_reduce_fromy memset")) return e;
+    const int nq = na / 4, nblk = eap_bn_act_fromy_blocks(n, na);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_fromy_kernel, dim3((unsigned)nblk, c, b), dim3(256), 0, s, c, (long)(n / 4), nq, nblk, slope, 1.0f / slope,
+                       reinterpret_cast<const float4 *>(gy), reinterpret_cast<const float4 *>(y), beta, inv_gamma, pg, pgx, gmax, xmax);
+    return eap::check_launch("bn_act_bwd_reduce_fromy");
 }
 
 // ---- per-cloud statistics over a point subset (the pose heads' batched per-cloud calls) ---------------------------

@@ -384,23 +384,24 @@ __global__ __launch_bounds__(256) void dense_scale_kernel(long long total, int m
 // mapped (the forward's G, seg = rp, l = ks rp): element l of a row is the pair (k, r) with DENSE INDEX l, found at segment k,
 // position r; k-blocks past the cloud's own prefix (n_rows) are not written -- the product never reads them.
 // colmap: as dense_rowmax_kernel's (the columns of dY that are one rigid part's query points)
+// BN (template): the operand is the gradient BEHIND a training-mode BatchNorm + leaky_relu (csrc/bn_act.hip), formed here from the
+// gradient in front of it (T = dL/dy') and the activated output Y2 = y' itself instead of being written out and read back:
+//     pre = y' > 0 ? y' : y' / slope,  xhat = (pre - beta) / gamma,  g = y' > 0 ? dy' : slope dy',  gx = k1 g - k2 - k3 xhat
+// per row (= channel) coefficients bn[0..4][m] = k1, k2, k3, beta, 1 / gamma (k1 = gamma invstd, k2 = k1 mean(g), k3 = k1 mean(g xhat)).
+// The pre-activation is recovered from the OUTPUT (leaky_relu with a positive slope is invertible), so the layer keeps no copy of
+// the conv output for its backward.  SPConvNets/utils/base_so3poseconv.py:L214-221.
+struct SplitBn { const f32x4 *Y2; const float *coef; float slope, inv_slope; };
+template <bool BN>
 __global__ __launch_bounds__(256) void dense_split_kernel(int nb, int m, int l, int na, int kb_total, int seg, long long seg_pitch4, int mapped,
                                                           const int32_t *__restrict__ n_rows, const int32_t *__restrict__ colmap,
                                                           const f32x4 *__restrict__ T, const float *__restrict__ scale2,
-                                                          u32x4 *__restrict__ planes) {
-    // block -> (k-block kb, row tile mt, cloud b): all k-blocks of one (mt, b) on ONE XCD (block id % 8) -- through a column map a
-    // k-block reads 16 scattered 240-byte point rows per operand row, and the 128-byte lines they share with their neighbours in memory
-    // are wanted by other k-blocks of the same (mt, b): in the same L2 they are fetched once
+                                                          u32x4 *__restrict__ planes, SplitBn bn) {
+    // block -> (k-block kb fastest, row tile mt, cloud b).  (Measured and dropped: all k-blocks of one (mt, b) on one XCD, so that the
+    // partial lines a column map's scattered 240-byte rows share meet in one L2 -- 3.16 -> 3.56 ms unmapped, 3.35 -> 3.72 mapped.)
     const int t = threadIdx.x;
-    int b, mt, kb;
-    {
-        const int mts = m >> 5;
-        const long long groups = (long long)mts * nb, id = blockIdx.x, full = groups / 8 * 8;
-        long long grp;
-        if (id < full * kb_total) { const long long slot = id >> 3; grp = slot / kb_total * 8 + (id & 7); kb = (int)(slot % kb_total); }
-        else { const long long r = id - full * kb_total; grp = full + r / kb_total; kb = (int)(r % kb_total); }
-        b = (int)(grp / mts); mt = (int)(grp - (long long)b * mts);
-    }
+    const int mts = m >> 5;
+    const int kb = (int)(blockIdx.x % (unsigned)kb_total), grp_ = (int)(blockIdx.x / (unsigned)kb_total), mt = grp_ % mts, b = grp_ / mts;
+    (void)nb;
     const int nq = na >> 2, RG = 256 / nq;                      // rows per pass
     const int aq = t % nq, rr = t / nq;
     if (rr >= RG) return;
@@ -409,13 +410,15 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int nb, int m, int l, 
     // item = (row i, k half kg); two items per round: sixteen independent 16-byte loads in flight per thread
     for (int it0 = rr; it0 < 64; it0 += 2 * RG) {
         f32x4 q[2][8];
+        f32x4 q2[BN ? 2 : 1][BN ? 8 : 1];
         int rowv[2], lanef[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int it = min(it0 + u * RG, 63);
             const int i = it & 31, kg = it >> 5, row = 32 * mt + i, l0 = 16 * kb + 8 * kg;
             rowv[u] = row; lanef[u] = i + 32 * kg;
-            const f32x4 *src = T + ((size_t)b * m + row) * (colmap ? (size_t)1 : (size_t)nseg) * seg_pitch4 + aq;
+            const size_t row_off = ((size_t)b * m + row) * (colmap ? (size_t)1 : (size_t)nseg) * seg_pitch4 + aq;
+            const f32x4 *src = T + row_off;
             int sg = l0 / seg, sr = l0 - sg * seg;                // segment and position of element l0 + e
             if (mapped) dense_kr(l0, nseg, sg, sr);               // (8 consecutive dense indices: one kernel point, 8 consecutive slots)
             if (colmap != nullptr) {
@@ -427,12 +430,47 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int nb, int m, int l, 
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) q[u][e] = ci[e] >= 0 ? src[(size_t)ci[e] * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (BN) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) q2[u][e] = ci[e] >= 0 ? bn.Y2[row_off + (size_t)ci[e] * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    q[u][e] = (l0 + e < l) ? src[(size_t)sg * seg_pitch4 + (size_t)sr * nq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const bool in = l0 + e < l;
+                    const size_t at = (size_t)sg * seg_pitch4 + (size_t)sr * nq;
+                    q[u][e] = in ? src[at] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (BN) q2[u][e] = in ? bn.Y2[row_off + at] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (++sr == seg) { sr = 0; ++sg; }
                 }
+            }
+        }
+        if constexpr (BN) {
+            // columns that do not exist (map < 0, past l) must stay exact zeros: their y' reads as 0 above, which alone would give -k2
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = min(it0 + u * RG, 63);
+                const int l0 = 16 * kb + 8 * (it >> 5);
+                const float k1 = bn.coef[rowv[u]], k2 = bn.coef[m + rowv[u]], k3 = bn.coef[2 * m + rowv[u]], be = bn.coef[3 * m + rowv[u]], ig = bn.coef[4 * m + rowv[u]];
+                int live = 0;                                   // bit e: element e of this item exists
+                if (colmap != nullptr) {
+                    if (l0 < l) {
+                        const int4 c0 = *reinterpret_cast<const int4 *>(colmap + (size_t)b * l + l0), c1 = *reinterpret_cast<const int4 *>(colmap + (size_t)b * l + l0 + 4);
+                        live = (c0.x >= 0) | (c0.y >= 0) << 1 | (c0.z >= 0) << 2 | (c0.w >= 0) << 3 | (c1.x >= 0) << 4 | (c1.y >= 0) << 5 | (c1.z >= 0) << 6 | (c1.w >= 0) << 7;
+                    }
+                } else {
+                    for (int e = 0; e < 8; ++e) live |= (l0 + e < l) << e;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float yv = q2[u][e][j], gv = q[u][e][j];
+                        const bool pos = yv > 0.f;
+                        const float gg = pos ? gv : gv * bn.slope, pre = pos ? yv : yv * bn.inv_slope;
+                        const float gx = fmaf(gg, k1, -k2) - ((pre - be) * ig) * k3;
+                        q[u][e][j] = ((live >> e) & 1) ? gx : 0.f;
+                    }
             }
         }
 #pragma unroll
@@ -462,22 +500,15 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int nb, int m, int l, 
 __global__ __launch_bounds__(256) void dense_untranspose_kernel(int nb, int o_total, int p, int na, int p_dst, const int32_t *__restrict__ map,
                                                                 const int32_t *__restrict__ pivot_pos,
                                                                 const float *__restrict__ yt, float *__restrict__ y,
-                                                                float *__restrict__ psum, float *__restrict__ psq) {
+                                                                float *__restrict__ psum, float *__restrict__ psq,
+                                                                const float *__restrict__ bn_scale = nullptr, const float *__restrict__ bn_shift = nullptr,
+                                                                float slope = 1.f) {
     extern __shared__ float tile[];
     __shared__ float red[2][256];
-    // block -> (chunk of 64 columns, o, b): all chunks of one (o, b) run on ONE XCD (block id % 8), eight (o, b) pairs side by side.  With
-    // a column map a chunk writes 64 SCATTERED 240-byte rows of Y[b][o]; the rows' shared 128-byte lines are completed by other
-    // chunks of the same (o, b) -- in the same L2 they merge before they leave for memory (chunks dealt round-robin to the XCDs
-    // sent every line out in pieces: 3.45 ms against 2.08 for the unmapped pass at 8 x 512 x 4096 x 60)
+    // block -> (chunk of 64 columns fastest, o, b).  (An XCD-owning map -- all chunks of one (o, b) in one L2 -- did not help the mapped
+    // pass: 3.45 -> 3.51 ms; 16-byte stores did: 3.51 -> 2.93, against 2.1-2.2 for the unmapped pass.)
     const int chunks = (p + 63) >> 6, t = threadIdx.x;
-    int b, o, p0;
-    {
-        const long long groups = (long long)o_total * nb, id = blockIdx.x, full = groups / 8 * 8;
-        long long grp; int chunk;
-        if (id < full * chunks) { const long long slot = id >> 3; grp = slot / chunks * 8 + (id & 7); chunk = (int)(slot % chunks); }
-        else { const long long r = id - full * chunks; grp = full + r / chunks; chunk = (int)(r % chunks); }
-        b = (int)(grp / o_total); o = (int)(grp - (long long)b * o_total); p0 = chunk * 64;
-    }
+    const int p0 = (int)(blockIdx.x % (unsigned)chunks) * 64, grp_ = (int)(blockIdx.x / (unsigned)chunks), o = grp_ % o_total, b = grp_ / o_total;
     const int nchunk_x = chunks, nb_z = nb;
     const int np = min(64, p - p0);
     const float pivot = psum ? yt[(size_t)o * p + (pivot_pos ? *pivot_pos : 0)] : 0.f;        // Yt[0][0][o][column of point 0]
@@ -503,7 +534,13 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int nb, int o_to
         const int q = map ? map[(size_t)b * p + p0 + pp] : p0 + pp;
         if (map != nullptr && (unsigned)q >= (unsigned)p_dst) continue;
         const float *src = tile + (4 * a4) * 65 + pp;
-        *reinterpret_cast<f32x4 *>(rows_y + (size_t)q * na + 4 * a4) = (f32x4){src[0], src[65], src[130], src[195]};
+        f32x4 v = {src[0], src[65], src[130], src[195]};
+        if (bn_scale != nullptr) {                                         // (block-uniform) BatchNorm + leaky_relu of channel o on the way out
+            const float sc = bn_scale[o], sh = bn_shift[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float u = fmaf(v[e], sc, sh); v[e] = u > 0.f ? u : u * slope; }
+        }
+        *reinterpret_cast<f32x4 *>(rows_y + (size_t)q * na + 4 * a4) = v;
     }
     if (psum == nullptr) return;                                           // (block-uniform)
     for (int h = 128; h > 0; h >>= 1) {                                    // (fixed order: bit-reproducible)
@@ -967,9 +1004,45 @@ extern "C" int eap_so3_dense_split_f32(int b, int m, int l, int na, int seg, int
     else
         hipLaunchKernelGGL(dense_rowmax_kernel, dim3(m, b), dim3(256), 0, s, m, l, na, seg, (long long)(seg_pitch / 4), colmap, reinterpret_cast<const f32x4 *>(src), scale, scale2);
     if ((long long)kb_total * (m / 32) * b > 0x7fffffffLL) return eap::bad_arg("so3_dense_split: too many workgroups");
-    hipLaunchKernelGGL(dense_split_kernel, dim3((unsigned)((long long)kb_total * (m / 32) * b)), dim3(256), 0, s, b, m, l, na, kb_total, seg, (long long)(seg_pitch / 4), mapped ? 1 : 0,
-                       n_rows, colmap, reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes));
+    hipLaunchKernelGGL(dense_split_kernel<false>, dim3((unsigned)((long long)kb_total * (m / 32) * b)), dim3(256), 0, s, b, m, l, na, kb_total, seg, (long long)(seg_pitch / 4), mapped ? 1 : 0,
+                       n_rows, colmap, reinterpret_cast<const f32x4 *>(src), scale2, reinterpret_cast<u32x4 *>(planes), SplitBn{nullptr, nullptr, 1.f, 1.f});
     return eap::check_launch("so3_dense_split");
+}
+
+// eap_so3_dense_split_f32 for dY = the gradient behind a training-mode BatchNorm + leaky_relu, formed on the way in (dense_split_kernel<true>):
+// grad = dL/dy' [b,m,l_src,na], act = y' (same shape), coef float [5][m] = k1, k2, k3, beta, 1 / gamma, rowbound [b,m,na] = an UPPER BOUND on
+// max_l |gx| as float bit patterns (the scale of a row is the power of two that brings it below 2^15: a bound that is too large costs
+// nothing but dynamic range, include/eap_hip.h).  colmap as eap_so3_dense_split_f32's (may be null: l = l_src).
+extern "C" int eap_so3_dense_split_bn_f32(int b, int m, int l, int l_src, int na, const uint32_t *rowbound, const int32_t *colmap, const float *grad,
+                                          const float *act, const float *coef, float slope, float *scale, void *planes, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (colmap == nullptr && l != l_src) return eap::bad_arg("so3_dense_split_bn: without a column map l = l_src");
+    if ((m % 32) != 0 || (na % 4) != 0 || na > 64 || b > 65535 || m > 65535 * 32 || ((reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(act)) & 15) ||
+        (colmap != nullptr && ((l & 7) != 0 || (reinterpret_cast<uintptr_t>(colmap) & 15) != 0)) || rowbound == nullptr || coef == nullptr || !(slope > 0.f))
+        return eap::bad_arg("so3_dense_split_bn: m % 32, na % 4, na <= 64, 16-byte aligned sources, a bound per row, a positive slope (column map: 16-byte aligned, l % 8)");
+    hipStream_t s = eap::S(stream);
+    const int kb_total = ceil_to(l, KC_BK) / 16;
+    float *scale2 = scale + (size_t)b * na * m;
+    hipLaunchKernelGGL(dense_scale_kernel, dim3(eap::cdiv((long long)b * m * na, 256)), dim3(256), 0, s, (long long)b * m * na, m, na, rowbound, scale, scale2);
+    if ((long long)kb_total * (m / 32) * b > 0x7fffffffLL) return eap::bad_arg("so3_dense_split_bn: too many workgroups");
+    const int seg = colmap ? l : l_src;
+    hipLaunchKernelGGL(dense_split_kernel<true>, dim3((unsigned)((long long)kb_total * (m / 32) * b)), dim3(256), 0, s, b, m, l, na, kb_total, seg, (long long)l_src * na / 4, 0,
+                       nullptr, colmap, reinterpret_cast<const f32x4 *>(grad), scale2, reinterpret_cast<u32x4 *>(planes),
+                       SplitBn{reinterpret_cast<const f32x4 *>(act), coef, slope, 1.0f / slope});
+    return eap::check_launch("so3_dense_split_bn");
+}
+
+// eap_so3_dense_untranspose_map_f32 / eap_so3_dense_untranspose_f32 (map null) with y = leaky_relu(bn_scale[o] yt + bn_shift[o], slope) on the
+// way out: the training-mode BatchNorm + activation behind the dense forward without a pass of its own (the moments come from a
+// statistics pass over Yt, eap_bn_stats_f32 on its [b na, o, p] view)
+extern "C" int eap_so3_dense_untranspose_bnact_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *yt, const float *bn_scale,
+                                                   const float *bn_shift, float slope, float *y, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if ((long long)eap::cdiv(p, 64) * o * b > 0x7fffffffLL || bn_scale == nullptr || bn_shift == nullptr || (map != nullptr && p_dst <= 0) || (map == nullptr && p_dst != p))
+        return eap::bad_arg("so3_dense_untranspose_bnact: scale and shift per channel; p_dst = p without a map");
+    hipLaunchKernelGGL(dense_untranspose_kernel, dim3((unsigned)((long long)eap::cdiv(p, 64) * o * b)), dim3(256), sizeof(float) * (size_t)na * 65, eap::S(stream), b, o, p, na,
+                       p_dst, map, nullptr, yt, y, nullptr, nullptr, bn_scale, bn_shift, slope);
+    return eap::check_launch("so3_dense_untranspose_bnact");
 }
 
 // ldz (dir 0): floats between consecutive (o, k) rows of Z, >= na rp (the columns past na rp are not written)

@@ -683,6 +683,63 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None, out=None, col_map=None):
     return y
 
 
+def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments):
+    """The dense forward with the training-mode BatchNorm + leaky_relu behind it applied by the re-ordering pass (the conv + BatchNorm
+    node of vgtk/so3conv/functional.py): product -> Yt; statistics pass over Yt; norm_moments(s1, s2, pivot, count) -> (scale, shift, slope)
+    per channel (float32 [o]); y' = leaky(scale y + shift) written through the geometry's point order.  -> y' [b,o,p,na]"""
+    b, o = g.shape[:2]
+    na = geo.na
+    ldg = geo.rp * na if ldg is None else int(ldg)
+    scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg, shape=(b, o, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
+    yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
+    call('eap_so3_dense_product_steps_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
+         _ptr(geo.kr), _ptr(geo.mask(1)), _ptr(geo.steps(1)), _ptr(yt),
+         tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp), 'executed_f16_flops': _dense_executed_flops(geo, o, p, 1),
+              'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
+    del planes
+    # moments of every channel over (cloud, anchor, point): Yt is [b na][o][p] for the statistics kernel; the pivot is its own first element
+    ps, pq = _partials(yt, b * na, o, p)
+    call('eap_bn_stats_f32', yt, b * na, o, _I64(p), _ptr(yt), _ptr(ps), _ptr(pq))
+    bn_scale, bn_shift, slope = norm_moments(ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64), yt[0, 0, :, 0].double(), b * na * p)
+    y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
+    call('eap_so3_dense_untranspose_bnact_f32', yt, b, o, p, na, p, _ptr(geo.order), _ptr(yt), _ptr(bn_scale), _ptr(bn_shift), _F32(slope), _ptr(y))
+    return y
+
+
+def bn_act_bwd_reduce_fromy(gy, y, beta, inv_gamma, slope):
+    """gy, y [b,c,p,na] (y = the layer's activated output) -> (sum g, sum g xhat) float64 [c] and the per-row maxima gmax, xmax float32 [b,c,na]
+    (csrc/bn_act.hip bn_act_bwd_reduce_fromy_kernel)."""
+    b, c, p, na = y.shape
+    n = p * na
+    nblk = int(lib.eap_bn_act_fromy_blocks(_I64(n), na))
+    pg = torch.empty(c, b * nblk, dtype=torch.float32, device=y.device)
+    pgx = torch.empty_like(pg)
+    gmax = torch.empty(b, c, na, dtype=torch.int32, device=y.device)
+    xmax = torch.empty_like(gmax)
+    call('eap_bn_act_bwd_reduce_fromy_f32', y, b, c, _I64(n), na, _F32(slope), _ptr(gy), _ptr(y), _ptr(beta), _ptr(inv_gamma), _ptr(pg), _ptr(pgx), _ptr(gmax), _ptr(xmax))
+    return pg.sum(1, dtype=torch.float64), pgx.sum(1, dtype=torch.float64), gmax.view(torch.float32), xmax.view(torch.float32)
+
+
+def so3_dense_bwd_bn(gy, yact, geo, ldz, coef, rowbound, slope):
+    """so3_dense_bwd for the gradient BEHIND a training-mode BatchNorm + leaky_relu, formed while it is split into the product's planes
+    (eap_so3_dense_split_bn_f32): gy = dL/dy', yact = y' [b,o,p,na], coef float32 [5,o] = k1, k2, k3, beta, 1/gamma, rowbound float32 [b,o,na] >=
+    max |gx| of every row.  -> Z as so3_dense_bwd."""
+    b, o, p, na = gy.shape
+    ldz = na * geo.rp if ldz is None else int(ldz)
+    colmap = geo.columns(None)
+    l = p if colmap is None else colmap.shape[1]
+    scale = torch.empty(2, b, na, o, dtype=torch.float32, device=gy.device)
+    planes = torch.empty(b * na * o * ((l + 31) // 32 * 32), dtype=torch.int32, device=gy.device)
+    call('eap_so3_dense_split_bn_f32', gy, b, o, l, p, na, _ptr(rowbound.view(torch.int32)), _ptr(colmap), _ptr(gy), _ptr(yact), _ptr(coef), _F32(slope), _ptr(scale),
+         _ptr(planes))
+    z = torch.empty(b, o, geo.ks, ldz, dtype=torch.float32, device=gy.device)
+    call('eap_so3_dense_product_steps_f32', gy, 0, b, o, l, na, geo.ks, geo.rp, _I64(ldz), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
+         _ptr(geo.kr), _ptr(geo.mask(0)), _ptr(geo.steps(0)), _ptr(z),
+         tag={'flops': 2.0 * b * o * l * na * geo.ks * geo.nn, 'executed_f16_flops': _dense_executed_flops(geo, o, l, 0),
+              'shape': ('so3_dense', 0, b, o, l, na, geo.ks, geo.rp)})
+    return z
+
+
 def _partials(x, b, c, n):
     nseg = int(lib.eap_bn_act_segments(_I64(n)))
     return (torch.empty(c, b * nseg, dtype=torch.float32, device=x.device),

@@ -151,14 +151,25 @@ def conv_norm_act(conv, norm, x, **conv_kwargs):
     """The block layer's `x = conv(x); feat = relu(norm(x.feats))` (SPConvNets/utils/base_so3poseconv.py:L205-222) for an
     InterSO3Conv / InterSO3PoseConv and a BatchNormLeakyReLU -> (inter_idx, inter_w, sample_idx, cloud with the activated
     features).  In inference (norm in eval mode, gradients off) the normalisation and the activation ride in the
-    contraction's epilogue -- the feature map is written once, no pass of its own; otherwise conv and norm run as usual."""
+    contraction's epilogue -- the feature map is written once, no pass of its own; in training the norm joins the conv's autograd
+    node where the conv runs the dense product; otherwise conv and norm run as usual."""
     from vgtk.spconv import SphericalPointCloud, SphericalPointCloudPose
+    from .functional import TrainEpilogue
     fold = not norm.training and not torch.is_grad_enabled()
     ep = norm.folded() if fold else None
+    if ep is None and norm.training and isinstance(norm, BatchNormLeakyReLU) and norm.negative_slope > 0:
+        # training: where the conv runs the dense product the normalisation joins its autograd node (no pass of its own in either
+        # direction, the conv output is never written: vgtk/so3conv/functional.py TrainEpilogue)
+        ep = TrainEpilogue(norm)
     if ep is not None:
         conv_kwargs = dict(conv_kwargs, epilogue=ep)
     inter_idx, inter_w, sample_idx, y = conv(x, **conv_kwargs)
-    feats = y.feats if (ep is not None and ep.applied) else norm(y.feats)
+    if ep is not None and ep.applied:
+        feats = y.feats
+        if norm.training:
+            norm.num_batches_tracked.add_(1)
+    else:
+        feats = norm(y.feats)
     pose = getattr(y, 'pose', None)
     out = SphericalPointCloudPose(y.xyz, feats, y.anchors, pose) if pose is not None else SphericalPointCloud(y.xyz, feats, y.anchors)
     return inter_idx, inter_w, sample_idx, out

@@ -567,6 +567,45 @@ class FoldedEpilogue:
         self.inference = not torch.is_grad_enabled()      # made under torch.no_grad(): the only place it may be applied
 
 
+class TrainEpilogue:
+    """A TRAINING-mode BatchNorm2d + leaky_relu right behind an inter conv (vgtk.so3conv.blocks.conv_norm_act; `x = conv(x); feat =
+    relu(norm(x.feats))`, SPConvNets/utils/base_so3poseconv.py:L205-222).  When the conv's forward runs the dense product it takes the
+    normalisation into its own node and sets `applied`:
+      forward   product -> Yt -> statistics pass over Yt -> the re-ordering pass writes y' = leaky(BatchNorm(y)) (no pass of the norm's own,
+                the conv output y is never written);
+      backward  one reduction pass over (dL/dy', y') -> the gradient behind the norm is formed WHILE it is split into the backward product's
+                planes (never written either).  The pre-activation is recovered from y' (leaky_relu with a positive slope is invertible):
+                the node keeps its output, not the conv output.
+    Otherwise (list kernels, posed parts, ...) `applied` stays False and the caller runs the norm module as a pass of its own.
+    A channel whose gamma is exactly 0 has a constant output: its input gradient is exactly 0 either way, its d gamma is reported as 0."""
+
+    def __init__(self, norm):
+        self.norm = norm
+        self.applied = False
+        self.inference = False
+        self.residual = None
+
+    def moments(self, s1, s2, pivot, count):
+        """pivoted sums of the conv output per channel -> (scale, shift, slope) of the fused pass; updates the running statistics exactly as
+        vgtk.so3conv.blocks._BNAct.forward does; leaves what the backward needs in self.saved"""
+        from .blocks import batch_moments
+        norm = self.norm
+        mean, var, total = batch_moments(s1, s2, pivot, count, norm.sync)
+        if norm.running_mean is not None:
+            with torch.no_grad():
+                m = norm.momentum
+                norm.running_mean.mul_(1.0 - m).add_(mean.to(norm.running_mean.dtype), alpha=m)
+                norm.running_var.mul_(1.0 - m).add_((var * (total / (total - 1))).to(norm.running_var.dtype), alpha=m)
+        invstd = torch.rsqrt(var + norm.eps)
+        gamma = norm.weight.detach().double()
+        scale64 = gamma * invstd
+        scale = scale64.float()
+        shift = (norm.bias.detach().double() - mean * scale64).float()
+        inv_gamma = torch.where(gamma == 0, torch.zeros_like(gamma), 1.0 / gamma).float()
+        self.saved = (scale, norm.bias.detach().float().contiguous(), inv_gamma.contiguous(), total)
+        return scale.contiguous(), shift.contiguous(), float(norm.negative_slope)
+
+
 def _contract_into(W, x, y, layout, epilogue=None, b0=0, x_bound=None):
     """y[b,o,pa] = W . x for the intermediate in one of its three layouts (epilogue: see FoldedEpilogue; b0 = first
     cloud of this slab, for the residual; x_bound = (words [b, p], anchors per point, factor) bounding x per point, see
@@ -612,6 +651,8 @@ DENSE_ROW_FACTOR = 5.0
 # the forward at widths that fill 128-row blocks only (the 64 -> 128 layer): with every k-step it tied with grouping + contraction
 # (round 5: 9.0 against 9.1 ms); with the empty k-steps skipped (round 6) it is decided by measurement, profiles/r06_dense_forward_128.txt
 DENSE_FWD_NARROW = os.environ.get('EAP_DENSE_FWD_128', '1') != '0'
+# a training-mode BatchNorm + leaky_relu behind a conv whose forward runs the dense product joins the conv's node (TrainEpilogue)
+FUSE_CONV_NORM = os.environ.get('EAP_FUSE_CONV_NORM', '1') != '0'
 
 
 def _dense_rows(rcap, n):
@@ -806,7 +847,9 @@ class _InterConv(torch.autograd.Function):
     with the re-associated feature gradient (csrc/so3_inter_inv.hip)."""
 
     @staticmethod
-    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None, grad_mode=True, geometry=None):
+    def forward(ctx, feats, W_param, idx, gx, rk, mult, sigma, ident, nonident=None, anchors=None, epilogue=None, grad_mode=True, geometry=None,
+                bn_weight=None, bn_bias=None):
+        # (bn_weight, bn_bias: the parameters of a TrainEpilogue's norm -- inputs of the node so that it can hand back their gradients)
         feats = feats.contiguous()
         W = W_param.contiguous()
         ctx.anchors = anchors.detach().contiguous() if anchors is not None else None   # the rotations `mult` was built from
@@ -821,6 +864,10 @@ class _InterConv(torch.autograd.Function):
         # grad_mode = torch.is_grad_enabled() AT THE CALL (inside forward() autograd always has it off; and under torch.no_grad()
         # needs_input_grad still reports the parameters although nothing will be differentiated)
         needs_grad = (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and grad_mode
+        train_ep = epilogue if isinstance(epilogue, TrainEpilogue) else None
+        if train_ep is not None:
+            epilogue = None                                # (the list kernels know nothing of it: `applied` stays False there)
+        ctx.bn = None
         if epilogue is not None and (needs_grad or not epilogue.inference):
             raise RuntimeError('a folded epilogue is an inference-time fusion: build and use it under torch.no_grad()')
         lists_ok = BACKWARD_MODE != 'dx' and _inv_lists_supported(idx, n, na, ks)
@@ -862,7 +909,14 @@ class _InterConv(torch.autograd.Function):
             head.wait()
             if parts is None:
                 geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)
-                y = _dense_forward(feats, W, head.rows, geo, p)
+                if train_ep is not None and FUSE_CONV_NORM:
+                    g_, ldg = _dense_g(_hip.rows_gather(feats, head.rows, geo.rp), W, geo)
+                    y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, train_ep.moments)
+                    del g_
+                    train_ep.applied = True
+                    ctx.bn = train_ep.saved + (float(train_ep.norm.negative_slope), bool(train_ep.norm.sync))
+                else:
+                    y = _dense_forward(feats, W, head.rows, geo, p)
             else:
                 geo = _PartsDense(parts, geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows, mult, ctx.anchors)
                 y = _dense_forward_parts(feats, W, head.rows, geo, p)
@@ -872,7 +926,7 @@ class _InterConv(torch.autograd.Function):
             ctx.layout, ctx.kept_x = 0, False
             ctx.W_param = weakref.ref(W_param)
             ctx.save_for_backward(W, torch.empty(0), idx, gx, rk, mult if mult is not None else torch.empty(0),
-                                  nonident if nonident is not None else torch.empty(0), feats)
+                                  nonident if nonident is not None else torch.empty(0), feats, *((y,) if (ctx.bn is not None and needs_grad) else ()))
             ctx.has_mult = mult is not None
             ctx.has_flag = nonident is not None
             ctx.sigma, ctx.ident, ctx.n = sigma, ident, feats.shape[2]
@@ -917,7 +971,8 @@ class _InterConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        W, x, idx, gx, rk, mult, nonident, feats = ctx.saved_tensors
+        W, x, idx, gx, rk, mult, nonident, feats = ctx.saved_tensors[:8]
+        yact = ctx.saved_tensors[8] if ctx.bn is not None else None
         mult = mult if ctx.has_mult else None
         nonident = nonident if ctx.has_flag else None
         gy = gy.contiguous()
@@ -941,16 +996,32 @@ class _InterConv(torch.autograd.Function):
                     a_ = ctx.dense[1]
                     ctx.dense[0] = _PartsDense(ctx.parts, a_[1], a_[2], a_[3], a_[4], a_[5], a_[6], a_[7], a_[8], mult, ctx.anchors)
             if ctx.parts is not None:
-                return _InterConv._backward_parts(ctx, gy, W, feats, head, ctx.dense[0]) + (None,) * 11
+                return _InterConv._backward_parts(ctx, gy, W, feats, head, ctx.dense[0]) + (None,) * 13
             geo = ctx.dense[0]
             if BACKWARD_LOG is not None:
-                BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(geo.rp), 'regime': 'dense rows'})
+                BACKWARD_LOG.append({'channels': (c, o), 'support_rows': n, 'referenced_rows_max': int(geo.rp), 'regime': 'dense rows',
+                                     **({'norm': 'in the node'} if ctx.bn is not None else {})})
             rp = geo.rp
             ra = na * rp
             # Z's rows padded to whole 128-column tiles where that puts the feature-gradient GEMM on the split-operand kernels
             # (the padding is never written: garbage columns of gFc nobody reads; the weight gradient contracts over ra columns)
             ldz = _hip.dense_pitch(ra) if (c % 128 == 0 and (o * ks) % 16 == 0 and ctx.needs_input_grad[0]) else ra
-            z = _hip.so3_dense_bwd(gy, geo, ldz)                                     # [b,o,ks,ldz] rows = [na,rp]: the lists' Z, anchor axis in front
+            g_bn_w = g_bn_b = None
+            if ctx.bn is not None:
+                # the BatchNorm + leaky_relu backward of the node (csrc/bn_act.hip header): one reduction pass over (dL/dy', y'), then gx is
+                # formed inside the split of the product's stored operand
+                k1, beta, inv_gamma, count, slope, sync = ctx.bn
+                from .blocks import all_reduce_sums
+                sg, sgx, gmax, xmax = _hip.bn_act_bwd_reduce_fromy(gy, yact, beta, inv_gamma, slope)
+                g_bn_w, g_bn_b = sgx.float(), sg.float()
+                tg, tgx = all_reduce_sums(sg, sgx, sync=sync)                        # whole-batch means (SyncBatchNorm backward)
+                k2 = (k1.double() * tg / count).float()
+                k3 = (k1.double() * tgx / count).float()
+                coef = torch.stack([k1, k2, k3, beta, inv_gamma]).contiguous()      # [5, o]
+                bound = (k1.abs()[None, :, None] * gmax + k2.abs()[None, :, None] + k3.abs()[None, :, None] * xmax).contiguous()
+                z = _hip.so3_dense_bwd_bn(gy, yact, geo, ldz, coef, bound, slope)
+            else:
+                z = _hip.so3_dense_bwd(gy, geo, ldz)                                 # [b,o,ks,ldz] rows = [na,rp]: the lists' Z, anchor axis in front
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ldz, dtype=torch.float32, device=gy.device)
@@ -959,7 +1030,7 @@ class _InterConv(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 fc = _hip.rows_gather(feats, head.rows, rp).transpose(2, 3).contiguous().view(b, c, ra)      # [b,c,(a,r)]
                 gW = _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz)
-            return gF, gW, None, None, None, None, None, None, None, None, None, None, None
+            return gF, gW, None, None, None, None, None, None, None, None, None, None, None, g_bn_w, g_bn_b
         if head is not None:
             rcap, any_nonident = head.decide()
             if BACKWARD_MODE == 'auto' and rcap * INV_ROW_FRACTION > n:
@@ -1018,9 +1089,12 @@ class _InterConv(torch.autograd.Function):
                     _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b, b_blocked=ctx.layout == 1)
             if ctx.needs_input_grad[0]:
                 gx_ = torch.empty_like(x.view(b, ck, pa))      # W^T gy
-                _hip.gemm(1, 0, ck, pa, o, W, ck, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
+                # (W^T written out -- a few MB: the product is then 'nn' with a shared A operand, which the split-operand kernels take;
+                # with the transposition left to the GEMM it ran on the fp32 matrix pipe: 15.6 of the 61.6 ms step at 16 x 512 points)
+                Wt = W.t().contiguous()
+                _hip.gemm(0, 0, ck, pa, o, Wt, o, 0, gy.view(b, o, pa), pa, o * pa, gx_, pa, ck * pa, b)
                 gF = _hip.so3_inter_group_bwd(gx_.view(b, c, ks, p, na), idx, gx, rk, mult, ctx.sigma, n, ctx.ident)
-        return gF, gW, None, None, None, None, None, None, None, None, None, None, None
+        return gF, gW, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
     @staticmethod
@@ -1231,9 +1305,12 @@ def inter_so3conv_fused(xyz, pose, feats, W, n_neighbor, anchors, kernels, radiu
                 raise NotImplementedError(
                     'anchor permutation with per-point poses needs a closed anchor set (kanchor 60 or 1)')
     gx, nonident = _hip.so3_prep(q_xyz, xyz, ball_idx, q_rot, rot, anchors.contiguous(), 0 if ident is None else ident)
+    bn_w = bn_b = None
+    if isinstance(epilogue, TrainEpilogue):
+        bn_w, bn_b = epilogue.norm.weight, epilogue.norm.bias
     y = _InterConv.apply(feats, W, ball_idx, gx, rk, mult, float(sigma), 0 if ident is None else ident, nonident,
                          anchors if mult is not None else None, epilogue, torch.is_grad_enabled(),
-                         (q_xyz.contiguous(), xyz.contiguous(), q_rot, rot))
+                         (q_xyz.contiguous(), xyz.contiguous(), q_rot, rot), bn_w, bn_b)
     inter_w = InterWeights(gx, rk, sigma)
     return ball_idx, (inter_w.materialize() if MATERIALIZE_INTER_W else inter_w), y
 

@@ -390,6 +390,16 @@ int eap_so3_dense_untranspose_map_f32(int b, int o, int p, int na, int p_dst, co
                                       eap_stream_t stream);
 int eap_so3_dense_untranspose_map_stats_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const int32_t *pivot_pos, const float *yt,
                                             float *y, float *psum, float *psq, eap_stream_t stream);
+/* conv + training-mode BatchNorm + leaky_relu as ONE node (round 6; `x = conv(x); feat = relu(norm(x.feats))`,
+ * SPConvNets/utils/base_so3poseconv.py:L205-222, and its autograd): the forward's re-ordering pass applies the normalisation on the way out
+ * (eap_so3_dense_untranspose_bnact_f32; the moments come from eap_bn_stats_f32 over Yt viewed as [b na, o, p]); the backward never writes
+ * the gradient behind the BatchNorm: eap_bn_act_bwd_reduce_fromy_f32 (csrc/bn_act.hip) reduces sum(g), sum(g xhat) and leaves per-row bounds,
+ * eap_so3_dense_split_bn_f32 forms gx = k1 g - k2 - k3 xhat while it splits it into the product's planes.  Both recover the
+ * pre-activation from the layer's OUTPUT (leaky_relu with a positive slope is invertible): the conv output is not kept. */
+int eap_so3_dense_split_bn_f32(int b, int m, int l, int l_src, int na, const uint32_t *rowbound, const int32_t *colmap, const float *grad,
+                               const float *act, const float *coef, float slope, float *scale, void *planes, eap_stream_t stream);
+int eap_so3_dense_untranspose_bnact_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *yt, const float *bn_scale,
+                                        const float *bn_shift, float slope, float *y, eap_stream_t stream);
 int eap_so3_dense_point_keys(int b, int p, const uint32_t *memb, int32_t *keys, eap_stream_t stream);
 int64_t eap_so3_dense_steps_words(int b, int p, int ks, int rp, int dir);
 int eap_so3_dense_steps(int b, int p, int ks, int rp, int dir, int skip, const int32_t *n_rows, const uint64_t *mask, int32_t *steps,
@@ -600,6 +610,11 @@ int eap_bn_act_bwd_apply_f32(int b, int c, int64_t n, float slope, const float *
 int eap_bn_act_bwd_apply_rowmax_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *x,
                                     const float *scale, const float *shift, const float *mean, const float *invstd,
                                     const float *k2, const float *k3, float *gx, uint32_t *rowmax, eap_stream_t stream);
+/* the reduction pass of the BatchNorm + leaky_relu backward from the layer's OUTPUT y' (see the conv + BatchNorm node above): partials of sum(g),
+ * sum(g xhat) [c][b * eap_bn_act_fromy_blocks(n, na)] and the largest |g|, |xhat| per (cloud, channel, anchor) [b,c,na] (float bit patterns) */
+int eap_bn_act_fromy_blocks(int64_t n, int na);
+int eap_bn_act_bwd_reduce_fromy_f32(int b, int c, int64_t n, int na, float slope, const float *gy, const float *y, const float *beta,
+                                    const float *inv_gamma, float *pg, float *pgx, uint32_t *gmax, uint32_t *xmax, eap_stream_t stream);
 
 /* Per-cloud statistics over a point subset: the pose heads run their unary stacks once per cloud on the cloud's member
  * points (`for i_bz in range(bz): ...` SPConvNets/models/..pn_38_multi_stage.py:L706-830, the head's BatchNorm2d layers

@@ -553,3 +553,55 @@ def test_sorted_points_against_index_order(dev):
         assert torch.allclose(a_.sum(1, dtype=torch.float64), b_.sum(1, dtype=torch.float64), rtol=1e-5, atol=1e-3)
     z1, z0 = _hip.so3_dense_bwd(gy, geo), _hip.so3_dense_bwd(gy, geo0)
     assert float((z1 - z0).abs().max()) < 2e-6 * float(z0.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# conv + training-mode BatchNorm + leaky_relu as one node (round 6)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('o,sort', [(256, True), (128, True), (256, False)])
+def test_conv_norm_node_against_separate_modules(dev, monkeypatch, o, sort):
+    """vgtk.so3conv.conv_norm_act in training mode with the norm inside the conv's autograd node (the re-ordering pass applies it, the
+    backward forms the gradient behind it inside the stored-operand split, the pre-activation is recovered from the OUTPUT) against the
+    same conv followed by the BatchNormLeakyReLU module as a pass of its own (pinned against torch's BatchNorm2d + leaky_relu in
+    tests/test_gpu_parity.py): y', dF, dW, d gamma, d beta and the running statistics."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    monkeypatch.setattr(_hip, 'SORT_DENSE_POINTS', sort)
+    B, P, c = 2, 512, 32
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(71, B, P)[0]).to(dev)
+    pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
+    gen = torch.Generator(device=dev).manual_seed(41)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    gamma0 = torch.rand(o, device=dev, generator=gen) + 0.5
+    gamma0[3] = -0.7                                            # a negative scale: the sign of the pre-activation still comes from y'
+    beta0 = torch.randn(o, device=dev, generator=gen) * 0.3
+    gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
+    out = {}
+    for fused in (False, True):
+        monkeypatch.setattr(L, 'FUSE_CONV_NORM', fused)
+        torch.manual_seed(2913)
+        conv = sptk.InterSO3PoseConv(c, o, 1, 1, radius, sigma, NN, kanchor=NA, permute_modes=1).to(dev)
+        norm = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
+        with torch.no_grad():
+            conv.basic_conv.W.copy_(W0); norm.weight.copy_(gamma0); norm.bias.copy_(beta0)
+        feats = feats0.clone().requires_grad_(True)
+        L.BACKWARD_LOG = []
+        y = sptk.conv_norm_act(conv, norm, zptk.SphericalPointCloudPose(xyz, feats, None, pose))[3].feats
+        grads = torch.autograd.grad(y, [feats, conv.basic_conv.W, norm.weight, norm.bias], gy)
+        log, L.BACKWARD_LOG = L.BACKWARD_LOG, None
+        assert log[0]['regime'] == 'dense rows' and (log[0].get('norm') == 'in the node') == fused, log
+        out[fused] = (y.detach(),) + grads + (norm.running_mean.clone(), norm.running_var.clone(), int(norm.num_batches_tracked))
+        with torch.no_grad():                                  # (training mode, gradients off: the fused forward alone)
+            y_ng = sptk.conv_norm_act(conv, norm, zptk.SphericalPointCloudPose(xyz, feats0, None, pose))[3].feats
+        assert torch.equal(y_ng, y.detach())
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    a, b_ = out[True], out[False]
+    assert rel(a[0], b_[0]) < 1e-5, rel(a[0], b_[0])                          # y'
+    assert rel(a[1], b_[1]) < 2e-5 and rel(a[2], b_[2]) < 5e-5              # dF, dW
+    assert rel(a[3], b_[3]) < 2e-5 and rel(a[4], b_[4]) < 2e-5              # d gamma, d beta
+    assert rel(a[5], b_[5]) < 1e-5 and rel(a[6], b_[6]) < 1e-5 and a[7] == b_[7] == 1
