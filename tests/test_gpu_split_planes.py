@@ -230,12 +230,15 @@ def test_two_plane_intra_conv_against_fp64(dev, B, C, O, P):
     assert err['f16x2'] <= 1.25 * err['fp32'] + 1e-7
 
 
-def test_inter_conv_layer_with_two_planes(dev):
+def test_inter_conv_layer_with_two_planes(dev, monkeypatch):
     """A whole InterSO3PoseConv layer (forward, dF, dW) with the contraction on two planes against three planes and against the
-    fp32 pipe; the forward contraction takes its operand bound from the features (nn x max|feats|), not from a pass over X."""
+    fp32 pipe; the forward contraction takes its operand bound from the features (nn x max|feats|), not from a pass over X.
+    (The list-kernel forward: at this width the dense product would take it since round 6 -- switched off here.)"""
     import synth_clouds
     import vgtk.so3conv as sptk
     import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
+    monkeypatch.setattr(L, 'DENSE_FWD_NARROW', False)
     torch.manual_seed(3)
     B, P, c, o = 2, 512, 64, 128
     xyz, _, pose = synth_clouds.laptop_batch(1, B, P)
