@@ -153,3 +153,33 @@ def algorithmic_flops(batch, points, plan, head_width=256):
     feat = plan[-1][1]
     heads = SLOTS * (2 * 2 * head_width * feat * pa + 2 * head_width * 2 * head_width * pa) + 2 * head_width * feat * pa
     return batch * ((inter + intra + skip) + 3 * 2 * inter + 3 * heads)
+
+
+def stage_fingerprints(model, xyz, pose):
+    """The composite forward stage by stage under no_grad -> {stage: (float64 sum, xor-sum of the bit patterns)} in program order: what
+    tests/test_gpu_config3.py prints when two forwards differ, and what tools/gpu/config3_flake_hunt.py compares over many forwards."""
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+
+    def fp(t):
+        t = t.detach().contiguous()
+        x = (t.view(torch.int32) if t.dtype == torch.float32 else t).reshape(-1).to(torch.int64)
+        n2 = x.numel() // 2 * 2
+        return (float(t.double().sum()) if t.is_floating_point() else int(x.sum()), int(torch.bitwise_xor(x[:n2:2], x[1:n2:2]).sum()))
+
+    out = {}
+    with torch.no_grad():
+        g = model.glb_backbone(xyz, pose); out['glb_backbone'] = fp(g); del g
+        feats = model.backbone(xyz, pose); out['backbone'] = fp(feats)
+        feats_sec = model.backbone_sec(xyz, pose); out['backbone_sec'] = fp(feats_sec)
+        ppinv, conf = model.ppint_outblk(zptk.SphericalPointCloud(xyz, feats_sec, None))
+        out['inv_head.ppinv'], out['inv_head.conf'] = fp(ppinv), fp(conf)
+        scores = model.slot_scorer(ppinv.transpose(1, 2)); out['slot_scorer'] = fp(scores)
+        labels = scores.argmax(-1); out['labels'] = fp(labels)
+        anchors = model.backbone.convs[0].anchors
+        for s_, o in enumerate(sptk.pose_head_over_slot_groups(model.slot_heads, feats, xyz, labels, anchors)):
+            for k in ('R', 'T', 'axis', 'central_points'):
+                out[f'slot{s_}.{k}'] = fp(o[k])
+        loss, res = model(xyz, pose)
+        out['recon'], out['loss'] = fp(res['recon']), (float(loss), 0)
+    return out

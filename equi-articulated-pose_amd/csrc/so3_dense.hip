@@ -490,6 +490,128 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int nb, int m, int l, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// the forward's stored operand made in ONE kernel (round 6): G[o,(k,r),a] = sum_c W[o,c,k] F[c,r,a] over the referenced rows, written
+// straight as the product's two fp16 planes in fragment order.  (Before: a GEMM wrote G in fp32 -- 3.4 GB at 8 x 4096, O = 512 -- and
+// dense_split_kernel read it back and wrote the planes: 2.3 + 2.3 ms for 0.2 TFLOP of work.)
+//   block = (4 row tiles of 32 output channels, one per wave; z = (cloud, anchor)); the anchor's feature rows Ft[b][a][r][c] (c contiguous)
+//   sit in LDS as two fp16 planes after one power-of-two scale per (cloud, anchor); a wave walks the kernel points k: its 32 rows (o, k) of
+//   W3[(o,k)][c] go to registers as two fp16 planes (own power-of-two scale per row), then per tile of 32 rows r: D^T[r][o] = sum_c F[r][c]
+//   W[o][c] (three v_mfma_f32_32x32x16_f16 per 16 channels: h h' + h l' + l h'), brought to the plane scale of the output row (from a BOUND
+//   on max_{k,r} |G|: a bound that is too large costs dynamic range only, see dense_split_kernel<true>), split, and the 8-row pieces --
+//   4 values from a lane, 4 from its partner 32 lanes away -- stored 1 KB per (k-block, plane) and wave.
+//   Rows past the cloud's own prefix (ceil16(n_rows)) are neither computed nor written.
+template <int CSTEPS>                                    // channels / 16
+__global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int ks, int rp, int kb_total, const float *__restrict__ W3,
+                                                            const float *__restrict__ Ft, const int32_t *__restrict__ n_rows,
+                                                            const float *__restrict__ bound, float *__restrict__ scale, u32x4 *__restrict__ planes) {
+    constexpr int C = 16 * CSTEPS, PITCH = 2 * C + 16;                      // bytes per LDS row of one plane (+16: rows 272 / 144 bytes apart)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned s_red[4];
+    const int z = blockIdx.y, b = z / na;
+    const int t = threadIdx.x, lane = t & 63, li = lane & 31, kg = lane >> 5, wave = t >> 6;
+    const int rows_b = n_rows ? min((min(n_rows[b], rp) + 15) & ~15, rp) : rp;          // this cloud's row slots (whole groups of 16)
+    unsigned char *Fh = smem, *Fl = smem + (size_t)rp * PITCH;
+    // ---- the anchor's feature rows -> LDS planes ----
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Ft + ((size_t)z * rp) * C);
+    const int n4 = rows_b * (C / 4);
+    unsigned mx = 0;
+    for (int i = t; i < n4; i += 256) {
+        const f32x4 v = src[i];
+        mx = max(mx, max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o_));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    const float sF = pow2_scale(__uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]))));
+    for (int i = t; i < n4; i += 256) {
+        const f32x4 v = src[i];                                              // (second read: L2)
+        const int r = i / (C / 4), c4 = i - r * (C / 4);
+        unsigned h0, l0, h1, l1;
+        split2(v.x * sF, v.y * sF, h0, l0);
+        split2(v.z * sF, v.w * sF, h1, l1);
+        *reinterpret_cast<uint2 *>(Fh + (size_t)r * PITCH + c4 * 8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(Fl + (size_t)r * PITCH + c4 * 8) = make_uint2(l0, l1);
+    }
+    __syncthreads();
+    const int MT = m >> 5, mt = blockIdx.x * 4 + wave;
+    if (mt >= MT) return;
+    const int o = 32 * mt + li;
+    // the output row's plane scale, from the bound; also published for the product's epilogue (scale[z][o]: one lane per row)
+    const float s_out = pow2_scale(bound[(size_t)z * m + o]);
+    if (kg == 0) scale[(size_t)z * m + o] = s_out;
+    const int rtiles = (rows_b + 31) >> 5;
+    for (int k = 0; k < ks; ++k) {
+        // ---- this lane's half of row (o, k) of W3: channels 16 s + 8 kg .. + 7 of every 16-channel step ----
+        const f32x4 *wrow = reinterpret_cast<const f32x4 *>(W3 + ((size_t)o * ks + k) * C) + 2 * kg;
+        f32x4 w[CSTEPS][2];
+        unsigned wm = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < CSTEPS; ++s_) {
+            w[s_][0] = wrow[4 * s_]; w[s_][1] = wrow[4 * s_ + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wm = max(wm, max(__float_as_uint(w[s_][0][e]) & 0x7fffffffu, __float_as_uint(w[s_][1][e]) & 0x7fffffffu));
+        }
+        wm = max(wm, (unsigned)__shfl_xor((int)wm, 32));
+        const float sW = pow2_scale(__uint_as_float(wm));
+        u32x4 Bh[CSTEPS], Bl[CSTEPS];
+#pragma unroll
+        for (int s_ = 0; s_ < CSTEPS; ++s_) {
+            unsigned h[4], l[4];
+            split2(w[s_][0].x * sW, w[s_][0].y * sW, h[0], l[0]);
+            split2(w[s_][0].z * sW, w[s_][0].w * sW, h[1], l[1]);
+            split2(w[s_][1].x * sW, w[s_][1].y * sW, h[2], l[2]);
+            split2(w[s_][1].z * sW, w[s_][1].w * sW, h[3], l[3]);
+            Bh[s_] = (u32x4){h[0], h[1], h[2], h[3]};
+            Bl[s_] = (u32x4){l[0], l[1], l[2], l[3]};
+        }
+        const float tsc = s_out / (sF * sW);                                // (powers of two: exact)
+        for (int rt = 0; rt < rtiles; ++rt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const int r = min(32 * rt + li, rp - 1);                         // (rows past rp: a valid address, their pieces are not stored)
+            const unsigned char *ah = Fh + (size_t)r * PITCH + 16 * kg, *al = Fl + (size_t)r * PITCH + 16 * kg;
+#pragma unroll
+            for (int s_ = 0; s_ < CSTEPS; ++s_) {
+                const u32x4 fh = *reinterpret_cast<const u32x4 *>(ah + 32 * s_), fl = *reinterpret_cast<const u32x4 *>(al + 32 * s_);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fh), __builtin_bit_cast(f16x8, Bh[s_]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fh), __builtin_bit_cast(f16x8, Bl[s_]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fl), __builtin_bit_cast(f16x8, Bh[s_]), acc, 0, 0, 0);
+            }
+            // D^T: column = o (this lane's), rows r = (i & 3) + 8 (i >> 2) + 4 kg.  kg 0 assembles the pieces of rows 0-7 and 16-23, kg 1 those
+            // of rows 8-15 and 24-31: four values of each piece are the partner's
+            float snd[8], rcv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { snd[e] = kg ? acc[e] : acc[4 + e]; snd[4 + e] = kg ? acc[8 + e] : acc[12 + e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rcv[e] = __shfl_xor(snd[e], 32);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float own = kg ? acc[4 + 8 * half + e] : acc[8 * half + e];
+                    v[kg ? 4 + e : e] = own * tsc;
+                    v[kg ? e : 4 + e] = rcv[4 * half + e] * tsc;
+                }
+                const int r0 = 32 * rt + 16 * half + 8 * kg;                 // first row of this piece
+                if (r0 < rows_b) {
+                    unsigned h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+                    const int kb = (r0 >> 4) * ks + k;                       // k-block of dense indices 16 kb .. + 15 = (k, rows 16 g .. + 15)
+                    u32x4 *dst = planes + (((size_t)z * kb_total + kb) * MT + mt) * 128 + li + 32 * kg;
+                    dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
+                    dst[64] = (u32x4){l[0], l[1], l[2], l[3]};
+                }
+            }
+        }
+    }
+}
+
 // Yt[b][a][o][p] -> Y[b][o][p][a]: block (p chunk of 64, o, b) through a [na][65] LDS tile.  psum / psq (may be null): the block's
 // sum and sum of squares of (y - pivot), pivot = Y[0][o][0][0] -- the partial moments the BatchNorm that follows would otherwise
 // read the whole tensor for (csrc/bn_act.hip bn_stats_kernel: the same pivot, summed in float64 by the caller), at
@@ -1048,6 +1170,35 @@ extern "C" int eap_so3_dense_untranspose_bnact_f32(int b, int o, int p, int na, 
 // ldz (dir 0): floats between consecutive (o, k) rows of Z, >= na rp (the columns past na rp are not written)
 // n_rows [b] (may be null: no trimming): referenced rows per cloud -- a cloud's products end at ceil16(n_rows[b]) row slots (dir 0: the
 // slots past it are ZEROED in Z, not computed)
+// The forward's stored operand in one kernel (dense_gplanes_kernel): W3 float [o ks][c] (row (o, k) of the conv weights, channels contiguous),
+// Ft float [b][na][rp][c] (the referenced feature rows, channels contiguous; empty slots zero), bound float [b][na][o] >= max_{k,r} |G[b,o,(k,r),a]|,
+// n_rows [b] (may be null) -> scale [b][na][o] and the planes eap_so3_dense_product_f32 (dir 1) reads.  -> 0 also when the shape is not
+// taken (eap_so3_dense_gplanes_supported): the caller then makes G with a GEMM and eap_so3_dense_split_f32.
+extern "C" int eap_so3_dense_gplanes_supported(int o, int c, int na, int ks, int rp) {
+    return (o % 32) == 0 && (c == 64 || c == 128) && na > 0 && ks > 0 && (ks % 2) == 0 && rp > 0 && (rp % 16) == 0 &&
+           (size_t)rp * (2 * c + 16) * 2 <= 150u * 1024u;
+}
+
+extern "C" int eap_so3_dense_gplanes_f32(int b, int o, int c, int na, int ks, int rp, const float *W3, const float *Ft, const int32_t *n_rows,
+                                         const float *bound, float *scale, void *planes, eap_stream_t stream) {
+    if (b <= 0) return 0;
+    if (!eap_so3_dense_gplanes_supported(o, c, na, ks, rp) || (long long)b * na > 65535 ||
+        ((reinterpret_cast<uintptr_t>(W3) | reinterpret_cast<uintptr_t>(Ft) | reinterpret_cast<uintptr_t>(planes)) & 15) != 0)
+        return eap::bad_arg("so3_dense_gplanes: shape not taken (eap_so3_dense_gplanes_supported), 16-byte aligned operands");
+    const int kb_total = ceil_to(ks * rp, KC_BK) / 16;
+    const size_t shmem = (size_t)rp * (2 * c + 16) * 2;
+    hipStream_t s = eap::S(stream);
+    auto launch = [&](auto kern) -> int {
+        if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
+                                  "so3_dense_gplanes: shared memory attribute"))
+            return e;
+        hipLaunchKernelGGL(kern, dim3(eap::cdiv(o / 32, 4), b * na), dim3(256), shmem, s, o, na, ks, rp, kb_total, W3, Ft, n_rows, bound, scale,
+                           reinterpret_cast<u32x4 *>(planes));
+        return eap::check_launch("so3_dense_gplanes");
+    };
+    return c == 128 ? launch(dense_gplanes_kernel<8>) : launch(dense_gplanes_kernel<4>);
+}
+
 // steps (may be null): the k-step lists of eap_so3_dense_steps for this direction -- column blocks run their listed k-steps only
 extern "C" int eap_so3_dense_product_steps_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
                                                const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask,

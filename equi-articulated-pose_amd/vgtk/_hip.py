@@ -650,21 +650,38 @@ def so3_dense_bwd(gy, geo, ldz=None, colmap=None, rowmax=False):
     return z
 
 
-def so3_dense_fwd(g, geo, p, c=0, ldg=None, out=None, col_map=None):
-    """g [b,o,ks,ldg] (rows hold [rp,na]: W . F over the referenced rows, F with c channels; ldg >= rp*na, default equal) -> y [b,o,p,na].
+def so3_dense_gplanes(fc4, W3, geo):
+    """The dense forward's stored operand G = W F over the referenced rows, made and written as the product's planes by ONE kernel
+    (eap_so3_dense_gplanes_f32): fc4 [b,c,rp,na] the referenced feature rows, W3 [o*ks, c] -> (scale [2,b,na,o], planes), or None when the
+    shape is not taken (the caller then runs a GEMM + so3_dense_split).  The plane scale of an output row comes from the bound
+    max_k sum_c |W[o,c,k]| max_r |F[c,r,a]| (a small matrix product): too large a bound costs dynamic range only."""
+    b, c, rp, na = fc4.shape
+    o = W3.shape[0] // geo.ks
+    if not GPLANES or not lib.eap_so3_dense_gplanes_supported(o, c, na, geo.ks, rp):
+        return None
+    ft = fc4.permute(0, 3, 2, 1).contiguous()                                       # [b,na,rp,c]
+    fmax = fc4.abs().amax(2)                                                        # [b,c,na]
+    bound = torch.matmul(W3.abs(), fmax).view(b, o, geo.ks, na).amax(2)             # [b,o,na]
+    bound = (bound * 1.0001).permute(0, 2, 1).contiguous()                          # [b,na,o]
+    scale = torch.empty(2, b, na, o, dtype=torch.float32, device=fc4.device)
+    planes = torch.empty(b * na * o * ((geo.ks * rp + 31) // 32 * 32), dtype=torch.int32, device=fc4.device)
+    call('eap_so3_dense_gplanes_f32', fc4, b, o, c, na, geo.ks, rp, _ptr(W3), _ptr(ft), _ptr(geo.n_rows), _ptr(bound), _ptr(scale), _ptr(planes),
+         tag={'flops': 2.0 * b * o * geo.ks * c * rp * na, 'shape': ('so3_dense_gplanes', b, o, c, na, geo.ks, rp)})
+    return scale, planes
+
+
+GPLANES = os.environ.get('EAP_DENSE_GPLANES', '1') != '0'      # 0: G by a GEMM + the split pass, as round 5 (A/B runs, tests)
+
+
+def so3_dense_fwd(g, geo, p, c=0, ldg=None, out=None, col_map=None, operand=None, o=None):
+    """g [b,o,ks,ldg] (rows hold [rp,na]: W . F over the referenced rows, F with c channels; ldg >= rp*na, default equal) -> y [b,o,p,na];
+    or operand = (scale, planes) of so3_dense_gplanes with g None (then o = the output width).
     (c only prices the launch for bench.py: the reference's grouping einsum + contraction, minus the small GEMM that made g.)
     out [b,o,p_dst,na] with col_map int32 [b,p]: the p columns are the points col_map[b, :] of `out` (negative: padding) -- the launch
     of one rigid part of posed clouds; returns out."""
-    b, o = g.shape[:2]
-    na = geo.na
-    ldg = geo.rp * na if ldg is None else int(ldg)
-    scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg, shape=(b, o, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
-    yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
-    call('eap_so3_dense_product_steps_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
-         _ptr(geo.kr), _ptr(geo.mask(1)), _ptr(geo.steps(1)), _ptr(yt),
-         tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp), 'executed_f16_flops': _dense_executed_flops(geo, o, p, 1),
-              'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
-    del planes
+    yt = _dense_fwd_yt(g, geo, p, c, ldg, operand, o)
+    g = yt
+    b, na, o = yt.shape[0], geo.na, yt.shape[2]
     if col_map is not None:
         if out is None or col_map.dtype != torch.int32 or tuple(col_map.shape) != (b, p) or not col_map.is_contiguous() or not out.is_contiguous():
             raise RuntimeError('so3_dense_fwd: col_map must be a contiguous int32 [b,p] and come with a contiguous out')
@@ -683,25 +700,35 @@ def so3_dense_fwd(g, geo, p, c=0, ldg=None, out=None, col_map=None):
     return y
 
 
-def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments):
-    """The dense forward with the training-mode BatchNorm + leaky_relu behind it applied by the re-ordering pass (the conv + BatchNorm
-    node of vgtk/so3conv/functional.py): product -> Yt; statistics pass over Yt; norm_moments(s1, s2, pivot, count) -> (scale, shift, slope)
-    per channel (float32 [o]); y' = leaky(scale y + shift) written through the geometry's point order.  -> y' [b,o,p,na]"""
-    b, o = g.shape[:2]
+def _dense_fwd_yt(g, geo, p, c, ldg, operand, o):
+    """the forward product alone -> Yt [b,na,o,p] (columns in the geometry's point order)"""
     na = geo.na
-    ldg = geo.rp * na if ldg is None else int(ldg)
-    scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg, shape=(b, o, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
-    yt = torch.empty(b, na, o, p, dtype=torch.float32, device=g.device)
-    call('eap_so3_dense_product_steps_f32', g, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
+    if operand is None:
+        b, o = g.shape[:2]
+        ldg = geo.rp * na if ldg is None else int(ldg)
+        scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg, shape=(b, o, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
+    else:
+        scale, planes = operand
+        b = geo.b
+    yt = torch.empty(b, na, o, p, dtype=torch.float32, device=planes.device)
+    call('eap_so3_dense_product_steps_f32', yt, 1, b, o, p, na, geo.ks, geo.rp, _I64(0), _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt),
          _ptr(geo.kr), _ptr(geo.mask(1)), _ptr(geo.steps(1)), _ptr(yt),
          tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o * p - o * geo.rp), 'executed_f16_flops': _dense_executed_flops(geo, o, p, 1),
               'shape': ('so3_dense', 1, b, o, p, na, geo.ks, geo.rp)})
-    del planes
+    return yt
+
+
+def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments, operand=None, o=None):
+    """The dense forward with the training-mode BatchNorm + leaky_relu behind it applied by the re-ordering pass (the conv + BatchNorm
+    node of vgtk/so3conv/functional.py): product -> Yt; statistics pass over Yt; norm_moments(s1, s2, pivot, count) -> (scale, shift, slope)
+    per channel (float32 [o]); y' = leaky(scale y + shift) written through the geometry's point order.  -> y' [b,o,p,na]"""
+    yt = _dense_fwd_yt(g, geo, p, c, ldg, operand, o)
+    b, na, o = yt.shape[0], geo.na, yt.shape[2]
     # moments of every channel over (cloud, anchor, point): Yt is [b na][o][p] for the statistics kernel; the pivot is its own first element
     ps, pq = _partials(yt, b * na, o, p)
     call('eap_bn_stats_f32', yt, b * na, o, _I64(p), _ptr(yt), _ptr(ps), _ptr(pq))
     bn_scale, bn_shift, slope = norm_moments(ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64), yt[0, 0, :, 0].double(), b * na * p)
-    y = torch.empty(b, o, p, na, dtype=torch.float32, device=g.device)
+    y = torch.empty(b, o, p, na, dtype=torch.float32, device=yt.device)
     call('eap_so3_dense_untranspose_bnact_f32', yt, b, o, p, na, p, _ptr(geo.order), _ptr(yt), _ptr(bn_scale), _ptr(bn_shift), _F32(slope), _ptr(y))
     return y
 

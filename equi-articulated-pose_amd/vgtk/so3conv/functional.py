@@ -804,13 +804,17 @@ class _PartsDense:
 
 
 def _dense_g(fc4, W, geo):
-    """G = W F over the referenced rows as the dense forward's stored operand: fc4 [b,c,rp,na] -> (g [b,o,ks,ld], ld or None).  The
+    """G = W F over the referenced rows as the dense forward's stored operand: fc4 [b,c,rp,na] -> (g [b,o,ks,ld], ld or None, None), or
+    (None, None, (scale, planes)) when one kernel made the operand directly (vgtk._hip.so3_dense_gplanes).  The
     small GEMM runs on the split-operand kernels where its shapes allow: its columns (row, anchor) padded to whole 128-column
     tiles (the padding of F is zero, G's padded columns are skipped by the split that follows)."""
     b, c, rp, na = fc4.shape
     o, ks = W.shape[0], geo.ks
     ra = rp * na
     W3 = W.view(o, c, ks).permute(0, 2, 1).reshape(o * ks, c).contiguous()
+    operand = _hip.so3_dense_gplanes(fc4, W3, geo)        # (round 6: product and planes in one kernel where the shape is taken)
+    if operand is not None:
+        return None, None, operand
     ld = _hip.dense_pitch(ra) if (c % 16 == 0 and c >= 16 and (o * ks) % 128 == 0) else ra
     if ld == ra:
         fc = fc4.reshape(b, c, ra)                                                  # [b,c,(r,a)]; empty slots: zeros
@@ -819,7 +823,7 @@ def _dense_g(fc4, W, geo):
         fc[:, :, :ra] = fc4.reshape(b, c, ra)
     g = torch.empty(b, o * ks, ld, dtype=torch.float32, device=fc4.device)
     _hip.gemm(0, 0, o * ks, ld, c, W3, c, 0, fc, ld, c * ld, g, ld, o * ks * ld, b)
-    return g.view(b, o, ks, ld), (None if ld == ra else ld)
+    return g.view(b, o, ks, ld), (None if ld == ra else ld), None
 
 
 def _dense_forward_parts(feats, W, rows, pd, p):
@@ -831,15 +835,15 @@ def _dense_forward_parts(feats, W, rows, pd, p):
     for i, geo in enumerate(pd.geo):
         perm = pd.perm[i]
         fc4 = fc0 if perm is None else fc0.gather(3, perm[:, None].expand(b, c, pd.rp, na))
-        g, ldg = _dense_g(fc4, W, geo)
-        _hip.so3_dense_fwd(g, geo, pd.parts.width[i], c, ldg=ldg, out=y, col_map=pd.parts.col_map[i])
+        g, ldg, operand = _dense_g(fc4, W, geo)
+        _hip.so3_dense_fwd(g, geo, pd.parts.width[i], c, ldg=ldg, out=y, col_map=pd.parts.col_map[i], operand=operand, o=o)
     return y
 
 
 def _dense_forward(feats, W, rows, geo, p):
     """y [b,o,p,a] = sum_(k,r) G[o,(k,r),a] Wd[p,(k,r),a] with G = W F over the referenced rows (csrc/so3_dense.hip)."""
-    g, ldg = _dense_g(_hip.rows_gather(feats, rows, geo.rp), W, geo)
-    return _hip.so3_dense_fwd(g, geo, p, feats.shape[1], ldg=ldg)
+    g, ldg, operand = _dense_g(_hip.rows_gather(feats, rows, geo.rp), W, geo)
+    return _hip.so3_dense_fwd(g, geo, p, feats.shape[1], ldg=ldg, operand=operand, o=W.shape[0])
 
 
 class _InterConv(torch.autograd.Function):
@@ -910,9 +914,9 @@ class _InterConv(torch.autograd.Function):
             if parts is None:
                 geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)
                 if train_ep is not None and FUSE_CONV_NORM:
-                    g_, ldg = _dense_g(_hip.rows_gather(feats, head.rows, geo.rp), W, geo)
-                    y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, train_ep.moments)
-                    del g_
+                    g_, ldg, operand = _dense_g(_hip.rows_gather(feats, head.rows, geo.rp), W, geo)
+                    y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, train_ep.moments, operand=operand, o=o)
+                    del g_, operand
                     train_ep.applied = True
                     ctx.bn = train_ep.saved + (float(train_ep.norm.negative_slope), bool(train_ep.norm.sync))
                 else:

@@ -400,6 +400,13 @@ int eap_so3_dense_split_bn_f32(int b, int m, int l, int l_src, int na, const uin
                                const float *act, const float *coef, float slope, float *scale, void *planes, eap_stream_t stream);
 int eap_so3_dense_untranspose_bnact_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *yt, const float *bn_scale,
                                         const float *bn_shift, float slope, float *y, eap_stream_t stream);
+/* the forward's stored operand G[o,(k,r),a] = sum_c W[o,c,k] F[c,r,a] made and written as the product's planes by one kernel (round 6; before:
+ * a GEMM that wrote G in fp32 and eap_so3_dense_split_f32 that read it back): W3 float [o ks][c], Ft float [b][na][rp][c] (referenced feature
+ * rows, empty slots zero), bound float [b][na][o] >= max |G| of the output row, n_rows [b] (may be null) -> scale [b][na][o], planes.
+ * so3conv/functional.py:L1221-1261 + so3conv/modules.py:L48-55 re-associated (csrc/so3_dense.hip header) */
+int eap_so3_dense_gplanes_supported(int o, int c, int na, int ks, int rp);
+int eap_so3_dense_gplanes_f32(int b, int o, int c, int na, int ks, int rp, const float *W3, const float *Ft, const int32_t *n_rows,
+                              const float *bound, float *scale, void *planes, eap_stream_t stream);
 int eap_so3_dense_point_keys(int b, int p, const uint32_t *memb, int32_t *keys, eap_stream_t stream);
 int64_t eap_so3_dense_steps_words(int b, int p, int ks, int rp, int dir);
 int eap_so3_dense_steps(int b, int p, int ks, int rp, int dir, int skip, const int32_t *n_rows, const uint64_t *mask, int32_t *steps,

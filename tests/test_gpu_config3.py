@@ -83,21 +83,20 @@ def test_config3_composite_step_at_full_size():
         again = model(xyz, pose)
         same = float(again[0]) == l0 and all(torch.equal(again[1][k], v) for k, v in o0.items())
         if not same:
-            # Seen once in eight runs of the whole suite (never in isolation, never with the hot-path kernels alone -- the three
-            # backbones are compared bit for bit below, and tools/gpu/uninit_check.py finds no read of unwritten memory): the layers
-            # behind the backbones are torch modules whose BLAS may pick an atomics-based algorithm.  Then two of three forwards must
-            # still be bit-equal and the odd one within rounding.
+            # Round-5 advisor finding: this assert was once relaxed to "two of three" after ONE mismatch in eight runs of the whole suite
+            # (never in isolation: tools/gpu/config3_flake_hunt.py, 36 forwards with the allocator's cache perturbed and NaN-filled between
+            # them, every stage bit-equal -- profiles/r06_config3_flake_hunt.txt; tools/gpu/uninit_check.py finds no read of unwritten
+            # memory).  It is strict again: a mismatch fails, and says WHICH stage differs first, with torch's own kernels pinned to their
+            # deterministic algorithms for the comparison (rocBLAS atomics off) -- if the stages differ even then it is this package's bug.
             diffs = {k: float((again[1][k].double() - v.double()).abs().max()) for k, v in o0.items()}
-            third = model(xyz, pose)
-            twin = again if float(third[0]) == float(again[0]) else None
-            if twin is None:
-                assert float(third[0]) == l0 and all(torch.equal(third[1][k], v) for k, v in o0.items()), (l0, float(again[0]), float(third[0]), diffs)
-            else:
-                assert all(torch.equal(third[1][k], again[1][k]) for k in o0), (l0, float(again[0]), float(third[0]), diffs)
-            assert abs(float(again[0]) - l0) <= 1e-5 * abs(l0), (l0, float(again[0]), diffs)
-            import warnings
-            warnings.warn(f'config-3 composite forward differed once between two calls: loss {l0} vs {float(again[0])}, max differences {diffs}')
-            del third
+            torch.use_deterministic_algorithms(True, warn_only=True)
+            try:
+                f1, f2 = C3.stage_fingerprints(model, xyz, pose), C3.stage_fingerprints(model, xyz, pose)
+            finally:
+                torch.use_deterministic_algorithms(False)
+            first = next((k for k in f1 if f1[k] != f2[k]), None)
+            raise AssertionError(f'config-3 composite forward differed between two calls: loss {l0} vs {float(again[0])}, max differences {diffs}; '
+                                 f'first differing stage under deterministic torch algorithms: {first}')
         del again
         # the hot path itself: the three backbones twice, bit for bit
         for bb in (model.glb_backbone, model.backbone, model.backbone_sec):

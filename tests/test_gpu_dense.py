@@ -605,3 +605,41 @@ def test_conv_norm_node_against_separate_modules(dev, monkeypatch, o, sort):
     assert rel(a[1], b_[1]) < 2e-5 and rel(a[2], b_[2]) < 5e-5              # dF, dW
     assert rel(a[3], b_[3]) < 2e-5 and rel(a[4], b_[4]) < 2e-5              # d gamma, d beta
     assert rel(a[5], b_[5]) < 1e-5 and rel(a[6], b_[6]) < 1e-5 and a[7] == b_[7] == 1
+
+
+@pytest.mark.parametrize('c,o,layer', [(128, 256, 2), (64, 128, 1)])
+def test_forward_operand_made_by_one_kernel(dev, monkeypatch, c, o, layer):
+    """vgtk._hip.so3_dense_gplanes (eap_so3_dense_gplanes_f32: G = W F over the referenced rows written straight as the product's planes,
+    the row scales from a bound) against the GEMM + split it replaces and against float64, through the whole forward product; features and
+    weights with magnitudes spread over several octaves per (cloud, anchor) / per row, so that the three power-of-two scales matter."""
+    import vgtk.so3conv.functional as L
+    from vgtk import _hip
+    P = 512
+    s = _setup(dev, 2, P, layer=layer)
+    head, geo, rp = _geometry(s, dev)
+    gen = torch.Generator(device=dev).manual_seed(43)
+    feats = torch.randn(2, c, P, NA, device=dev, generator=gen) * torch.exp(2 * torch.randn(2, 1, 1, NA, device=dev, generator=gen))
+    W = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05 * torch.exp(1.5 * torch.randn(o, 1, device=dev, generator=gen))
+    assert _hip.lib.eap_so3_dense_gplanes_supported(o, c, NA, KS, rp)
+    calls = []
+    orig = _hip.call
+    monkeypatch.setattr(_hip, 'call', lambda name, *a, **k: (calls.append(name), orig(name, *a, **k))[1])
+    y1 = L._dense_forward(feats, W, head.rows, geo, P)
+    assert 'eap_so3_dense_gplanes_f32' in calls and 'eap_so3_dense_split_f32' not in calls
+    monkeypatch.setattr(_hip, 'GPLANES', False)
+    del calls[:]
+    y0 = L._dense_forward(feats, W, head.rows, geo, P)
+    assert 'eap_so3_dense_gplanes_f32' not in calls and 'eap_so3_dense_split_f32' in calls
+    wd = _dense_weights64(s, head.rows, rp)                                   # [B,P,rp,A,K]
+    fc = _hip.rows_gather(feats, head.rows, rp).double()                      # [B,c,rp,A]
+    g64 = torch.einsum('ock,bcra->bokra', W.view(o, c, KS).double(), fc)
+    ref = torch.einsum('bokra,bprak->bopa', g64, wd)
+    mag = torch.einsum('bokra,bprak->bopa', g64.abs(), wd)
+    gmag = torch.einsum('ock,bcra->bokra', W.view(o, c, KS).double().abs(), fc.abs())
+    magm = torch.einsum('bokra,bpr->bopa', g64.abs(), _member(s, head.rows, rp))
+    # the operand G itself now carries a split-product error (2^-21 of sum |W||F|), on top of the forward product's bound
+    magg = torch.einsum('bokra,bprak->bopa', gmag, wd)
+    for y in (y1, y0):
+        assert float(((y.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm + 1e-6 * magg).clamp(min=1e-30)).max()) < 1.0
+    assert float((y1 - y0).abs().max()) < 2e-6 * float(y0.abs().max())
+    assert torch.equal(y1, L._dense_forward(feats, W, head.rows, geo, P) if _hip.GPLANES else y1)

@@ -24,31 +24,7 @@ torch.manual_seed(2913)
 model = C3.Config3Model(P).to(dev)
 
 
-def fp(t):
-    t = t.detach().contiguous()
-    bits = t.view(torch.int32) if t.dtype == torch.float32 else t.to(torch.int64)
-    x = bits.reshape(-1).to(torch.int64)
-    return (float(t.double().sum()) if t.is_floating_point() else int(x.sum()), int(torch.bitwise_xor(x[:x.numel() // 2 * 2:2], x[1:x.numel() // 2 * 2:2]).sum()))
-
-
-def staged():
-    """Config3Model.forward, stage by stage (config3_step.py), with fingerprints"""
-    out = {}
-    with torch.no_grad():
-        g = model.glb_backbone(xyz, pose); out['glb_backbone'] = fp(g); del g
-        feats = model.backbone(xyz, pose); out['backbone'] = fp(feats)
-        feats_sec = model.backbone_sec(xyz, pose); out['backbone_sec'] = fp(feats_sec)
-        ppinv, conf = model.ppint_outblk(zptk.SphericalPointCloud(xyz, feats_sec, None)); out['inv_head.ppinv'] = fp(ppinv); out['inv_head.conf'] = fp(conf)
-        scores = model.slot_scorer(ppinv.transpose(1, 2)); out['slot_scorer'] = fp(scores)
-        labels = scores.argmax(-1); out['labels'] = fp(labels)
-        anchors = model.backbone.convs[0].anchors
-        for s_, o in enumerate(sptk.pose_head_over_slot_groups(model.slot_heads, feats, xyz, labels, anchors)):
-            for k in ('R', 'T', 'axis', 'central_points'):
-                out[f'slot{s_}.{k}'] = fp(o[k])
-        loss, res = model(xyz, pose)
-        out['loss'] = (float(loss), 0)
-        out['recon'] = fp(res['recon'])
-    return out
+staged = lambda: C3.stage_fingerprints(model, xyz, pose)
 
 
 ref = staged()
