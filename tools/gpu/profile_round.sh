@@ -15,7 +15,7 @@ if [ -z "$QUICK" ]; then
   ( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 ) > $O/pytest.log 2>&1
   echo "pytest rc $?" >> $O/pytest.log
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
-  timeout 1500 python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+  timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cp $R/gpurun_out/bench_detail.json $O/bench_detail.json
 fi
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/bench_under_rocprof.json 2> $O/prof.err
