@@ -543,17 +543,25 @@ __global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int k
     const float s_out = pow2_scale(bound[(size_t)z * m + o]);
     if (kg == 0) scale[(size_t)z * m + o] = s_out;
     const int rtiles = (rows_b + 31) >> 5;
-    for (int k = 0; k < ks; ++k) {
-        // ---- this lane's half of row (o, k) of W3: channels 16 s + 8 kg .. + 7 of every 16-channel step ----
+    // this lane's half of row (o, k) of W3: channels 16 s + 8 kg .. + 7 of every 16-channel step; the next kernel point's row is requested
+    // before this one's tiles are computed (one wave per SIMD and block: nobody else hides the L2 round trip)
+    f32x4 wn[CSTEPS][2];
+    auto load_w = [&](int k) __attribute__((always_inline)) {
         const f32x4 *wrow = reinterpret_cast<const f32x4 *>(W3 + ((size_t)o * ks + k) * C) + 2 * kg;
+#pragma unroll
+        for (int s_ = 0; s_ < CSTEPS; ++s_) { wn[s_][0] = wrow[4 * s_]; wn[s_][1] = wrow[4 * s_ + 1]; }
+    };
+    load_w(0);
+    for (int k = 0; k < ks; ++k) {
         f32x4 w[CSTEPS][2];
         unsigned wm = 0;
 #pragma unroll
         for (int s_ = 0; s_ < CSTEPS; ++s_) {
-            w[s_][0] = wrow[4 * s_]; w[s_][1] = wrow[4 * s_ + 1];
+            w[s_][0] = wn[s_][0]; w[s_][1] = wn[s_][1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) wm = max(wm, max(__float_as_uint(w[s_][0][e]) & 0x7fffffffu, __float_as_uint(w[s_][1][e]) & 0x7fffffffu));
         }
+        if (k + 1 < ks) load_w(k + 1);
         wm = max(wm, (unsigned)__shfl_xor((int)wm, 32));
         const float sW = pow2_scale(__uint_as_float(wm));
         u32x4 Bh[CSTEPS], Bl[CSTEPS];

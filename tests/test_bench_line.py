@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-CANNED = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r05_[mnp]_bench.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'r06_*bench_detail.json')))
+# full records: the objects round 5 printed as its line, and round 6's bench_detail.json files of complete runs (with the CPU legs)
+CANNED = [f for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r05_[mnp]_bench.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'r06_*bench_detail.json')))
+          if all(k in json.load(open(f)) for k in ('cpu_baseline', 'zpconv_roofline', 'other_configs', 'config3_step'))]
 CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config')
 
 
