@@ -323,7 +323,7 @@ def distributed_report(world, backend, dev):
 def zpconv_roofline(dev, points, clouds=8, channels=64):
     """The standalone native zpconv ops (vgtk.cuda.zpconv.inter_zpconv_forward / _backward, the op the north
     star puts an HBM-roofline target on): algorithmic bytes = idx + w read once, feats / grad
-    read once, out / gfeats written once; time = HIP events around 5 launches after 2 warm-up launches.  Separate from
+    read once, out / gfeats written once; time = HIP events around groups of 3 launches after 3 warm-up launches, median of 5 groups.  Separate from
     the timed steps (the shipped models never call this op: they use the fused grouping)."""
     import synth_clouds
     import vgtk.cuda.zpconv as Z
@@ -336,17 +336,23 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
     feats = torch.randn(clouds, channels, points, NA, device=dev)
     byts = 4.0 * clouds * (2.0 * points * NA * KS * NN + channels * points * NA + channels * KS * points * NA)
 
-    def timed(fn, warm=2, reps=5):
+    def timed(fn, warm=3, reps=3, groups=5):
+        # median over `groups` event-timed groups of `reps` launches (one group of 5 swung by 10 % between runs of the same build on the
+        # same box -- 8.96 / 9.76 ms for the backward -- depending on what ran just before)
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        ms = []
+        for _ in range(groups):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / reps)
+        ms.sort()
+        return ms[len(ms) // 2]
 
     ms = timed(lambda: Z.inter_zpconv_forward(idx, w, feats))
     grad = torch.randn(clouds, channels, KS, points, NA, device=dev)

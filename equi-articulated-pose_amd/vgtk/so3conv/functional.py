@@ -882,11 +882,11 @@ class _InterConv(torch.autograd.Function):
         # whether the batch can take it is known on the host once the lists' first half has run -- one host wait per layer,
         # only for layers whose width fills the dense kernel's blocks
         probe = parts = None
-        # (a folded inference epilogue does not stop it: the dense forward leaves `epilogue.applied` False and the caller runs the
-        # norm as a pass of its own -- cheaper than giving up the dense product for the 128 -> 512 layer)
+        # (a folded inference epilogue does not stop it: the dense forward's re-ordering pass applies it; posed parts leave
+        # `epilogue.applied` False and the caller runs the norm as a pass of its own)
         # (without gradients only the forward can use the product, and 'auto' takes it at o % 256 == 0 only: no probe -- and no host wait --
         # for an inference call it could not change)
-        if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0)
+        if (DENSE_MODE != 'off' and geometry is not None and lists_ok and (epilogue is None or o % 256 == 0 or DENSE_FWD_NARROW)
                 and (needs_grad or o % 256 == 0 or DENSE_FWD_NARROW or DENSE_MODE == 'force')
                 and _hip.so3_dense_supported(p, na, ks, 16, o)):
             probe = (geometry[2], geometry[3])
@@ -919,6 +919,12 @@ class _InterConv(torch.autograd.Function):
                     del g_, operand
                     train_ep.applied = True
                     ctx.bn = train_ep.saved + (float(train_ep.norm.negative_slope), bool(train_ep.norm.sync))
+                elif epilogue is not None and epilogue.residual is None:
+                    # an inference-mode norm folded into one per-channel map: applied by the re-ordering pass too
+                    g_, ldg, operand = _dense_g(_hip.rows_gather(feats, head.rows, geo.rp), W, geo)
+                    y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, None, operand=operand, o=o, affine=(epilogue.scale, epilogue.shift, epilogue.slope))
+                    del g_, operand
+                    epilogue.applied = True
                 else:
                     y = _dense_forward(feats, W, head.rows, geo, p)
             else:

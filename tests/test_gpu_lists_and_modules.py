@@ -1033,7 +1033,7 @@ def test_streaming_kernels_take_operands_at_any_4_byte_offset(dev):
     assert torch.equal(sptk.masked_max(v, mask), sptk.masked_max(v.clone(), mask))
 
 
-def test_inference_mode_batchnorm_folds_into_the_contraction(dev):
+def test_inference_mode_batchnorm_folds_into_the_contraction(dev, monkeypatch):
     """SURVEY.md 8(f) row 1, second half: in eval mode under no_grad the block layer's BatchNorm2d + leaky_relu (and the
     separable block's skip branch with its sum, base_so3poseconv.py:L214-221, L319-328) ride in the epilogue of the
     contraction that produces their input (csrc/gemm_bf16x3.hip).  Against conv + eval-mode norm as separate passes, and
@@ -1042,7 +1042,9 @@ def test_inference_mode_batchnorm_folds_into_the_contraction(dev):
     import torch.nn.functional as F
     import vgtk.so3conv as sptk
     import vgtk.spconv as zptk
+    import vgtk.so3conv.functional as L
     from vgtk import _hip
+    monkeypatch.setattr(L, 'DENSE_MODE', 'off')            # the list kernels' contraction first; the dense forward's re-ordering pass below
     torch.manual_seed(21)
     B, P = 2, 512
     xyz, _, pose = synth_clouds.laptop_batch(3, B, P)
@@ -1081,6 +1083,20 @@ def test_inference_mode_batchnorm_folds_into_the_contraction(dev):
     assert rel_err(separate.cpu().numpy(), torch_ref.cpu().numpy()) < 2e-6
     assert rel_err(fused.feats.cpu().numpy(), separate.cpu().numpy()) < 2e-6
     assert rel_err(fused_skip.cpu().numpy(), separate_skip.cpu().numpy()) < 2e-6
+    # the same layer on the dense product (the default where few rows are referenced): the folded norm rides in the re-ordering pass
+    monkeypatch.setattr(L, 'DENSE_MODE', 'auto')
+    launched = []
+    _hip.KERNEL_TIMES = launched
+    try:
+        with torch.no_grad():
+            L.FORWARD_LOG = []
+            _, _, _, fused_d = sptk.conv_norm_act(conv, norm, x)
+            flog, L.FORWARD_LOG = L.FORWARD_LOG, None
+    finally:
+        _hip.KERNEL_TIMES = None
+    names = [n for n, *_ in launched]
+    assert flog[0]['dense'] and 'eap_so3_dense_untranspose_bnact_f32' in names and not any(n.startswith('eap_bn_act') for n in names), names
+    assert rel_err(fused_d.feats.cpu().numpy(), separate.cpu().numpy()) < 1e-5
     # training mode or gradients on: nothing is folded, same API
     norm.train()
     _, _, _, tr = sptk.conv_norm_act(conv, norm, x)
