@@ -158,22 +158,55 @@ __global__ __launch_bounds__(256) void dense_member_kernel(int p, int n_sup, int
 __global__ __launch_bounds__(256) void dense_mask_kernel(int p, int ks, int rp, int dir, int wtiles, int steps,
                                                          const unsigned *__restrict__ memb, unsigned *__restrict__ bits) {
     constexpr int W = MEMB_WORDS;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5;
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= (long long)wtiles * steps) return;
     const int wt = (int)(wv / steps), step = (int)(wv - (long long)wt * steps);
     const int nkr = ks * rp;
     unsigned word = 0;
+    // The dense index keeps a group of 16 row slots together (d = (r / 16) 16 ks + 16 k + r % 16), so a wave's 32 weights per lane meet
+    // few membership words: (first version: 32 dependent word reads per lane, 0.25 ms per launch)
+    if (dir == 0 && (ks & 3) == 0) {
+        // backward: the wave tile's 64 columns are 4 kernel points x the 16 rows of ONE group g; the row of a column is 16 g + (lane & 15)
+        // for both column halves j; the k-step's 32 points need one word each -- lane l holds the word of point 32 step + (l & 31)
+        const int g = (64 * wt) / (16 * ks), pt_own = 32 * step + li;
+        const unsigned own = (pt_own < p && 2 * (g >> 1) < 2 * W) ? memb[((size_t)b * p + pt_own) * W + (g >> 1)] : 0u;
+        const int sh = 16 * (g & 1) + (li & 15);
+        const bool col0 = 64 * wt + li < nkr, col1 = 64 * wt + 32 + li < nkr;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int tt = i >> 4, j = (i >> 3) & 1, e = i & 7;
-        const int n = 64 * wt + 32 * j + (lane & 31);
-        const int kk = 32 * step + 16 * tt + 8 * (lane >> 5) + e;
-        const int pt = dir ? n : kk, kr = dir ? kk : n;
-        if (pt < p && kr < nkr) {
-            int k_, r;
-            dense_kr(kr, ks, k_, r);
-            word |= ((memb[((size_t)b * p + pt) * W + (r >> 5)] >> (r & 31)) & 1u) << i;
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned wd = (unsigned)__shfl((int)own, 16 * tt + 8 * kg + e);
+                const unsigned bit = (wd >> sh) & 1u;
+                word |= (col0 ? bit : 0u) << (16 * tt + e);
+                word |= (col1 ? bit : 0u) << (16 * tt + 8 + e);
+            }
+    } else if (dir == 1) {
+        // forward: the k-step's 32 dense indices are 2 kernel points x the 16 rows of ONE group g (16 ks is a multiple of 32): the lane's
+        // rows are 16 g + 8 kg + e for both k-blocks tt; two points per lane (the column halves j), one word each
+        const int d0 = 32 * step, g = d0 / (16 * ks);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pt = 64 * wt + 32 * j + li;
+            const unsigned wd = (pt < p && (g >> 1) < W) ? memb[((size_t)b * p + pt) * W + (g >> 1)] : 0u;
+            const unsigned byte = (wd >> (16 * (g & 1) + 8 * kg)) & 0xffu;                      // rows 16 g + 8 kg .. + 7
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (d0 + 16 * tt < nkr) word |= byte << (16 * tt + 8 * j);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int tt = i >> 4, j = (i >> 3) & 1, e = i & 7;
+            const int n = 64 * wt + 32 * j + (lane & 31);
+            const int kk = 32 * step + 16 * tt + 8 * (lane >> 5) + e;
+            const int pt = dir ? n : kk, kr = dir ? kk : n;
+            if (pt < p && kr < nkr) {
+                int k_, r;
+                dense_kr(kr, ks, k_, r);
+                word |= ((memb[((size_t)b * p + pt) * W + (r >> 5)] >> (r & 31)) & 1u) << i;
+            }
         }
     }
     bits[(((size_t)b * wtiles + wt) * steps + step) * 64 + lane] = word;
@@ -591,9 +624,15 @@ __global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int k
             }
             // D^T: column = o (this lane's), rows r = (i & 3) + 8 (i >> 2) + 4 kg.  kg 0 assembles the pieces of rows 0-7 and 16-23, kg 1 those
             // of rows 8-15 and 24-31: four values of each piece are the partner's
+            // (every select below picks between two NAMED values: written as acc[kg ? i : j] hipcc turns the choice into a dynamic index into
+            // the accumulator vector -- sixteen compare + select pairs per element, ~600 idle cycles of hazard padding per tile)
+            float av[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { av[i] = acc[i]; asm volatile("" : "+v"(av[i])); }
+            const bool hi = kg != 0;
             float snd[8], rcv[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { snd[e] = kg ? acc[e] : acc[4 + e]; snd[4 + e] = kg ? acc[8 + e] : acc[12 + e]; }
+            for (int e = 0; e < 4; ++e) { snd[e] = hi ? av[e] : av[4 + e]; snd[4 + e] = hi ? av[8 + e] : av[12 + e]; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) rcv[e] = __shfl_xor(snd[e], 32);
 #pragma unroll
@@ -601,9 +640,9 @@ __global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int k
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float own = kg ? acc[4 + 8 * half + e] : acc[8 * half + e];
-                    v[kg ? 4 + e : e] = own * tsc;
-                    v[kg ? e : 4 + e] = rcv[4 * half + e] * tsc;
+                    const float own = (hi ? av[4 + 8 * half + e] : av[8 * half + e]) * tsc, got = rcv[4 * half + e] * tsc;
+                    v[e] = hi ? got : own;
+                    v[4 + e] = hi ? own : got;
                 }
                 const int r0 = 32 * rt + 16 * half + 8 * kg;                 // first row of this piece
                 if (r0 < rows_b) {

@@ -239,6 +239,11 @@ def gemm_epilogue(transB, M, N, K, A, lda, B, ldb, strideB, C, ldc, strideC, bat
     return True
 
 
+def gemm_nn_takes_split(M, N, K, A, lda, B, ldb):
+    """Would gemm(0, 0, ...) with these operands (one item) run on a split-operand kernel?"""
+    return bool(SPLIT_BF16_CONTRACTION and lib.eap_gemm_bf16x3_nn_f32_supported(M, N, K, _ptr(A), _I64(lda), _ptr(B), _I64(ldb), _I64(0)))
+
+
 def gemm_reduce_takes_split(M, N, K, A, lda, strideA, B, ldb, strideB, ldc):
     """Would gemm_reduce(0, 1, ...) with these operands run on the split-bf16 kernel?"""
     return bool(SPLIT_BF16_CONTRACTION and lib.eap_gemm_bf16x3_reduce_f32_supported(M, N, K, _ptr(A), _I64(lda), _I64(strideA), _ptr(B), _I64(ldb),
@@ -718,16 +723,20 @@ def _dense_fwd_yt(g, geo, p, c, ldg, operand, o):
     return yt
 
 
-def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments, operand=None, o=None):
+def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments, operand=None, o=None, affine=None):
     """The dense forward with the training-mode BatchNorm + leaky_relu behind it applied by the re-ordering pass (the conv + BatchNorm
     node of vgtk/so3conv/functional.py): product -> Yt; statistics pass over Yt; norm_moments(s1, s2, pivot, count) -> (scale, shift, slope)
-    per channel (float32 [o]); y' = leaky(scale y + shift) written through the geometry's point order.  -> y' [b,o,p,na]"""
+    per channel (float32 [o]); y' = leaky(scale y + shift) written through the geometry's point order.  affine = (scale, shift, slope)
+    instead of norm_moments: an inference-mode norm folded into one per-channel map (FoldedEpilogue), no statistics pass.  -> y' [b,o,p,na]"""
     yt = _dense_fwd_yt(g, geo, p, c, ldg, operand, o)
     b, na, o = yt.shape[0], geo.na, yt.shape[2]
-    # moments of every channel over (cloud, anchor, point): Yt is [b na][o][p] for the statistics kernel; the pivot is its own first element
-    ps, pq = _partials(yt, b * na, o, p)
-    call('eap_bn_stats_f32', yt, b * na, o, _I64(p), _ptr(yt), _ptr(ps), _ptr(pq))
-    bn_scale, bn_shift, slope = norm_moments(ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64), yt[0, 0, :, 0].double(), b * na * p)
+    if affine is not None:
+        bn_scale, bn_shift, slope = affine[0].contiguous(), affine[1].contiguous(), float(affine[2])
+    else:
+        # moments of every channel over (cloud, anchor, point): Yt is [b na][o][p] for the statistics kernel; the pivot is its own first element
+        ps, pq = _partials(yt, b * na, o, p)
+        call('eap_bn_stats_f32', yt, b * na, o, _I64(p), _ptr(yt), _ptr(ps), _ptr(pq))
+        bn_scale, bn_shift, slope = norm_moments(ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64), yt[0, 0, :, 0].double(), b * na * p)
     y = torch.empty(b, o, p, na, dtype=torch.float32, device=yt.device)
     call('eap_so3_dense_untranspose_bnact_f32', yt, b, o, p, na, p, _ptr(geo.order), _ptr(yt), _ptr(bn_scale), _ptr(bn_shift), _F32(slope), _ptr(y))
     return y
