@@ -671,7 +671,7 @@ def so3_dense_gplanes(fc4, W3, geo):
     scale = torch.empty(2, b, na, o, dtype=torch.float32, device=fc4.device)
     planes = torch.empty(b * na * o * ((geo.ks * rp + 31) // 32 * 32), dtype=torch.int32, device=fc4.device)
     call('eap_so3_dense_gplanes_f32', fc4, b, o, c, na, geo.ks, rp, _ptr(W3), _ptr(ft), _ptr(geo.n_rows), _ptr(bound), _ptr(scale), _ptr(planes),
-         tag={'flops': 2.0 * b * o * geo.ks * c * rp * na, 'shape': ('so3_dense_gplanes', b, o, c, na, geo.ks, rp)})
+         tag={'flops': 0.0, 'shape': ('so3_dense_gplanes', b, o, c, na, geo.ks, rp)})      # (write-bound operand preparation: not priced as matrix work)
     return scale, planes
 
 

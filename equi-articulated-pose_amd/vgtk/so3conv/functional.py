@@ -1093,16 +1093,9 @@ class _InterConv(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[1]:
                 gW = torch.empty_like(W)          # sum_b gy_b x_b^T
-                if ctx.layout == 2 and b > 1 and _hip.gemm_nn_takes_split(o, ck, pa, gy, pa, x, ck):
-                    # X^T [pa, ck]: dW = sum_b dY_b X^T_b, every cloud's product on the split-operand 'nn' kernel (its batched form wants a
-                    # shared A operand; the batch-reducing kernels of this layout run on the fp32 pipe: 15.5 of the 55 ms step at 16 x 512
-                    # points), summed over the clouds in a fixed order
-                    per = torch.empty(b, o, ck, dtype=torch.float32, device=gy.device)
-                    gy3, x3 = gy.view(b, o, pa), x.view(b, pa, ck)
-                    for bi in range(b):
-                        _hip.gemm(0, 0, o, ck, pa, gy3[bi], pa, 0, x3[bi], ck, 0, per[bi], ck, 0, 1)
-                    gW = per.sum(0)
-                elif ctx.layout == 2:     # X^T [pa, ck]: dW = dY X^T is a plain row-major product
+                # (measured and dropped: every cloud's dY_b X^T_b on the split-operand 'nn' kernel instead of the batch-reducing fp32 kernel --
+                # 512 x 3072 outputs over K = 30720 are 48 workgroups without a split of K: 15.5 -> 48 ms at 16 x 512 points)
+                if ctx.layout == 2:     # X^T [pa, ck]: dW = dY X^T is a plain row-major product
                     _hip.gemm_reduce(0, 0, o, ck, pa, gy, pa, o * pa, x, ck, ck * pa, gW, ck, b)
                 else:
                     _hip.gemm_reduce(0, 1, o, ck, pa, gy, pa, o * pa, x, pa, ck * pa, gW, ck, b, b_blocked=ctx.layout == 1)
