@@ -328,6 +328,8 @@ def zpconv_roofline(dev, points, clouds=8, channels=64):
     import synth_clouds
     import vgtk.cuda.zpconv as Z
     import vgtk.cuda.grouping as G
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()            # (the 12 GB operands of this leg from fresh blocks, whatever the legs before it left cached)
     xyz = torch.from_numpy(synth_clouds.laptop_batch(0, clouds, points)[0]).to(dev)
     radius = synth_clouds.backbone_layers(points)[1][2]
     ball = G.ball_query(xyz, xyz, radius, NN)
