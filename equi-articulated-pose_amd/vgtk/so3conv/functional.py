@@ -469,8 +469,14 @@ class _ListHead:
                         dense_bad = dense_bad + ((torch.matmul(r, r.transpose(-1, -2)) - eye.double()).abs().max() > 1e-6).to(torch.int32)
                     elif rot is not None:
                         dense_bad = dense_bad + (rot[:, :, :3, :3] != eye).any().to(torch.int32)
-            stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32), dense_bad.to(torch.int32)])
-            self.host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+            # how many 16-row groups of the referenced rows a point's list touches, averaged per cloud, the largest cloud average x 16:
+            # what the dense product with listed k-steps executes is proportional to it (csrc/so3_dense.hip dense_keys_kernel)
+            groups16 = torch.zeros((), dtype=torch.int32, device=dev)
+            if self.memb is not None:
+                touched = ((self.memb & 0xffff) != 0).sum((1, 2)) + ((self.memb & -65536) != 0).sum((1, 2))       # [b]
+                groups16 = (touched.max().to(torch.float32) * (16.0 / max(idx.shape[1], 1))).to(torch.int32)
+            stats = torch.stack([self.n_rows.max().to(torch.int32), flag.to(torch.int32), dense_bad.to(torch.int32), groups16])
+            self.host = torch.empty(4, dtype=torch.int32, pin_memory=True)
             self.host.copy_(stats, non_blocking=True)
             self.entries = _hip.inv_lists_fill(idx, gx, self.rows, self.off, n_sup) if (prefill and gx is not None) else None
             self.event = torch.cuda.Event()
@@ -500,8 +506,13 @@ class _ListHead:
     def decide(self):
         """-> (rcap, any_nonident) as Python values."""
         self.event.synchronize()
-        rcap, flag, _ = self.host.tolist()
+        rcap, flag, _, _ = self.host.tolist()
         return int(rcap), bool(flag)
+
+    def groups_touched(self):
+        """mean number of 16-row groups a point's list touches (the largest per-cloud mean); blocks on the host like decide()"""
+        self.event.synchronize()
+        return int(self.host[3]) / 16.0
 
     def dense_possible(self):
         """every cloud can take the dense product (see __init__); blocks on the host like decide()"""
@@ -642,14 +653,17 @@ FORWARD_LOG = None       # the same for the forward: {'channels', 'dense': the d
 
 # The dense product over the referenced rows (csrc/so3_dense.hip): 'auto' takes it when every cloud of the batch can (no pose
 # rotation, no padded lists) and a cloud references few enough rows: it does rows / nsample times the flops of the list kernels on
-# a pipe ~4.5 x as fast.  The BACKWARD takes it up to DENSE_ROW_FACTOR x nsample rows at any width it supports (128-row blocks are
-# bound by the weight evaluation: 8.9 against 12.1 ms for the 64 -> 128 layer at 280 rows); the FORWARD only where the output
-# width fills 256-row blocks (at 128 it ties with grouping + contraction: 10.0 against 9.5 ms).  'off' never; 'force' whenever the
-# shapes are taken (tests).
+# a pipe ~4.5 x as fast.  Both directions take it up to DENSE_ROW_FACTOR x nsample rows at any width it supports ('off' never; 'force'
+# whenever the shapes are taken: tests).
 DENSE_MODE = os.environ.get('EAP_DENSE', 'auto')
 DENSE_ROW_FACTOR = 5.0
+# ... and beyond that row count (up to the 512 row slots the membership words hold) while a point's list touches few enough 16-row groups: with
+# the listed k-steps the product executes ~ groups_touched x 16 / nsample times the algorithmic flops (x 3 on the fp16 pipe at ~1.3 PFLOP/s)
+# against the list kernels' 0.46 of the fp32 peak -- it wins below ~24 groups; 16 leaves margin for the per-block overheads
+DENSE_MAX_GROUPS = float(os.environ.get('EAP_DENSE_MAX_GROUPS', '16'))
 # the forward at widths that fill 128-row blocks only (the 64 -> 128 layer): with every k-step it tied with grouping + contraction
-# (round 5: 9.0 against 9.1 ms); with the empty k-steps skipped (round 6) it is decided by measurement, profiles/r06_dense_forward_128.txt
+# (round 5: 9.0 against 9.1 ms); with the empty k-steps skipped (round 6) the product wins: 4.2 + 1.3 + 0.9 ms against 5.7 + 3.3, same run
+# 129.2 against 128.0 clouds/s before the operand kernel, more after it
 DENSE_FWD_NARROW = os.environ.get('EAP_DENSE_FWD_128', '1') != '0'
 # a training-mode BatchNorm + leaky_relu behind a conv whose forward runs the dense product joins the conv's node (TrainEpilogue)
 FUSE_CONV_NORM = os.environ.get('EAP_FUSE_CONV_NORM', '1') != '0'
@@ -671,7 +685,7 @@ def _dense_wanted(head, o, p, na, ks, nn, n):
         return 0, False
     if DENSE_MODE == 'force':
         return rp, True
-    if rp > DENSE_ROW_FACTOR * nn:
+    if rp > DENSE_ROW_FACTOR * nn and not (rp <= _hip.DENSE_MAX_ROWS and head.groups_touched() <= DENSE_MAX_GROUPS):
         return 0, False
     return rp, (o % 256 == 0) or DENSE_FWD_NARROW
 

@@ -643,3 +643,26 @@ def test_forward_operand_made_by_one_kernel(dev, monkeypatch, c, o, layer):
         assert float(((y.double() - ref).abs() / (1e-6 * mag + 5e-7 * magm + 1e-6 * magg).clamp(min=1e-30)).max()) < 1.0
     assert float((y1 - y0).abs().max()) < 2e-6 * float(y0.abs().max())
     assert torch.equal(y1, L._dense_forward(feats, W, head.rows, geo, P) if _hip.GPLANES else y1)
+
+
+def test_many_rows_few_groups_take_the_dense_product(dev, monkeypatch):
+    """Beyond 5 x nsample referenced rows the default decision looks at how many 16-row groups a point's list touches (the listed k-steps make
+    the executed work proportional to that, not to the row count): 2048-point clouds with the 512-point plan's deepest radius reference
+    ~410-420 rows per cloud but a list touches ~12 of their 26 groups -> dense rows in both directions, same results as the list kernels;
+    with the bound lowered below that, back to the lists."""
+    import synth_clouds
+    import vgtk.so3conv.functional as L
+    B, P, c, o = 2, 2048, 32, 256
+    _, _, radius, sigma = synth_clouds.backbone_layers(512)[2]
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(91, B, P)[0]).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(47)
+    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
+    y0, gF0, gW0, log0, _ = _layer_run(dev, monkeypatch, 'off', xyz, None, feats0, W0, c, o, radius, sigma)
+    y1, gF1, gW1, log1, y1n = _layer_run(dev, monkeypatch, 'auto', xyz, None, feats0, W0, c, o, radius, sigma)
+    assert log1[0]['regime'] == 'dense rows' and log1[0]['referenced_rows_max'] > 5 * NN, log1
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(y1, y0) < 2e-5 and rel(gF1, gF0) < 2e-5 and rel(gW1, gW0) < 5e-5 and torch.equal(y1n, y1)
+    monkeypatch.setattr(L, 'DENSE_MAX_GROUPS', 4.0)
+    _, _, _, log2, _ = _layer_run(dev, monkeypatch, 'auto', xyz, None, feats0, W0, c, o, radius, sigma)
+    assert log2[0]['regime'] != 'dense rows'
