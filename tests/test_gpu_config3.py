@@ -74,30 +74,32 @@ def test_config3_composite_step_at_full_size():
     model = C3.Config3Model(P).to(dev)
     params = model.trained_parameters()
     opt = torch.optim.Adam(params, lr=1e-4)        # bench.py's rate; 2e-3 (the reduced-size test's) overshoots at full width
-    with torch.no_grad():
-        first = model(xyz, pose)
-        l0, o0 = float(first[0]), {k: first[1][k].clone() for k in ('scores', 'slot_R', 'slot_T', 'labels', 'recon')}
-        del first
-        # (training-mode BatchNorms only move their running statistics between the two calls; the batch statistics they
-        # normalise with are the same)
-        again = model(xyz, pose)
-        same = float(again[0]) == l0 and all(torch.equal(again[1][k], v) for k, v in o0.items())
-        if not same:
-            # Round-5 advisor finding: this assert was once relaxed to "two of three" after ONE mismatch in eight runs of the whole suite
-            # (never in isolation: tools/gpu/config3_flake_hunt.py, 36 forwards with the allocator's cache perturbed and NaN-filled between
-            # them, every stage bit-equal -- profiles/r06_config3_flake_hunt.txt; tools/gpu/uninit_check.py finds no read of unwritten
-            # memory).  It is strict again: a mismatch fails, and says WHICH stage differs first, with torch's own kernels pinned to their
-            # deterministic algorithms for the comparison (rocBLAS atomics off) -- if the stages differ even then it is this package's bug.
-            diffs = {k: float((again[1][k].double() - v.double()).abs().max()) for k, v in o0.items()}
-            torch.use_deterministic_algorithms(True, warn_only=True)
-            try:
+    # Run-to-run reproducibility of the whole composite forward, STRICT (round-5 advisor finding: this assert had been relaxed to "two of
+    # three" after one mismatch in eight runs of the whole suite, never reproduced in isolation -- tools/gpu/config3_flake_hunt.py: 36
+    # forwards with the allocator's cache perturbed and NaN-filled between them, every stage bit-equal, profiles/r06_config3_flake_hunt.txt;
+    # tools/gpu/uninit_check.py finds no read of unwritten memory).  The comparison runs with torch's own kernels pinned to their
+    # deterministic algorithms (rocBLAS atomics off: the layers behind the backbones are torch modules), so that whatever still differs
+    # is this package's; a mismatch fails and names the first stage that differs.
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        with torch.no_grad():
+            first = model(xyz, pose)
+            l0, o0 = float(first[0]), {k: first[1][k].clone() for k in ('scores', 'slot_R', 'slot_T', 'labels', 'recon')}
+            del first
+            # (training-mode BatchNorms only move their running statistics between the two calls; the batch statistics they
+            # normalise with are the same)
+            again = model(xyz, pose)
+            same = float(again[0]) == l0 and all(torch.equal(again[1][k], v) for k, v in o0.items())
+            if not same:
+                diffs = {k: float((again[1][k].double() - v.double()).abs().max()) for k, v in o0.items()}
                 f1, f2 = C3.stage_fingerprints(model, xyz, pose), C3.stage_fingerprints(model, xyz, pose)
-            finally:
-                torch.use_deterministic_algorithms(False)
-            first = next((k for k in f1 if f1[k] != f2[k]), None)
-            raise AssertionError(f'config-3 composite forward differed between two calls: loss {l0} vs {float(again[0])}, max differences {diffs}; '
-                                 f'first differing stage under deterministic torch algorithms: {first}')
-        del again
+                first_bad = next((k for k in f1 if f1[k] != f2[k]), None)
+                raise AssertionError(f'config-3 composite forward differed between two calls: loss {l0} vs {float(again[0])}, max differences {diffs}; '
+                                     f'first differing stage of two more forwards: {first_bad}')
+            del again
+    finally:
+        torch.use_deterministic_algorithms(False)
+    with torch.no_grad():
         # the hot path itself: the three backbones twice, bit for bit
         for bb in (model.glb_backbone, model.backbone, model.backbone_sec):
             f1 = bb(xyz, pose)
