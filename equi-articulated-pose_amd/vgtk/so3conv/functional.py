@@ -1031,6 +1031,7 @@ class _InterConv(torch.autograd.Function):
             # (the padding is never written: garbage columns of gFc nobody reads; the weight gradient contracts over ra columns)
             ldz = _hip.dense_pitch(ra) if (c % 128 == 0 and (o * ks) % 16 == 0 and ctx.needs_input_grad[0]) else ra
             g_bn_w = g_bn_b = None
+            z_bound = None
             if ctx.bn is not None:
                 # the BatchNorm + leaky_relu backward of the node (csrc/bn_act.hip header): one reduction pass over (dL/dy', y'), then gx is
                 # formed inside the split of the product's stored operand
@@ -1044,12 +1045,21 @@ class _InterConv(torch.autograd.Function):
                 coef = torch.stack([k1, k2, k3, beta, inv_gamma]).contiguous()      # [5, o]
                 bound = (k1.abs()[None, :, None] * gmax + k2.abs()[None, :, None] + k3.abs()[None, :, None] * xmax).contiguous()
                 z = _hip.so3_dense_bwd_bn(gy, yact, geo, ldz, coef, bound, slope)
+                if ldz % 4 == 0 and rp % 4 == 0:
+                    # a bound on Z's columns for the feature-gradient GEMM below (it then runs with two fp16 planes per operand instead of
+                    # three bf16 planes, without a pass over Z): |Z[o,k,(a,r)]| = |sum_p gx[o,p,a] w| <= max_o bound[o,a] x (points listing row r)
+                    live = torch.arange(rp, device=gy.device)[None, :] < head.n_rows[:, None]                      # (slots past a cloud's rows: zero columns)
+                    cntf = torch.where(live, head.cnt[:, :rp], torch.zeros_like(head.cnt[:, :rp])).clamp(min=0, max=p).to(torch.float32)
+                    cols = bound.amax(1)[:, :, None] * cntf[:, None, :]                                           # [b,na,rp]
+                    words = torch.zeros(b, ldz // 4, dtype=torch.float32, device=gy.device)
+                    words[:, :ra // 4] = cols.view(b, na, rp // 4, 4).amax(3).view(b, ra // 4)
+                    z_bound = (words.view(torch.int32), 4, 1.0)
             else:
                 z = _hip.so3_dense_bwd(gy, geo, ldz)                                 # [b,o,ks,ldz] rows = [na,rp]: the lists' Z, anchor axis in front
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
                 gFc = torch.empty(b, c, ldz, dtype=torch.float32, device=gy.device)
-                _hip.gemm(0, 0, c, ldz, o * ks, W2, o * ks, 0, z, ldz, o * ks * ldz, gFc, ldz, c * ldz, b)
+                _hip.gemm(0, 0, c, ldz, o * ks, W2, o * ks, 0, z, ldz, o * ks * ldz, gFc, ldz, c * ldz, b, b_bound=z_bound)
                 gF = _hip.rows_scatter(gFc[:, :, :ra].reshape(b, c, na, rp).transpose(2, 3).contiguous(), head.rows, n)
             if ctx.needs_input_grad[1]:
                 fc = _hip.rows_gather(feats, head.rows, rp).transpose(2, 3).contiguous().view(b, c, ra)      # [b,c,(a,r)]
