@@ -694,6 +694,14 @@ def _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz=None):
     """dW[o,(c,k)] = sum_{b,(r,a)} Z[b,o,k,(r,a)] Fc[b,c,(r,a)] for Z [b, o*ks, ra] (row pitch ldz >= ra) and the referenced feature
     rows Fc [b, c, ra] (any order of the (row, anchor) axis, the same in both)."""
     ldz = ra if ldz is None else ldz
+    if c == 64:
+        # 64 feature channels: zero rows up to 128 put the transposed product on the split kernel too (the 64-row one ran on the fp32 pipe)
+        fcp = torch.zeros(b, 128, ra, dtype=torch.float32, device=z.device)
+        fcp[:, :c] = fc.reshape(b, c, ra)
+        if _hip.gemm_reduce_takes_split(128, o * ks, ra, fcp, ra, 128 * ra, z, ldz, o * ks * ldz, o * ks):
+            dt = torch.empty(128, o * ks, dtype=torch.float32, device=z.device)
+            _hip.gemm_reduce(0, 1, 128, o * ks, ra, fcp, ra, 128 * ra, z, ldz, o * ks * ldz, dt, o * ks, b)
+            return dt[:c].reshape(c, o, ks).permute(1, 0, 2).reshape(o, c * ks).contiguous()
     if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ldz, o * ks * ldz, o * ks):
         # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
         # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe
@@ -1029,7 +1037,9 @@ class _InterConv(torch.autograd.Function):
             ra = na * rp
             # Z's rows padded to whole 128-column tiles where that puts the feature-gradient GEMM on the split-operand kernels
             # (the padding is never written: garbage columns of gFc nobody reads; the weight gradient contracts over ra columns)
-            ldz = _hip.dense_pitch(ra) if (c % 128 == 0 and (o * ks) % 16 == 0 and ctx.needs_input_grad[0]) else ra
+            # (c = 64: W2 padded to 128 zero-extended rows for the same reason -- the 64-row product ran on the fp32 pipe: 0.92 ms)
+            pad_c = 128 if (c == 64 and ctx.bn is not None) else c
+            ldz = _hip.dense_pitch(ra) if (pad_c % 128 == 0 and (o * ks) % 16 == 0 and ctx.needs_input_grad[0]) else ra
             g_bn_w = g_bn_b = None
             z_bound = None
             if ctx.bn is not None:
@@ -1058,9 +1068,11 @@ class _InterConv(torch.autograd.Function):
                 z = _hip.so3_dense_bwd(gy, geo, ldz)                                 # [b,o,ks,ldz] rows = [na,rp]: the lists' Z, anchor axis in front
             if ctx.needs_input_grad[0]:
                 W2 = W.view(o, c, ks).permute(1, 0, 2).reshape(c, o * ks).contiguous()
-                gFc = torch.empty(b, c, ldz, dtype=torch.float32, device=gy.device)
-                _hip.gemm(0, 0, c, ldz, o * ks, W2, o * ks, 0, z, ldz, o * ks * ldz, gFc, ldz, c * ldz, b, b_bound=z_bound)
-                gF = _hip.rows_scatter(gFc[:, :, :ra].reshape(b, c, na, rp).transpose(2, 3).contiguous(), head.rows, n)
+                if pad_c != c:
+                    W2 = torch.cat([W2, torch.zeros(pad_c - c, o * ks, dtype=torch.float32, device=gy.device)])
+                gFc = torch.empty(b, pad_c, ldz, dtype=torch.float32, device=gy.device)
+                _hip.gemm(0, 0, pad_c, ldz, o * ks, W2, o * ks, 0, z, ldz, o * ks * ldz, gFc, ldz, pad_c * ldz, b, b_bound=z_bound)
+                gF = _hip.rows_scatter(gFc[:, :c, :ra].reshape(b, c, na, rp).transpose(2, 3).contiguous(), head.rows, n)
             if ctx.needs_input_grad[1]:
                 fc = _hip.rows_gather(feats, head.rows, rp).transpose(2, 3).contiguous().view(b, c, ra)      # [b,c,(a,r)]
                 gW = _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz)
