@@ -558,8 +558,8 @@ def test_sorted_points_against_index_order(dev):
 # ------------------------------------------------------------------------------------------------------------------------
 # conv + training-mode BatchNorm + leaky_relu as one node (round 6)
 # ------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('o,sort', [(256, True), (128, True), (256, False)])
-def test_conv_norm_node_against_separate_modules(dev, monkeypatch, o, sort):
+@pytest.mark.parametrize('c,o,sort', [(32, 256, True), (32, 128, True), (32, 256, False), (64, 128, True), (128, 256, True)])
+def test_conv_norm_node_against_separate_modules(dev, monkeypatch, c, o, sort):
     """vgtk.so3conv.conv_norm_act in training mode with the norm inside the conv's autograd node (the re-ordering pass applies it, the
     backward forms the gradient behind it inside the stored-operand split, the pre-activation is recovered from the OUTPUT) against the
     same conv followed by the BatchNormLeakyReLU module as a pass of its own (pinned against torch's BatchNorm2d + leaky_relu in
@@ -570,7 +570,7 @@ def test_conv_norm_node_against_separate_modules(dev, monkeypatch, o, sort):
     import vgtk.so3conv.functional as L
     from vgtk import _hip
     monkeypatch.setattr(_hip, 'SORT_DENSE_POINTS', sort)
-    B, P, c = 2, 512, 32
+    B, P = 2, 512                                               # (c = 64 / 128: the operand kernel and the padded 64-channel gradient products)
     _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
     xyz = torch.from_numpy(synth_clouds.laptop_batch(71, B, P)[0]).to(dev)
     pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
