@@ -613,7 +613,8 @@ class TrainEpilogue:
         scale = scale64.float()
         shift = (norm.bias.detach().double() - mean * scale64).float()
         inv_gamma = torch.where(gamma == 0, torch.zeros_like(gamma), 1.0 / gamma).float()
-        self.saved = (scale, norm.bias.detach().float().contiguous(), inv_gamma.contiguous(), total)
+        # (copies, not views of the parameters: the backward must see the values this forward normalised with)
+        self.saved = (scale, norm.bias.detach().float().clone(), inv_gamma.contiguous(), total)
         return scale.contiguous(), shift.contiguous(), float(norm.negative_slope)
 
 
