@@ -695,14 +695,8 @@ def _weight_grad_from_z(z, fc, b, c, o, ks, ra, ldz=None):
     """dW[o,(c,k)] = sum_{b,(r,a)} Z[b,o,k,(r,a)] Fc[b,c,(r,a)] for Z [b, o*ks, ra] (row pitch ldz >= ra) and the referenced feature
     rows Fc [b, c, ra] (any order of the (row, anchor) axis, the same in both)."""
     ldz = ra if ldz is None else ldz
-    if c == 64:
-        # 64 feature channels: zero rows up to 128 put the transposed product on the split kernel too (the 64-row one ran on the fp32 pipe)
-        fcp = torch.zeros(b, 128, ra, dtype=torch.float32, device=z.device)
-        fcp[:, :c] = fc.reshape(b, c, ra)
-        if _hip.gemm_reduce_takes_split(128, o * ks, ra, fcp, ra, 128 * ra, z, ldz, o * ks * ldz, o * ks):
-            dt = torch.empty(128, o * ks, dtype=torch.float32, device=z.device)
-            _hip.gemm_reduce(0, 1, 128, o * ks, ra, fcp, ra, 128 * ra, z, ldz, o * ks * ldz, dt, o * ks, b)
-            return dt[:c].reshape(c, o, ks).permute(1, 0, 2).reshape(o, c * ks).contiguous()
+    # (measured and dropped: 64 feature channels zero-padded to 128 rows to reach the split kernel -- 0.66 -> 0.53 ms per step, and the
+    # kernel-against-kernel bar of tests/test_gpu_lists_and_modules.py::test_permuted_clouds_on_the_two_tile_kernel, 2e-6, went to 3.2e-6)
     if _hip.gemm_reduce_takes_split(c, o * ks, ra, fc, ra, c * ra, z, ldz, o * ks * ldz, o * ks):
         # the transposed product Fc_b Z_b^T [c, o*ks] has the tile shape the split-bf16 kernel takes (>= 128 rows,
         # >= 256 columns); Z_b Fc_b^T with its 64-128 columns would stay on the fp32 pipe
