@@ -658,16 +658,18 @@ def so3_dense_bwd(gy, geo, ldz=None, colmap=None, rowmax=False):
 def so3_dense_gplanes(fc4, W3, geo):
     """The dense forward's stored operand G = W F over the referenced rows, made and written as the product's planes by ONE kernel
     (eap_so3_dense_gplanes_f32): fc4 [b,c,rp,na] the referenced feature rows, W3 [o*ks, c] -> (scale [2,b,na,o], planes), or None when the
-    shape is not taken (the caller then runs a GEMM + so3_dense_split).  The plane scale of an output row comes from the bound
-    max_k sum_c |W[o,c,k]| max_r |F[c,r,a]| (a small matrix product): too large a bound costs dynamic range only."""
+    shape is not taken (the caller then runs a GEMM + so3_dense_split).  The plane scale of an output row comes from a bound on its
+    magnitude: too large a bound costs dynamic range only."""
     b, c, rp, na = fc4.shape
     o = W3.shape[0] // geo.ks
     if not GPLANES or not lib.eap_so3_dense_gplanes_supported(o, c, na, geo.ks, rp):
         return None
     ft = fc4.permute(0, 3, 2, 1).contiguous()                                       # [b,na,rp,c]
-    fmax = fc4.abs().amax(2)                                                        # [b,c,na]
-    bound = torch.matmul(W3.abs(), fmax).view(b, o, geo.ks, na).amax(2)             # [b,o,na]
-    bound = (bound * 1.0001).permute(0, 2, 1).contiguous()                          # [b,na,o]
+    # |G[o,(k,r),a]| <= max_k sum_c |W[o,c,k]| x max_{c,r} |F[c,r,a]|: two reductions over small tensors (the tighter sum_c |W| max_r |F_c|
+    # is a matrix product whose launch path cost more host time than it saved range)
+    wsum = W3.abs().sum(1).view(o, geo.ks).amax(1)                                  # [o]
+    fm = fc4.abs().amax((1, 2))                                                     # [b,na]
+    bound = (fm[:, :, None] * (wsum * 1.0001)[None, None, :]).contiguous()          # [b,na,o]
     scale = torch.empty(2, b, na, o, dtype=torch.float32, device=fc4.device)
     planes = torch.empty(b * na * o * ((geo.ks * rp + 31) // 32 * 32), dtype=torch.int32, device=fc4.device)
     call('eap_so3_dense_gplanes_f32', fc4, b, o, c, na, geo.ks, rp, _ptr(W3), _ptr(ft), _ptr(geo.n_rows), _ptr(bound), _ptr(scale), _ptr(planes),
