@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void dense_split_kernel(int nb, int m, int l, 
 //   4 values from a lane, 4 from its partner 32 lanes away -- stored 1 KB per (k-block, plane) and wave.
 //   Rows past the cloud's own prefix (ceil16(n_rows)) are neither computed nor written.
 template <int CSTEPS>                                    // channels / 16
-__global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int ks, int rp, int kb_total, const float *__restrict__ W3,
+__global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int ks, int rp, int rch, int kb_total, const float *__restrict__ W3,
                                                             const float *__restrict__ Ft, const int32_t *__restrict__ n_rows,
                                                             const float *__restrict__ bound, float *__restrict__ scale, u32x4 *__restrict__ planes) {
     constexpr int C = 16 * CSTEPS, PITCH = 2 * C + 16;                      // bytes per LDS row of one plane (+16: rows 272 / 144 bytes apart)
@@ -544,115 +544,122 @@ __global__ __launch_bounds__(256) void dense_gplanes_kernel(int m, int na, int k
     const int z = blockIdx.y, b = z / na;
     const int t = threadIdx.x, lane = t & 63, li = lane & 31, kg = lane >> 5, wave = t >> 6;
     const int rows_b = n_rows ? min((min(n_rows[b], rp) + 15) & ~15, rp) : rp;          // this cloud's row slots (whole groups of 16)
-    unsigned char *Fh = smem, *Fl = smem + (size_t)rp * PITCH;
-    // ---- the anchor's feature rows -> LDS planes ----
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(Ft + ((size_t)z * rp) * C);
-    const int n4 = rows_b * (C / 4);
-    unsigned mx = 0;
-    for (int i = t; i < n4; i += 256) {
-        const f32x4 v = src[i];
-        mx = max(mx, max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
-                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
-    }
-#pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o_));
-    if (lane == 0) s_red[wave] = mx;
-    __syncthreads();
-    const float sF = pow2_scale(__uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]))));
-    for (int i = t; i < n4; i += 256) {
-        const f32x4 v = src[i];                                              // (second read: L2)
-        const int r = i / (C / 4), c4 = i - r * (C / 4);
-        unsigned h0, l0, h1, l1;
-        split2(v.x * sF, v.y * sF, h0, l0);
-        split2(v.z * sF, v.w * sF, h1, l1);
-        *reinterpret_cast<uint2 *>(Fh + (size_t)r * PITCH + c4 * 8) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2 *>(Fl + (size_t)r * PITCH + c4 * 8) = make_uint2(l0, l1);
-    }
-    __syncthreads();
+    unsigned char *Fh = smem, *Fl = smem + (size_t)rch * PITCH;
     const int MT = m >> 5, mt = blockIdx.x * 4 + wave;
-    if (mt >= MT) return;
-    const int o = 32 * mt + li;
+    const bool active = mt < MT;                                             // (wave-uniform; an idle wave still meets the barriers below)
+    const int o = 32 * min(mt, MT - 1) + li;
     // the output row's plane scale, from the bound; also published for the product's epilogue (scale[z][o]: one lane per row)
     const float s_out = pow2_scale(bound[(size_t)z * m + o]);
-    if (kg == 0) scale[(size_t)z * m + o] = s_out;
-    const int rtiles = (rows_b + 31) >> 5;
-    // this lane's half of row (o, k) of W3: channels 16 s + 8 kg .. + 7 of every 16-channel step; the next kernel point's row is requested
-    // before this one's tiles are computed (one wave per SIMD and block: nobody else hides the L2 round trip)
-    f32x4 wn[CSTEPS][2];
-    auto load_w = [&](int k) __attribute__((always_inline)) {
-        const f32x4 *wrow = reinterpret_cast<const f32x4 *>(W3 + ((size_t)o * ks + k) * C) + 2 * kg;
-#pragma unroll
-        for (int s_ = 0; s_ < CSTEPS; ++s_) { wn[s_][0] = wrow[4 * s_]; wn[s_][1] = wrow[4 * s_ + 1]; }
-    };
-    load_w(0);
-    for (int k = 0; k < ks; ++k) {
-        f32x4 w[CSTEPS][2];
-        unsigned wm = 0;
-#pragma unroll
-        for (int s_ = 0; s_ < CSTEPS; ++s_) {
-            w[s_][0] = wn[s_][0]; w[s_][1] = wn[s_][1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wm = max(wm, max(__float_as_uint(w[s_][0][e]) & 0x7fffffffu, __float_as_uint(w[s_][1][e]) & 0x7fffffffu));
+    if (active && kg == 0) scale[(size_t)z * m + o] = s_out;
+    // The anchor's rows pass through LDS in chunks of rch rows (a multiple of 32; all of them at once where they fit: the bench layers);
+    // a chunk has its own power-of-two scale, which the output scale below takes off again.
+    for (int rc0 = 0; rc0 < rows_b; rc0 += rch) {
+        const int nrows = min(rch, rows_b - rc0);
+        if (rc0 > 0) __syncthreads();                                        // everybody is done with the previous chunk's planes
+        // ---- the chunk's feature rows -> LDS planes ----
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(Ft + ((size_t)z * rp + rc0) * C);
+        const int n4 = nrows * (C / 4);
+        unsigned mx = 0;
+        for (int i = t; i < n4; i += 256) {
+            const f32x4 v = src[i];
+            mx = max(mx, max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+                             max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
         }
-        if (k + 1 < ks) load_w(k + 1);
-        wm = max(wm, (unsigned)__shfl_xor((int)wm, 32));
-        const float sW = pow2_scale(__uint_as_float(wm));
-        u32x4 Bh[CSTEPS], Bl[CSTEPS];
 #pragma unroll
-        for (int s_ = 0; s_ < CSTEPS; ++s_) {
-            unsigned h[4], l[4];
-            split2(w[s_][0].x * sW, w[s_][0].y * sW, h[0], l[0]);
-            split2(w[s_][0].z * sW, w[s_][0].w * sW, h[1], l[1]);
-            split2(w[s_][1].x * sW, w[s_][1].y * sW, h[2], l[2]);
-            split2(w[s_][1].z * sW, w[s_][1].w * sW, h[3], l[3]);
-            Bh[s_] = (u32x4){h[0], h[1], h[2], h[3]};
-            Bl[s_] = (u32x4){l[0], l[1], l[2], l[3]};
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o_));
+        if (lane == 0) s_red[wave] = mx;
+        __syncthreads();
+        const float sF = pow2_scale(__uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]))));
+        for (int i = t; i < n4; i += 256) {
+            const f32x4 v = src[i];                                          // (second read: L2)
+            const int r = i / (C / 4), c4 = i - r * (C / 4);
+            unsigned h0, l0, h1, l1;
+            split2(v.x * sF, v.y * sF, h0, l0);
+            split2(v.z * sF, v.w * sF, h1, l1);
+            *reinterpret_cast<uint2 *>(Fh + (size_t)r * PITCH + c4 * 8) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(Fl + (size_t)r * PITCH + c4 * 8) = make_uint2(l0, l1);
         }
-        const float tsc = s_out / (sF * sW);                                // (powers of two: exact)
-        for (int rt = 0; rt < rtiles; ++rt) {
-            f32x16 acc;
+        __syncthreads();
+        if (!active) continue;
+        const int rtiles = (nrows + 31) >> 5;
+        // this lane's half of row (o, k) of W3: channels 16 s + 8 kg .. + 7 of every 16-channel step; the next kernel point's row is requested
+        // before this one's tiles are computed (one wave per SIMD and block: nobody else hides the L2 round trip)
+        f32x4 wn[CSTEPS][2];
+        auto load_w = [&](int k) __attribute__((always_inline)) {
+            const f32x4 *wrow = reinterpret_cast<const f32x4 *>(W3 + ((size_t)o * ks + k) * C) + 2 * kg;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            const int r = min(32 * rt + li, rp - 1);                         // (rows past rp: a valid address, their pieces are not stored)
-            const unsigned char *ah = Fh + (size_t)r * PITCH + 16 * kg, *al = Fl + (size_t)r * PITCH + 16 * kg;
+            for (int s_ = 0; s_ < CSTEPS; ++s_) { wn[s_][0] = wrow[4 * s_]; wn[s_][1] = wrow[4 * s_ + 1]; }
+        };
+        load_w(0);
+        for (int k = 0; k < ks; ++k) {
+            f32x4 w[CSTEPS][2];
+            unsigned wm = 0;
 #pragma unroll
             for (int s_ = 0; s_ < CSTEPS; ++s_) {
-                const u32x4 fh = *reinterpret_cast<const u32x4 *>(ah + 32 * s_), fl = *reinterpret_cast<const u32x4 *>(al + 32 * s_);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fh), __builtin_bit_cast(f16x8, Bh[s_]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fh), __builtin_bit_cast(f16x8, Bl[s_]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fl), __builtin_bit_cast(f16x8, Bh[s_]), acc, 0, 0, 0);
+                w[s_][0] = wn[s_][0]; w[s_][1] = wn[s_][1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wm = max(wm, max(__float_as_uint(w[s_][0][e]) & 0x7fffffffu, __float_as_uint(w[s_][1][e]) & 0x7fffffffu));
             }
-            // D^T: column = o (this lane's), rows r = (i & 3) + 8 (i >> 2) + 4 kg.  kg 0 assembles the pieces of rows 0-7 and 16-23, kg 1 those
-            // of rows 8-15 and 24-31: four values of each piece are the partner's
-            // (every select below picks between two NAMED values: written as acc[kg ? i : j] hipcc turns the choice into a dynamic index into
-            // the accumulator vector -- sixteen compare + select pairs per element, ~600 idle cycles of hazard padding per tile)
-            float av[16];
+            if (k + 1 < ks) load_w(k + 1);
+            wm = max(wm, (unsigned)__shfl_xor((int)wm, 32));
+            const float sW = pow2_scale(__uint_as_float(wm));
+            u32x4 Bh[CSTEPS], Bl[CSTEPS];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { av[i] = acc[i]; asm volatile("" : "+v"(av[i])); }
-            const bool hi = kg != 0;
-            float snd[8], rcv[8];
+            for (int s_ = 0; s_ < CSTEPS; ++s_) {
+                unsigned h[4], l[4];
+                split2(w[s_][0].x * sW, w[s_][0].y * sW, h[0], l[0]);
+                split2(w[s_][0].z * sW, w[s_][0].w * sW, h[1], l[1]);
+                split2(w[s_][1].x * sW, w[s_][1].y * sW, h[2], l[2]);
+                split2(w[s_][1].z * sW, w[s_][1].w * sW, h[3], l[3]);
+                Bh[s_] = (u32x4){h[0], h[1], h[2], h[3]};
+                Bl[s_] = (u32x4){l[0], l[1], l[2], l[3]};
+            }
+            const float tsc = s_out / (sF * sW);                            // (powers of two: exact)
+            for (int rt = 0; rt < rtiles; ++rt) {
+                f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { snd[e] = hi ? av[e] : av[4 + e]; snd[4 + e] = hi ? av[8 + e] : av[12 + e]; }
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                const int r = min(32 * rt + li, rch - 1);                    // (rows past the chunk: a valid LDS address, their pieces are not stored)
+                const unsigned char *ah = Fh + (size_t)r * PITCH + 16 * kg, *al = Fl + (size_t)r * PITCH + 16 * kg;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rcv[e] = __shfl_xor(snd[e], 32);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float own = (hi ? av[4 + 8 * half + e] : av[8 * half + e]) * tsc, got = rcv[4 * half + e] * tsc;
-                    v[e] = hi ? got : own;
-                    v[4 + e] = hi ? own : got;
+                for (int s_ = 0; s_ < CSTEPS; ++s_) {
+                    const u32x4 fh = *reinterpret_cast<const u32x4 *>(ah + 32 * s_), fl = *reinterpret_cast<const u32x4 *>(al + 32 * s_);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fh), __builtin_bit_cast(f16x8, Bh[s_]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fh), __builtin_bit_cast(f16x8, Bl[s_]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fl), __builtin_bit_cast(f16x8, Bh[s_]), acc, 0, 0, 0);
                 }
-                const int r0 = 32 * rt + 16 * half + 8 * kg;                 // first row of this piece
-                if (r0 < rows_b) {
-                    unsigned h[4], l[4];
+                // D^T: column = o (this lane's), rows r = (i & 3) + 8 (i >> 2) + 4 kg.  kg 0 assembles the pieces of rows 0-7 and 16-23, kg 1
+                // those of rows 8-15 and 24-31: four values of each piece are the partner's
+                // (every select below picks between two NAMED values: written as acc[kg ? i : j] hipcc turns the choice into a dynamic index
+                // into the accumulator vector -- sixteen compare + select pairs per element, ~600 idle cycles of hazard padding per tile)
+                float av[16];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
-                    const int kb = (r0 >> 4) * ks + k;                       // k-block of dense indices 16 kb .. + 15 = (k, rows 16 g .. + 15)
-                    u32x4 *dst = planes + (((size_t)z * kb_total + kb) * MT + mt) * 128 + li + 32 * kg;
-                    dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
-                    dst[64] = (u32x4){l[0], l[1], l[2], l[3]};
+                for (int i = 0; i < 16; ++i) { av[i] = acc[i]; asm volatile("" : "+v"(av[i])); }
+                const bool hi = kg != 0;
+                float snd[8], rcv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { snd[e] = hi ? av[e] : av[4 + e]; snd[4 + e] = hi ? av[8 + e] : av[12 + e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rcv[e] = __shfl_xor(snd[e], 32);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float own = (hi ? av[4 + 8 * half + e] : av[8 * half + e]) * tsc, got = rcv[4 * half + e] * tsc;
+                        v[e] = hi ? got : own;
+                        v[4 + e] = hi ? own : got;
+                    }
+                    const int r0 = rc0 + 32 * rt + 16 * half + 8 * kg;       // first row slot of this piece
+                    if (r0 < rc0 + nrows) {
+                        unsigned h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+                        const int kb = (r0 >> 4) * ks + k;                   // k-block of dense indices 16 kb .. + 15 = (k, rows 16 g .. + 15)
+                        u32x4 *dst = planes + (((size_t)z * kb_total + kb) * MT + mt) * 128 + li + 32 * kg;
+                        dst[0] = (u32x4){h[0], h[1], h[2], h[3]};
+                        dst[64] = (u32x4){l[0], l[1], l[2], l[3]};
+                    }
                 }
             }
         }
@@ -1222,8 +1229,7 @@ extern "C" int eap_so3_dense_untranspose_bnact_f32(int b, int o, int p, int na, 
 // n_rows [b] (may be null) -> scale [b][na][o] and the planes eap_so3_dense_product_f32 (dir 1) reads.  -> 0 also when the shape is not
 // taken (eap_so3_dense_gplanes_supported): the caller then makes G with a GEMM and eap_so3_dense_split_f32.
 extern "C" int eap_so3_dense_gplanes_supported(int o, int c, int na, int ks, int rp) {
-    return (o % 32) == 0 && (c == 64 || c == 128) && na > 0 && ks > 0 && (ks % 2) == 0 && rp > 0 && (rp % 16) == 0 &&
-           (size_t)rp * (2 * c + 16) * 2 <= 150u * 1024u;
+    return (o % 32) == 0 && (c == 64 || c == 128) && na > 0 && ks > 0 && (ks % 2) == 0 && rp > 0 && (rp % 16) == 0;
 }
 
 extern "C" int eap_so3_dense_gplanes_f32(int b, int o, int c, int na, int ks, int rp, const float *W3, const float *Ft, const int32_t *n_rows,
@@ -1233,13 +1239,17 @@ extern "C" int eap_so3_dense_gplanes_f32(int b, int o, int c, int na, int ks, in
         ((reinterpret_cast<uintptr_t>(W3) | reinterpret_cast<uintptr_t>(Ft) | reinterpret_cast<uintptr_t>(planes)) & 15) != 0)
         return eap::bad_arg("so3_dense_gplanes: shape not taken (eap_so3_dense_gplanes_supported), 16-byte aligned operands");
     const int kb_total = ceil_to(ks * rp, KC_BK) / 16;
-    const size_t shmem = (size_t)rp * (2 * c + 16) * 2;
+    // rows per LDS chunk (a multiple of 16): all of them where their two planes fit in 84 KB (144 rows at c = 128, 288 at c = 64: the bench
+    // layers in one piece, as before the chunking), else chunks of that size
+    const int fit = (int)((84u * 1024u) / ((size_t)(2 * c + 16) * 2)) / 16 * 16;
+    const int rch = min(rp, max(fit, 32));
+    const size_t shmem = (size_t)rch * (2 * c + 16) * 2;
     hipStream_t s = eap::S(stream);
     auto launch = [&](auto kern) -> int {
         if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
                                   "so3_dense_gplanes: shared memory attribute"))
             return e;
-        hipLaunchKernelGGL(kern, dim3(eap::cdiv(o / 32, 4), b * na), dim3(256), shmem, s, o, na, ks, rp, kb_total, W3, Ft, n_rows, bound, scale,
+        hipLaunchKernelGGL(kern, dim3(eap::cdiv(o / 32, 4), b * na), dim3(256), shmem, s, o, na, ks, rp, rch, kb_total, W3, Ft, n_rows, bound, scale,
                            reinterpret_cast<u32x4 *>(planes));
         return eap::check_launch("so3_dense_gplanes");
     };
