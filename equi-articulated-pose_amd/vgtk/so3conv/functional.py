@@ -930,7 +930,10 @@ class _InterConv(torch.autograd.Function):
             head.wait()
             if parts is None:
                 geo = _hip.DenseGeometry(geometry[0], geometry[1], head.memb, head.rows, rp, rk, sigma, idx.shape[2], head.n_rows)
-                if train_ep is not None and FUSE_CONV_NORM:
+                # (a frozen conv under a trainable norm -- gradients wanted for the norm's parameters only -- keeps the separate module:
+                # the node's backward is the conv's dense backward)
+                bn_only = grad_mode and not needs_grad and len(ctx.needs_input_grad) > 14 and (ctx.needs_input_grad[13] or ctx.needs_input_grad[14])
+                if train_ep is not None and FUSE_CONV_NORM and not bn_only:
                     g_, ldg, operand = _dense_g(_hip.rows_gather(feats, head.rows, geo.rp), W, geo)
                     y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, train_ep.moments, operand=operand, o=o)
                     del g_, operand

@@ -666,3 +666,32 @@ def test_many_rows_few_groups_take_the_dense_product(dev, monkeypatch):
     monkeypatch.setattr(L, 'DENSE_MAX_GROUPS', 4.0)
     _, _, _, log2, _ = _layer_run(dev, monkeypatch, 'auto', xyz, None, feats0, W0, c, o, radius, sigma)
     assert log2[0]['regime'] != 'dense rows'
+
+
+def test_frozen_conv_under_a_trainable_norm_keeps_the_separate_module(dev, monkeypatch):
+    """Gradients wanted for the norm's parameters only (conv weights and input frozen): the node's backward is the conv's dense backward, which
+    does not exist then -- conv_norm_act falls back to conv + norm module, and d gamma / d beta come out as from the modules."""
+    import synth_clouds
+    import vgtk.so3conv as sptk
+    import vgtk.spconv as zptk
+    B, P, c, o = 2, 512, 32, 256
+    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
+    xyz = torch.from_numpy(synth_clouds.laptop_batch(73, B, P)[0]).to(dev)
+    pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
+    gen = torch.Generator(device=dev).manual_seed(53)
+    feats = torch.randn(B, c, P, NA, device=dev, generator=gen)
+    gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
+    torch.manual_seed(2913)
+    conv = sptk.InterSO3PoseConv(c, o, 1, 1, radius, sigma, NN, kanchor=NA, permute_modes=1).to(dev)
+    conv.basic_conv.W.requires_grad_(False)
+    norm = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
+    x = zptk.SphericalPointCloudPose(xyz, feats, None, pose)
+    y = sptk.conv_norm_act(conv, norm, x)[3].feats
+    gw, gb = torch.autograd.grad(y, [norm.weight, norm.bias], gy)
+    with torch.no_grad():
+        raw = conv(x)[3].feats
+    norm2 = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
+    y2 = norm2(raw)
+    gw2, gb2 = torch.autograd.grad(y2, [norm2.weight, norm2.bias], gy)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(y.detach(), y2.detach()) < 1e-5 and rel(gw, gw2) < 2e-5 and rel(gb, gb2) < 2e-5
