@@ -286,7 +286,7 @@ def expected_scaling(world, ms_per_step, n_params):
     and rank the compute is the single-GPU step (weak scaling: the same clouds per GPU) plus
       * the gradient all-reduce (4 n_params bytes, ring over xGMI: 2 (N - 1) / N of the bytes per link at ~40 GB/s effective for
         a few-MB message + 2 (N - 1) hops of ~10 us), launched from autograd hooks: the deepest layer's bucket (89 % of the
-        bytes) travels under the ~25 ms of the two shallower layers' backward -- only the last, small bucket is exposed;
+        bytes) travels under the ~10 ms of the two shallower layers' backward -- only the last, small bucket is exposed;
       * one all-gather of 5.76 kB per cloud of pose hypotheses (latency-bound, ~(N - 1) x 10 us by the default ring);
       * 6 SyncBatchNorm moment exchanges (3 forward, 3 backward, <= 8 kB each): blocking, ~(N - 1) x 10 us each by the ring;
       * the max over ranks of box-to-box speed differences (+-3 % between boxes measured this round) and barrier skew.
