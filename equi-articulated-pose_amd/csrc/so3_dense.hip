@@ -729,40 +729,6 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int nb, int o_to
     }
 }
 
-// Yt'[b][a][p][o] (the transposed tile of kc_gemm_kernel SWAP: channels contiguous) -> Y[b][o][p_dst][a] with y = leaky(bn_scale[o] yt + bn_shift[o])
-// on the way (bn_scale null: plain copy).  Block = (4 consecutive columns p, 64 channels, cloud) through a [na][4][65] LDS tile: reads 256-byte
-// runs of channels, writes the 240-byte rows of (channel, point) as 16-byte pieces; map as dense_untranspose_kernel's.
-constexpr int UPO_P = 4, UPO_O = 64;
-__global__ __launch_bounds__(256) void dense_untranspose_po_kernel(int o_total, int p, int na, int p_dst, const int32_t *__restrict__ map,
-                                                                   const float *__restrict__ ytp, float *__restrict__ y,
-                                                                   const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float slope) {
-    extern __shared__ float tile[];                                         // [na][UPO_P][UPO_O + 1]
-    const int ochunks = o_total / UPO_O, pchunks = (p + UPO_P - 1) / UPO_P, t = threadIdx.x;
-    const int oc = (int)(blockIdx.x % (unsigned)ochunks), rest = (int)(blockIdx.x / (unsigned)ochunks), pc = rest % pchunks, b = rest / pchunks;
-    const int o0 = oc * UPO_O, p0 = pc * UPO_P, np = min(UPO_P, p - p0);
-    for (int i = t; i < na * UPO_P * UPO_O; i += 256) {
-        const int oo = i & (UPO_O - 1), pp = (i >> 6) & (UPO_P - 1), a = i >> 8;
-        if (pp < np) {
-            float v = ytp[(((size_t)b * na + a) * p + p0 + pp) * o_total + o0 + oo];
-            if (bn_scale != nullptr) {
-                const float u = fmaf(v, bn_scale[o0 + oo], bn_shift[o0 + oo]);
-                v = u > 0.f ? u : u * slope;
-            }
-            tile[(a * UPO_P + pp) * (UPO_O + 1) + oo] = v;
-        }
-    }
-    __syncthreads();
-    const int nq = na >> 2;
-    for (int i = t; i < UPO_O * np * nq; i += 256) {
-        const int a4 = i % nq, row = i / nq, pp = row % np, oo = row / np;
-        const int q = map ? map[(size_t)b * p + p0 + pp] : p0 + pp;
-        if (map != nullptr && (unsigned)q >= (unsigned)p_dst) continue;
-        const float *src = tile + ((4 * a4) * UPO_P + pp) * (UPO_O + 1) + oo;
-        constexpr int AS = UPO_P * (UPO_O + 1);
-        *reinterpret_cast<f32x4 *>(y + (((size_t)b * o_total + o0 + oo) * (size_t)(map ? p_dst : p) + q) * na + 4 * a4) = (f32x4){src[0], src[AS], src[2 * AS], src[3 * AS]};
-    }
-}
-
 // Z[b][o][k][a][r] = 0 for the row slots r >= ceil16(n_rows[b]) the trimmed backward product does not write (the GEMMs that follow
 // contract over them against zero feature rows: 0 x garbage must not be NaN)
 __global__ __launch_bounds__(256) void dense_zero_tail_kernel(int rows_ok, int na, int rp, long long ldz, const int32_t *__restrict__ n_rows,
@@ -794,18 +760,12 @@ struct KcArgs {
     float *C; long long cB, cA, ldm; int rp; long long kstride;     // element (row, n) of (b, a) at C[b cB + a cA + row ldm + (n / rp) kstride + n % rp]
     int row_slots;                        // row slots of the dense index range (the launcher's rp; `rp` above is the output's column split)
     const int32_t *steps;                 // (may be null) [b][blocks_n][KS + 1]: count, then the k-steps this column block runs (dense_steps_kernel)
-    const float *pivot; float *psum, *psq; long long mstride;      // SWAP: per-channel pivot (may be null), partial moments [channel][mstride] at z blocks_n + bn
 };
 
 // DBG (timing ablations, `make ABLATION=1` + EAP_DENSE_DEBUG, WRONG results): 1 = no mask (all lanes kept), 2 = no k-side table
 // reads (constants), 4 = no weight evaluation at all (the B fragments of the prologue for every k-block), 8 = no DMA inside the k-loop,
 // 16 = no fragment reads of the stored operand inside the k-loop
-// SWAP (forward only): the two operands of v_mfma_f32_32x32x16_f16 have the same per-lane format (8 consecutive contraction elements), so the
-// products can be issued with the GENERATED operand as A and the STORED one as B: the accumulators then hold the transposed tile -- a lane
-// owns one output CHANNEL per row tile and 32 of the block's points.  The channel moments a BatchNorm behind the layer needs are lane-private
-// sums (+ one exchange with the lane 32 away, + the four waves through LDS), and the tile is stored as Yt'[b][a][point][channel] (a wave
-// store covers 128 contiguous bytes of channels).  The statistics pass over the 4 GB output is gone.
-template <int MI, int FORM, int DBG = 0, int SWAP = 0>
+template <int MI, int FORM, int DBG = 0>
 __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g) {
     static_assert(MI == 8 || MI == 4, "the DMA piece schedule below: 8 or 4 KB of the stored operand per wave and k-step");
     constexpr unsigned WB = MI * 1024u;                    // bytes of the stored operand a wave moves per k-step
@@ -967,8 +927,7 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
         }
     };
     auto mm = [&](const u32x4 &fa, const u32x4 &fb, f32x16 &c) __attribute__((always_inline)) {
-        if constexpr (SWAP) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb), __builtin_bit_cast(f16x8, fa), c, 0, 0, 0);
-        else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb), c, 0, 0, 0);
     };
 #define SB() __builtin_amdgcn_sched_barrier(0)
     // issue order inside a product: one matrix instruction, then NV vector instructions in its shadow (hipcc on its own puts the
@@ -1082,44 +1041,6 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
     float *isc = reinterpret_cast<float *>(smem);
     if (t < 32 * MI) isc[t] = 1.0f / g.scale[(size_t)z * (32 * g.MT) + 32 * MI * bm + t];
     __syncthreads();
-    if constexpr (SWAP) {
-        // transposed tile: acc[i][j][r] = Y[channel 32 (MI bm + i) + li][point 64 wt + 32 j + (r & 3) + 8 (r >> 2) + 4 kg]
-        float *red = isc + 32 * MI;                         // [wave][32 MI][2]
-        float *Cz = g.C + b * g.cB + a * g.cA;              // Yt'[b][a][point][channel]
-        const int O = 32 * g.MT;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int cl = 32 * i + li, ch = 32 * MI * bm + cl;
-            const float sc = isc[cl], piv = g.pivot ? g.pivot[ch] : 0.f;
-            float s_ = 0.f, q_ = 0.f;
-            if (active) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pnt = 64 * wt + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        if (pnt < N) {
-                            const float v = acc[i][j][r] * sc, d = v - piv;
-                            Cz[(long long)pnt * O + ch] = v;
-                            s_ += d;
-                            q_ = fmaf(d, d, q_);
-                        }
-                    }
-            }
-            s_ += __shfl_xor(s_, 32);
-            q_ += __shfl_xor(q_, 32);
-            if (kg == 0) { red[(wave * 32 * MI + cl) * 2] = s_; red[(wave * 32 * MI + cl) * 2 + 1] = q_; }
-        }
-        __syncthreads();
-        if (t < 32 * MI) {                                   // (fixed order: bit-reproducible)
-            float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-            for (int w_ = 0; w_ < 4; ++w_) { s_ += red[(w_ * 32 * MI + t) * 2]; q_ += red[(w_ * 32 * MI + t) * 2 + 1]; }
-            const size_t at = (size_t)(32 * MI * bm + t) * g.mstride + (size_t)z * g.blocks_n + bn;
-            g.psum[at] = s_; g.psq[at] = q_;
-        }
-        return;
-    }
     if (!active) return;
     float *Cz = g.C + b * g.cB + a * g.cA + (long long)(32 * MI * bm) * g.ldm;
 #pragma unroll
@@ -1139,7 +1060,7 @@ __global__ __launch_bounds__(256, MI == 4 ? 2 : 1) void kc_gemm_kernel(KcArgs g)
     }
 }
 
-template <int MI, int FORM, int DBG = 0, int SWAP = 0>
+template <int MI, int FORM, int DBG = 0>
 int kc_launch(const KcArgs &g, hipStream_t s) {
     constexpr size_t shmem = 4 * (2 * (size_t)MI * 2048u + 2048u) + KC_LIST_BYTES;      // the ring + the k-step list
     // per DEVICE (a process may drive several GPUs: the attribute belongs to the function object of the current device) and
@@ -1149,16 +1070,15 @@ int kc_launch(const KcArgs &g, hipStream_t s) {
     if (int e = eap::hip_fail(hipGetDevice(&dev), "so3_dense: hipGetDevice")) return e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(set_on.load(std::memory_order_acquire) & bit)) {
-        if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_gemm_kernel<MI, FORM, DBG, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_gemm_kernel<MI, FORM, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       (int)shmem), "so3_dense: shared memory attribute"))
             return e;
         set_on.fetch_or(bit, std::memory_order_release);
     }
     const long long blocks = (long long)g.zcount * g.tiles_m * g.blocks_n;
     if (blocks > 0x7fffffffLL) return eap::bad_arg("so3_dense: too many workgroups");
-    hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM, DBG, SWAP>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
-    if (SWAP) eap::set_kernel(MI == 8 ? "kc_gemm_kernel<8, 1, 0, 1>" : "kc_gemm_kernel<4, 1, 0, 1>");
-    else eap::set_kernel(MI == 8 ? (FORM ? "kc_gemm_kernel<8, 1>" : "kc_gemm_kernel<8, 0>") : (FORM ? "kc_gemm_kernel<4, 1>" : "kc_gemm_kernel<4, 0>"));
+    hipLaunchKernelGGL((kc_gemm_kernel<MI, FORM, DBG>), dim3((unsigned)blocks), dim3(256), shmem, s, g);
+    eap::set_kernel(MI == 8 ? (FORM ? "kc_gemm_kernel<8, 1>" : "kc_gemm_kernel<8, 0>") : (FORM ? "kc_gemm_kernel<4, 1>" : "kc_gemm_kernel<4, 0>"));
     return eap::check_launch("so3_dense product");
 }
 
@@ -1336,11 +1256,10 @@ extern "C" int eap_so3_dense_gplanes_f32(int b, int o, int c, int na, int ks, in
     return c == 128 ? launch(dense_gplanes_kernel<8>) : launch(dense_gplanes_kernel<4>);
 }
 
-namespace {
-// psum != null: the forward with the transposed tile (kc_gemm_kernel SWAP): out = Yt'[b][a][p][o], partial channel moments of (y - pivot[channel])
-int dense_product_impl(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
-                       const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask,
-                       const int32_t *steps, float *out, const float *pivot, float *psum, float *psq, eap_stream_t stream) {
+// steps (may be null): the k-step lists of eap_so3_dense_steps for this direction -- column blocks run their listed k-steps only
+extern "C" int eap_so3_dense_product_steps_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
+                                               const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask,
+                                               const int32_t *steps, float *out, eap_stream_t stream) {
     if (b <= 0) return 0;
     if (!eap_so3_dense_supported(p, na, ks, rp, o)) return eap::bad_arg("so3_dense_product: shape not taken (eap_so3_dense_supported)");
     const int p_pad = ceil_to(p, KC_BK), kd_pad = ceil_to(ks * rp, KC_BK);
@@ -1367,7 +1286,6 @@ int dense_product_impl(int dir, int b, int o, int p, int na, int ks, int rp, int
     }
     g.mask = reinterpret_cast<const unsigned *>(mask);
     g.steps = (steps != nullptr && g.KS <= KC_LIST_BYTES / 4) ? steps : nullptr;      // (longer contraction axes run every k-step)
-    g.pivot = pivot; g.psum = psum; g.psq = psq; g.mstride = (long long)g.zcount * g.blocks_n;
     g.C = out;
     g.neg_inv_sigma = -1.0f / sigma;
     g.n_rows = n_rows; g.ks = ks; g.trim = dir ? 2 : 1;       // (columns / k axis are dense indices either way; without n_rows every slot counts)
@@ -1391,32 +1309,8 @@ int dense_product_impl(int dir, int b, int o, int p, int na, int ks, int rp, int
         }
     }
 #endif
-    if (psum != nullptr) {
-        if (dir != 1 || !g_dense_form || psq == nullptr) return eap::bad_arg("so3_dense_product_moments: the forward (dir 1) with the default weight form");
-        return wide ? kc_launch<8, 1, 0, 1>(g, eap::S(stream)) : kc_launch<4, 1, 0, 1>(g, eap::S(stream));
-    }
     if (!wide) return g_dense_form ? kc_launch<4, 1>(g, eap::S(stream)) : kc_launch<4, 0>(g, eap::S(stream));
     return g_dense_form ? kc_launch<8, 1>(g, eap::S(stream)) : kc_launch<8, 0>(g, eap::S(stream));
-}
-}  // namespace
-
-// steps (may be null): the k-step lists of eap_so3_dense_steps for this direction -- column blocks run their listed k-steps only
-extern "C" int eap_so3_dense_product_steps_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
-                                               const void *planes, const float *scale, const float *pt, const float *kr, const uint64_t *mask,
-                                               const int32_t *steps, float *out, eap_stream_t stream) {
-    return dense_product_impl(dir, b, o, p, na, ks, rp, ldz, sigma, n_rows, planes, scale, pt, kr, mask, steps, out, nullptr, nullptr, nullptr, stream);
-}
-
-// The forward product with its tile transposed (kc_gemm_kernel SWAP): ytp = Yt'[b][na][p][o] (channels contiguous) and the partial moments
-// psum / psq float [o][b na blocks], blocks = eap_so3_dense_moments_blocks(p), of (y - pivot[channel]) (pivot float [o], may be null: 0) --
-// what the BatchNorm behind the layer starts from, without a pass over the output (summed by the caller in float64, fixed order).
-extern "C" int eap_so3_dense_moments_blocks(int p) { return (p + 255) / 256; }
-
-extern "C" int eap_so3_dense_product_moments_f32(int b, int o, int p, int na, int ks, int rp, float sigma, const int32_t *n_rows, const void *planes,
-                                                 const float *scale, const float *pt, const float *kr, const uint64_t *mask, const int32_t *steps,
-                                                 const float *pivot, float *ytp, float *psum, float *psq, eap_stream_t stream) {
-    if (psum == nullptr || psq == nullptr) return eap::bad_arg("so3_dense_product_moments: the partial arrays");
-    return dense_product_impl(1, b, o, p, na, ks, rp, 0, sigma, n_rows, planes, scale, pt, kr, mask, steps, ytp, pivot, psum, psq, stream);
 }
 
 extern "C" int eap_so3_dense_product_f32(int dir, int b, int o, int p, int na, int ks, int rp, int64_t ldz, float sigma, const int32_t *n_rows,
@@ -1450,22 +1344,6 @@ extern "C" int eap_so3_dense_steps(int b, int p, int ks, int rp, int dir, int sk
     hipLaunchKernelGGL(dense_steps_kernel, dim3(blocks_n, b), dim3(256), sizeof(int) * (size_t)KS, eap::S(stream), KS, blocks_n, 4 * blocks_n, dir, ks, rp, skip,
                        n_rows, reinterpret_cast<const unsigned *>(mask), steps);
     return eap::check_launch("so3_dense_steps");
-}
-
-// The re-ordering pass for eap_so3_dense_product_moments_f32's output: ytp [b][na][p][o] -> y [b][o][p_dst][na], y = leaky(bn_scale[o] yt + bn_shift[o])
-// on the way (bn_scale / bn_shift null: plain); map int32 [b,p] (may be null: p_dst = p) as eap_so3_dense_untranspose_map_f32's.  o % 64 == 0.
-extern "C" int eap_so3_dense_untranspose_po_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *ytp, const float *bn_scale,
-                                                const float *bn_shift, float slope, float *y, eap_stream_t stream) {
-    if (b <= 0) return 0;
-    const long long blocks = (long long)(o / UPO_O) * ((p + UPO_P - 1) / UPO_P) * b;
-    if ((o % UPO_O) != 0 || (na % 4) != 0 || blocks > 0x7fffffffLL || (map != nullptr && p_dst <= 0) || (map == nullptr && p_dst != p) || (bn_scale == nullptr) != (bn_shift == nullptr))
-        return eap::bad_arg("so3_dense_untranspose_po: o % 64, na % 4, p_dst = p without a map, scale and shift together");
-    const size_t shmem = sizeof(float) * (size_t)na * UPO_P * (UPO_O + 1);
-    if (int e = eap::hip_fail(hipFuncSetAttribute(reinterpret_cast<const void *>(dense_untranspose_po_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
-                              "so3_dense_untranspose_po: shared memory attribute"))
-        return e;
-    hipLaunchKernelGGL(dense_untranspose_po_kernel, dim3((unsigned)blocks), dim3(256), shmem, eap::S(stream), o, p, na, p_dst, map, ytp, y, bn_scale, bn_shift, slope);
-    return eap::check_launch("so3_dense_untranspose_po");
 }
 
 // psum, psq (may be null): float [o][b * ceil(p / 64)] partial sums of (y - y[0,o,0,0]) and of its square per 64-point chunk

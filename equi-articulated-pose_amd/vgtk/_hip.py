@@ -725,40 +725,11 @@ def _dense_fwd_yt(g, geo, p, c, ldg, operand, o):
     return yt
 
 
-# The forward product with its tile transposed (kc_gemm_kernel SWAP): the channel moments of a training-mode BatchNorm behind the layer come
-# out of the product's epilogue, no statistics pass over Yt (include/eap_hip.h: eap_so3_dense_product_moments_f32).  '0': the statistics pass.
-SWAP_FORWARD = os.environ.get('EAP_DENSE_SWAP', '1') != '0'
-
-
-def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments, operand=None, o=None, affine=None, pivot=None):
+def so3_dense_fwd_bnact(g, geo, p, c, ldg, norm_moments, operand=None, o=None, affine=None):
     """The dense forward with the training-mode BatchNorm + leaky_relu behind it applied by the re-ordering pass (the conv + BatchNorm
     node of vgtk/so3conv/functional.py): product -> Yt; statistics pass over Yt; norm_moments(s1, s2, pivot, count) -> (scale, shift, slope)
     per channel (float32 [o]); y' = leaky(scale y + shift) written through the geometry's point order.  affine = (scale, shift, slope)
     instead of norm_moments: an inference-mode norm folded into one per-channel map (FoldedEpilogue), no statistics pass.  -> y' [b,o,p,na]"""
-    o_ = g.shape[1] if operand is None else o
-    if SWAP_FORWARD and affine is None and o_ % 64 == 0 and lib.eap_so3_dense_form(-1) == 1:
-        # pivot float32 [o] (any value near the channel means keeps the moments well conditioned: the norm's running mean; None: 0)
-        na, b = geo.na, geo.b
-        if operand is None:
-            ldg_ = geo.rp * na if ldg is None else int(ldg)
-            scale, planes = so3_dense_split(g, seg=geo.rp, seg_pitch=ldg_, shape=(b, o_, geo.ks * geo.rp, na), mapped=True, n_rows=geo.n_rows)
-        else:
-            scale, planes = operand
-        nblk = int(lib.eap_so3_dense_moments_blocks(p))
-        ytp = torch.empty(b, na, p, o_, dtype=torch.float32, device=planes.device)
-        ps = torch.empty(o_, b * na * nblk, dtype=torch.float32, device=planes.device)
-        pq = torch.empty_like(ps)
-        piv = None if pivot is None else pivot.detach().to(torch.float32).contiguous().clone()
-        call('eap_so3_dense_product_moments_f32', ytp, b, o_, p, na, geo.ks, geo.rp, _F32(geo.sigma), _ptr(geo.n_rows), _ptr(planes), _ptr(scale), _ptr(geo.pt), _ptr(geo.kr),
-             _ptr(geo.mask(1)), _ptr(geo.steps(1)), _ptr(piv), _ptr(ytp), _ptr(ps), _ptr(pq),
-             tag={'flops': 2.0 * b * c * geo.ks * na * (p * geo.nn + o_ * p - o_ * geo.rp), 'executed_f16_flops': _dense_executed_flops(geo, o_, p, 1),
-                  'shape': ('so3_dense', 1, b, o_, p, na, geo.ks, geo.rp)})
-        del planes
-        zero = torch.zeros(o_, dtype=torch.float64, device=ytp.device)
-        bn_scale, bn_shift, slope = norm_moments(ps.sum(1, dtype=torch.float64), pq.sum(1, dtype=torch.float64), zero if piv is None else piv.double(), b * na * p)
-        y = torch.empty(b, o_, p, na, dtype=torch.float32, device=ytp.device)
-        call('eap_so3_dense_untranspose_po_f32', ytp, b, o_, p, na, p, _ptr(geo.order), _ptr(ytp), _ptr(bn_scale), _ptr(bn_shift), _F32(slope), _ptr(y))
-        return y
     yt = _dense_fwd_yt(g, geo, p, c, ldg, operand, o)
     b, na, o = yt.shape[0], geo.na, yt.shape[2]
     if affine is not None:

@@ -935,7 +935,7 @@ class _InterConv(torch.autograd.Function):
                 bn_only = grad_mode and not needs_grad and len(ctx.needs_input_grad) > 14 and (ctx.needs_input_grad[13] or ctx.needs_input_grad[14])
                 if train_ep is not None and FUSE_CONV_NORM and not bn_only:
                     g_, ldg, operand = _dense_g(_hip.rows_gather(feats, head.rows, geo.rp), W, geo)
-                    y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, train_ep.moments, operand=operand, o=o, pivot=train_ep.norm.running_mean)
+                    y = _hip.so3_dense_fwd_bnact(g_, geo, p, c, ldg, train_ep.moments, operand=operand, o=o)
                     del g_, operand
                     train_ep.applied = True
                     ctx.bn = train_ep.saved + (float(train_ep.norm.negative_slope), bool(train_ep.norm.sync))

@@ -407,16 +407,6 @@ int eap_so3_dense_untranspose_bnact_f32(int b, int o, int p, int na, int p_dst, 
 int eap_so3_dense_gplanes_supported(int o, int c, int na, int ks, int rp);
 int eap_so3_dense_gplanes_f32(int b, int o, int c, int na, int ks, int rp, const float *W3, const float *Ft, const int32_t *n_rows,
                               const float *bound, float *scale, void *planes, eap_stream_t stream);
-/* the forward product with its tile TRANSPOSED (generated operand as A, stored as B: same per-lane operand format): ytp = Yt'[b][na][p][o] and the
- * partial channel moments psum / psq float [o][b na eap_so3_dense_moments_blocks(p)] of (y - pivot[channel]) (pivot float [o] or null) -- a lane of
- * the transposed tile owns one channel, so the moments the BatchNorm behind the layer needs are lane-private sums and the statistics pass
- * over the output disappears; eap_so3_dense_untranspose_po_f32 re-orders that layout into Y [b][o][p_dst][na] (optionally normalising). */
-int eap_so3_dense_moments_blocks(int p);
-int eap_so3_dense_product_moments_f32(int b, int o, int p, int na, int ks, int rp, float sigma, const int32_t *n_rows, const void *planes,
-                                      const float *scale, const float *pt, const float *kr, const uint64_t *mask, const int32_t *steps,
-                                      const float *pivot, float *ytp, float *psum, float *psq, eap_stream_t stream);
-int eap_so3_dense_untranspose_po_f32(int b, int o, int p, int na, int p_dst, const int32_t *map, const float *ytp, const float *bn_scale,
-                                     const float *bn_shift, float slope, float *y, eap_stream_t stream);
 int eap_so3_dense_point_keys(int b, int p, const uint32_t *memb, int32_t *keys, eap_stream_t stream);
 int64_t eap_so3_dense_steps_words(int b, int p, int ks, int rp, int dir);
 int eap_so3_dense_steps(int b, int p, int ks, int rp, int dir, int skip, const int32_t *n_rows, const uint64_t *mask, int32_t *steps,

@@ -695,48 +695,3 @@ def test_frozen_conv_under_a_trainable_norm_keeps_the_separate_module(dev, monke
     gw2, gb2 = torch.autograd.grad(y2, [norm2.weight, norm2.bias], gy)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     assert rel(y.detach(), y2.detach()) < 1e-5 and rel(gw, gw2) < 2e-5 and rel(gb, gb2) < 2e-5
-
-
-@pytest.mark.parametrize('c,o', [(128, 256), (64, 128)])
-def test_forward_with_the_transposed_tile_and_epilogue_moments(dev, monkeypatch, c, o):
-    """vgtk._hip.SWAP_FORWARD: the conv + norm node's forward on eap_so3_dense_product_moments_f32 (the products issued with the generated
-    operand as A: transposed tile, channel moments from the product's epilogue, Yt'[b,a,p,o]) + eap_so3_dense_untranspose_po_f32, against the
-    same node with the statistics pass over Yt: y', the gradients (they see the same y'), the running statistics; no eap_bn_stats_f32 launch;
-    a pivot far from the channel means (running_mean set to 3) must not matter."""
-    import synth_clouds
-    import vgtk.so3conv as sptk
-    import vgtk.spconv as zptk
-    import vgtk.so3conv.functional as L
-    from vgtk import _hip
-    B, P = 2, 512
-    _, _, radius, sigma = synth_clouds.backbone_layers(4096)[2]
-    xyz = torch.from_numpy(synth_clouds.laptop_batch(75, B, P)[0]).to(dev)
-    pose = torch.eye(4, device=dev).repeat(B, P, 1, 1)
-    gen = torch.Generator(device=dev).manual_seed(59)
-    feats0 = torch.randn(B, c, P, NA, device=dev, generator=gen)
-    W0 = torch.randn(o, c * KS, device=dev, generator=gen) * 0.05
-    gy = torch.randn(B, o, P, NA, device=dev, generator=gen)
-    out = {}
-    for swap in (False, True):
-        monkeypatch.setattr(_hip, 'SWAP_FORWARD', swap)
-        torch.manual_seed(2913)
-        conv = sptk.InterSO3PoseConv(c, o, 1, 1, radius, sigma, NN, kanchor=NA, permute_modes=1).to(dev)
-        norm = sptk.BatchNormLeakyReLU(o, negative_slope=0.01).to(dev)
-        with torch.no_grad():
-            conv.basic_conv.W.copy_(W0)
-            norm.weight.uniform_(0.5, 1.5); norm.bias.uniform_(-0.3, 0.3)
-            norm.running_mean.fill_(3.0)
-        feats = feats0.clone().requires_grad_(True)
-        launched = []
-        _hip.KERNEL_TIMES = launched
-        try:
-            y = sptk.conv_norm_act(conv, norm, zptk.SphericalPointCloudPose(xyz, feats, None, pose))[3].feats
-            grads = torch.autograd.grad(y, [feats, conv.basic_conv.W, norm.weight, norm.bias], gy)
-        finally:
-            _hip.KERNEL_TIMES = None
-        names = [n for n, *_ in launched]
-        assert ('eap_so3_dense_product_moments_f32' in names) == swap and ('eap_bn_stats_f32' in names) == (not swap), names
-        out[swap] = (y.detach(),) + grads + (norm.running_mean.clone(), norm.running_var.clone())
-    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-    for a_, b_, bar in zip(out[True], out[False], (1e-5, 2e-5, 5e-5, 2e-5, 2e-5, 1e-5, 1e-5)):
-        assert rel(a_, b_) < bar, (rel(a_, b_), bar)

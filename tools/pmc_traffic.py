@@ -23,10 +23,8 @@ def key_of(name):
         elif ch == '(' and depth == 0:
             break
         out += ch
-    if out.startswith('gemm_dma_f32_kernel'):
+    if out.startswith('gemm_dma_f32_kernel') or out.startswith('kc_gemm_kernel'):
         out = re.sub(r',\s*0>$', '>', out)      # trailing default template argument of the GEMM (ablation switch)
-    if out.startswith('kc_gemm_kernel'):        # <MI, FORM, ablation switch, SWAP>: '<8, 1, 0, 0>' is eap_last_kernel()'s '<8, 1>', the swapped forward keeps all four
-        out = re.sub(r',\s*0,\s*0>$', '>', out)
     m = re.match(r'(gemm_bf16x3_kernel|gemm_f16x2_kernel)<(\d+), (\d+), \d+, (\d+)(?:, (?:true|false))?>$', out)
     if m:                                       # <MI, WN, ablation switch, B layout, pre-split weights> -> the name eap_last_kernel() reports
         out = '%s<%s, %s%s>' % (m.group(1), m.group(2), m.group(3), ('', ', nn', ', gather')[int(m.group(4))])
