@@ -682,7 +682,8 @@ __global__ __launch_bounds__(256) void dense_untranspose_kernel(int nb, int o_to
     extern __shared__ float tile[];
     __shared__ float red[2][256];
     // block -> (chunk of 64 columns fastest, o, b).  (An XCD-owning map -- all chunks of one (o, b) in one L2 -- did not help the mapped
-    // pass: 3.45 -> 3.51 ms; 16-byte stores did: 3.51 -> 2.93, against 2.1-2.2 for the unmapped pass.)
+    // pass: 3.45 -> 3.51 ms with dword stores, 2.81 / 2.81 against 2.86 / 2.75 ms with the 16-byte stores that did: 3.51 -> 2.93, against
+    // 2.1-2.2 for the unmapped pass.)
     const int chunks = (p + 63) >> 6, t = threadIdx.x;
     const int p0 = (int)(blockIdx.x % (unsigned)chunks) * 64, grp_ = (int)(blockIdx.x / (unsigned)chunks), o = grp_ % o_total, b = grp_ / o_total;
     const int nchunk_x = chunks, nb_z = nb;
